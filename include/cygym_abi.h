@@ -1,0 +1,184 @@
+/* cygym_abi.h -- C ABI of libcygym_hip.so: the batched, MI355X-native tick of
+ * CyGym's Volt_Typhoon_CyberDefenseEnv.
+ *
+ * Plain C across the boundary: pointers, sizes, PODs.  No torch / C++ types.
+ * Every device buffer is CALLER-OWNED (the Python host allocates torch tensors
+ * and passes tensor.data_ptr()); the library never allocates or frees HBM except
+ * for its private copy of the (<= ~100 KB) shared topology made in cygym_create.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to
+ * the reference checkout).  The reference has no FFI of its own -- it is 100 %
+ * Python -- so "what the reference's FFI would bind" is the method surface of the
+ * environment object; INTEGRATION.md shows the ctypes stub a maintainer would add.
+ *
+ * Conventions
+ *   * every function returns 0 on success, a negative CYGYM_E* code otherwise;
+ *     cygym_last_error() gives the message; nothing throws or aborts.
+ *   * calls on one handle are stream-ordered and asynchronous w.r.t. the host;
+ *     they are not thread-safe per handle.  Distinct handles (one per GPU /
+ *     process) are independent.
+ *   * N = number of envs of this handle (one shard), M = devices per env,
+ *     X = exploits, E = directed edges of the shared cached adjacency.
+ */
+#ifndef CYGYM_ABI_H
+#define CYGYM_ABI_H
+
+#include <stdint.h>
+#include "cygym_spec.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CYGYM_ABI_VERSION 1
+
+#define CYGYM_OK            0
+#define CYGYM_EINVAL       -1  /* bad argument / shape                       */
+#define CYGYM_EHIP         -2  /* a HIP runtime call failed                  */
+#define CYGYM_EUNSUPPORTED -3  /* configuration outside the implemented path */
+#define CYGYM_ENOTBOUND    -4  /* cygym_bind not called                      */
+
+/* Shared topology + static per-device columns (HOST pointers; copied at create).
+ * Flattening of Subnet.net / Subnet.graph as cached by
+ * volt_typhoon_env.py:456-473 (_outnbrs/_innbrs, neighbour order preserved) and
+ * of the static Device/App/Vulnerability/Exploit attributes the tick reads
+ * (CDSimulatorComponents.py:120-127, 217-243, 491-531). */
+typedef struct cygym_topology {
+  int32_t n_devices;        /* M  (= Max_network_size = len(subnet.net))       */
+  int32_t n_exploits;       /* X  (= len(simulator.exploits)) <= 6             */
+  int32_t n_edges;          /* E                                                */
+  int32_t reserved0;
+  const uint8_t* dstatic;   /* [M] CG_D_DC | CG_D_SERVER                        */
+  const uint8_t* vuln;      /* [M] bit e: an app vuln id is in exploits[e].target */
+  const uint8_t* napps;     /* [M] len(device.apps)                             */
+  const float*   os_val;    /* [M] os_to_float(device.OS)  CyberDefenseEnv.py:125 */
+  const float*   version;   /* [M] float(device.version) or -1                  */
+  const float*   anomaly;   /* [M] device.anomaly_score (static on fast-scan path) */
+  const int32_t* out_ptr;   /* [M+1] CSR of _outnbrs                            */
+  const int32_t* out_col;   /* [E]                                              */
+  const int32_t* in_ptr;    /* [M+1] CSR of _innbrs                             */
+  const int32_t* in_col;    /* [E]                                              */
+  const int32_t* in_eid;    /* [E] out-CSR slot of each in-entry (blocked bit)  */
+} cygym_topology;
+
+/* Scalar knobs: plain attributes of the reference env object
+ * (volt_typhoon_env.py:32-117, CyberDefenseEnv.py:19-62). */
+typedef struct cygym_config {
+  uint64_t seed;                 /* Philox key                                  */
+  int64_t  env_id_base;          /* global id of env 0 of this shard            */
+  int32_t  num_of_device;        /* env.numOfDevice                             */
+  int32_t  min_network_size;     /* env.Min_network_size                        */
+  int32_t  max_exploits;         /* env.MaxExploits                             */
+  int32_t  evolve_period;        /* env._evolve_period                          */
+  int32_t  workload_cap;         /* env.workload_cap, -1 = None                 */
+  int32_t  workload_period_base; /* env.workload_period_base                    */
+  int32_t  workload_period_max;  /* env.workload_period_max                     */
+  int32_t  scaling_vulnerability;/* env.scaling_vulnerability                   */
+  int32_t  fast_scan;            /* env.fast_scan (must be 1)                   */
+  int32_t  n_att_actions;        /* env.attacker_action_space.n                 */
+  int32_t  n_def_actions;        /* env.defender_action_space.n                 */
+  int32_t  zero_day;             /* env.zero_day                                */
+  int32_t  zero_day_owned_mask;  /* bit i: i in common|private exploit indices  */
+  int32_t  default_high;         /* env.default_high                            */
+  int32_t  baseline;             /* 0 Nash, 1 No Defense, 2 Preset, 3 No Attack */
+  int32_t  auto_reset;           /* 1: reload snapshot when done (batched only) */
+  int32_t  episode_limit;        /* done iff step_num > limit (1000) CyberDefenseEnv.py:549 */
+  int32_t  reserved1;
+  double   work_scale, comp_scale, def_scale, gamma;
+  uint64_t p_add_thr;            /* ceil(p_add * 2^32)      CyberDefenseEnv.py:679 */
+  uint64_t p_attacker_thr;       /* ceil(p_attacker * 2^32) CyberDefenseEnv.py:690 */
+  uint64_t poisson_thr[CG_POISSON_TABLE]; /* np.random.poisson(lambda_events) :668 */
+  uint64_t tri_thr[CG_TRI_TABLE];         /* ceil(triangular(0,2,5)) CDSimulator.py:308 */
+} cygym_config;
+
+/* Per-env mutable state, struct-of-arrays, DEVICE pointers (caller-owned). */
+typedef struct cygym_buffers {
+  uint8_t*  flags;      /* [N][M] CG_F_*                                        */
+  uint8_t*  busy;       /* [N][M] Device.busy_time (saturates at 255)           */
+  uint8_t*  wl;         /* [N][M] Workload.processing_time, 0 = no workload     */
+  uint8_t*  comp_by;    /* [N][M] bitmask over exploit index                    */
+  uint8_t*  st_flags;   /* [N][M] stash (actions 11/12) volt_typhoon_env.py:419 */
+  uint8_t*  st_busy;    /* [N][M]                                               */
+  uint8_t*  st_wl;      /* [N][M]                                               */
+  uint8_t*  st_comp_by; /* [N][M]                                               */
+  uint32_t* blocked;    /* [N][EW] bit per out-CSR slot, EW = ceil(E/32)        */
+  uint16_t* ring;       /* [N][CG_LOG_RING][2] last comm-log (from,to) pairs    */
+  int32_t*  ienv;       /* [N][CG_I_COUNT]                                      */
+  double*   fenv;       /* [N][CG_D_COUNT]                                      */
+  int32_t   n_envs;     /* leading dimension (N, or 1 for a broadcast snapshot) */
+  int32_t   reserved;
+} cygym_buffers;
+
+/* One tick's actions for every env, DEVICE pointers.
+ * The reference's action is (action_type, exploit_indices, device_indices,
+ * app_index) or a list of such tuples (volt_typhoon_env.py:818, 842-876). */
+typedef struct cygym_actions {
+  const int32_t* mode;      /* [N] CG_MODE_*  (env.mode)                        */
+  const int32_t* n_groups;  /* [N] 0: step(action); g>0: step_grouped(g groups) */
+  const int32_t* atype;     /* [N][G]                                           */
+  const int32_t* n_exploit; /* [N][G]                                           */
+  const int32_t* exploit;   /* [N][G][CG_MAX_EXPLOITS]                          */
+  const int32_t* app;       /* [N][G] app_index, -1 when not a Python int       */
+  const int32_t* dev_cnt;   /* [N][G] len(device_indices)                       */
+  const int16_t* dev_idx;   /* [N][L] the groups' device lists, concatenated    */
+  int32_t max_groups;       /* G                                                */
+  int32_t max_devs;         /* L                                                */
+} cygym_actions;
+
+/* What step() returns, for every env, DEVICE pointers. */
+typedef struct cygym_outputs {
+  float*   obs;     /* [N][M][6] env.state  CyberDefenseEnv.py:146-191          */
+  double*  raw;     /* [N] raw_reward                                           */
+  double*  shaped;  /* [N] shaped_reward                                        */
+  uint8_t* done;    /* [N]                                                      */
+} cygym_outputs;
+
+typedef struct cygym_handle cygym_handle;
+
+int cygym_version(void);
+const char* cygym_last_error(const cygym_handle* h);  /* h may be NULL */
+
+/* Replaces: building the env object's caches after initialize_environment()
+ * (volt_typhoon_env.py:1485, :456) -- ingests the RESULT, flattened. */
+int cygym_create(const cygym_topology* topo, const cygym_config* cfg, int32_t n_envs,
+                 int32_t device_id, cygym_handle** out);
+void cygym_destroy(cygym_handle* h);
+/* attribute writes on the env object (env.base_line = ..., env.comp_scale = ...) */
+int cygym_set_config(cygym_handle* h, const cygym_config* cfg);
+int cygym_bind(cygym_handle* h, const cygym_buffers* state);
+
+/* Replaces: reset(from_init=True) volt_typhoon_env.py:1904-1936 (restore the
+ * pickled initial env).  `snapshot` has n_envs == 1 (broadcast) or N.
+ * env_ids: DEVICE int32[n] or NULL for all envs. */
+int cygym_reset(cygym_handle* h, const cygym_buffers* snapshot, const int32_t* env_ids,
+                int32_t n, void* stream);
+
+/* Replaces: randomize_compromise_and_ownership() volt_typhoon_env.py:330-383 */
+int cygym_randomize(cygym_handle* h, const int32_t* env_ids, int32_t n, void* stream);
+
+/* Replaces: step(action) volt_typhoon_env.py:818-1333 and
+ * step_grouped(groups) :694-779, incl. evolve_network CyberDefenseEnv.py:583-875,
+ * arrivals :575-596 / CDSimulator.py:244-348, logger/detector CDSimulator.py:663-742. */
+int cygym_step(cygym_handle* h, const cygym_actions* a, const cygym_outputs* o, void* stream);
+
+/* Replaces: _get_state / _get_defender_state / _get_attacker_state
+ * CyberDefenseEnv.py:146-257.  role 0: full [N][6M]; 1: defender [N][6M];
+ * 2: attacker [N][4M + MaxExploits].  out: DEVICE float32. */
+int cygym_observe(cygym_handle* h, int32_t role, float* out, void* stream);
+
+/* Synthetic action script of bench.py -- not a reference
+ * interface: fills one tick's cygym_actions from Philox on device. */
+int cygym_gen_actions(cygym_handle* h, int32_t tick, int32_t* mode, int32_t* n_groups,
+                      int32_t* atype, int32_t* n_exploit, int32_t* exploit, int32_t* app,
+                      int32_t* dev_cnt, int16_t* dev_idx, int32_t max_devs, void* stream);
+
+/* Timing aid: run `fn`-less HIP-event bracket on a stream.  Returns milliseconds
+ * between two events recorded around the work enqueued by the caller in between:
+ *   cygym_timer_start(h, stream); ...launches...; cygym_timer_stop(h, stream, &ms) */
+int cygym_timer_start(cygym_handle* h, void* stream);
+int cygym_timer_stop(cygym_handle* h, void* stream, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CYGYM_ABI_H */

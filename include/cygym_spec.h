@@ -1,0 +1,174 @@
+/* cygym_spec.h -- bit layouts, RNG sites and draw conventions of the batched
+ * CyGym tick.  Shared verbatim by the HIP kernels (cygym_amd/csrc), the C oracle
+ * (oracle/cygym_oracle.c) and mirrored in Python (cygym_amd/spec.py).
+ *
+ * Nothing here is copied from the reference; it is the flat (struct-of-arrays)
+ * restatement of the object graph the reference mutates:
+ *   Device flags ........ CDSimulatorComponents.py:217-243
+ *   Workload ............ CDSimulatorComponents.py:18-26
+ *   device stash ........ volt_typhoon_env.py:419-453
+ *   busy-set cache ...... volt_typhoon_env.py:117, 904-908, 1330
+ *   _active_ids set ..... CyberDefenseEnv.py:654-659
+ */
+#ifndef CYGYM_SPEC_H
+#define CYGYM_SPEC_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#define CYGYM_HD __host__ __device__ __forceinline__
+#else
+#define CYGYM_HD static inline
+#endif
+
+/* ---- per-device dynamic flag byte (plane `flags`, u8 [N][M]) ---- */
+#define CG_F_COMP       0x01u /* Device.isCompromised                      */
+#define CG_F_OWNED      0x02u /* Device.attacker_owned                     */
+#define CG_F_KNOWN      0x04u /* Device.Known_to_attacker                  */
+#define CG_F_REACH      0x08u /* Device.reachable_by_attacker              */
+#define CG_F_NYA        0x10u /* Device.Not_yet_added                      */
+#define CG_F_EVOACT     0x20u /* member of env._active_ids (evolve_network)*/
+#define CG_F_BUSYC      0x40u /* member of env._busy_devices (cached set)  */
+#define CG_F_WLADV      0x80u /* Device.workload.adversarial               */
+
+/* ---- per-device stash flag byte (plane `st_flags`) -- action 11/12 ---- */
+#define CG_S_VALID      0x40u /* device id present in env._device_ckpts    */
+/* bits COMP/KNOWN/REACH/NYA/WLADV reuse the CG_F_* positions              */
+#define CG_S_KEEP (CG_F_COMP | CG_F_KNOWN | CG_F_REACH | CG_F_NYA | CG_F_WLADV)
+
+/* ---- per-device static byte (plane `dstatic`, u8 [M], per topology) ---- */
+#define CG_D_DC         0x01u /* device_type == "DomainController"         */
+#define CG_D_SERVER     0x02u /* wtype == 'server'                         */
+/* vuln mask (which exploit indices can compromise this device) is its own
+ * plane `vuln` u8 [M]; number of apps is plane `napps` u8 [M].             */
+
+/* ---- per-env scalar flags (i32 column ENV_FLAGS) ---- */
+#define CG_E_HAS_CKPT   0x01 /* env.checkpoint is not None                 */
+#define CG_E_EVO_INIT   0x02 /* env._active_ids exists                     */
+#define CG_E_DET_TRAIN  0x04 /* simulator.detector.trained                 */
+#define CG_E_DET_RANDOM 0x08 /* simulator.detector.random_detection        */
+#define CG_E_PREV_SET   0x10 /* env._prev_att_potential is not None        */
+#define CG_E_TOPO_OVF   0x20 /* evolve wanted to add an edge (unsupported) */
+#define CG_E_BUSY_SAT   0x40 /* a busy counter saturated at 255            */
+
+/* ---- per-env integer counters: column indices of `ienv` i32 [N][CG_I_COUNT] */
+enum {
+  CG_I_STEP_NUM = 0,     /* env.step_num                                   */
+  CG_I_DEF_STEP,         /* env.defender_step                              */
+  CG_I_ATT_STEP,         /* env.attacker_step                              */
+  CG_I_WORK_DONE,        /* env.work_done                                  */
+  CG_I_CKPT_CNT,         /* env.checkpoint_count                           */
+  CG_I_REVERT_CNT,       /* env.revert_count                               */
+  CG_I_SCAN_CNT,         /* env.scan_cnt                                   */
+  CG_I_COMP_CNT,         /* env.compromised_devices_cnt                    */
+  CG_I_EDGES_BLOCKED,    /* env.edges_blocked                              */
+  CG_I_EDGES_ADDED,      /* env.edges_added                                */
+  CG_I_FLAGS,            /* CG_E_* bits                                    */
+  CG_I_RNG_TICK,         /* monotone tick counter feeding the Philox ctr   */
+  CG_I_LOG_TOTAL,        /* len(simulator.logger.logs)                     */
+  CG_I_DISCOVERED,       /* bitmask over exploit index: Exploit.discovered */
+  CG_I_LAST_NCOMP,       /* n_comp of the last tick (for host-side info)   */
+  CG_I_LAST_ATYPE,       /* info['executed_atype'] of the last tick        */
+  CG_I_COUNT
+};
+
+/* ---- per-env f64 accumulators: `fenv` f64 [N][CG_D_COUNT] ---- */
+enum {
+  CG_D_DEF_COST = 0,     /* env.defensive_cost                             */
+  CG_D_CLEAN_COST,       /* env.clearning_cost (sic)                       */
+  CG_D_PREV_ATT_POT,     /* env._prev_att_potential                        */
+  CG_D_COUNT
+};
+
+/* ---- actions ---- */
+#define CG_MODE_DEFENDER 0
+#define CG_MODE_ATTACKER 1
+
+/* ---- comm-log ring ---- */
+#define CG_LOG_RING 32       /* entries kept per env (fast scan reads 30)  */
+#define CG_SCAN_WINDOW 30    /* volt_typhoon_env.py:1052                   */
+
+/* ---- RNG sites: one id per random call site on the step path ---- */
+enum {
+  CG_SITE_STALL_REVERT = 1,  /* volt_typhoon_env.py:936 / :643   a=device            */
+  CG_SITE_STALL_CLEAN,       /* :1009 / :689                     a=device b=occurrence*/
+  CG_SITE_STALL_PATCH,       /* :1018                            a=device b=occurrence*/
+  CG_SITE_STALL_SCAN,        /* :1069                            a=sender b=scan ord. */
+  CG_SITE_STALL_ISOLATE,     /* :1120                            a=device b=iteration */
+  CG_SITE_PICK_BLOCK,        /* :505                             a=device b=occurrence*/
+  CG_SITE_PICK_UNBLOCK,      /* :511                             a=device b=occurrence*/
+  CG_SITE_PROBE_SRC,         /* :1189                                                 */
+  CG_SITE_ZERODAY,           /* :1136                            a=position in list   */
+  CG_SITE_ARR_CLIENT,        /* CDSimulator.py:298 (wtype client) a=device (sort key) */
+  CG_SITE_ARR_SERVER,        /* CDSimulator.py:298 (wtype server) a=device (sort key) */
+  CG_SITE_ARR_TIME,          /* CDSimulator.py:308               a=device             */
+  CG_SITE_EVO_POISSON,       /* CyberDefenseEnv.py:668                                */
+  CG_SITE_EVO_COIN,          /* :679                             a=event index        */
+  CG_SITE_EVO_PICK_IN,       /* :681 -> :675                     a=event index        */
+  CG_SITE_EVO_PICK_ACT,      /* :703 -> :675                     a=event index        */
+  CG_SITE_EVO_ATT,           /* :690                             a=event index        */
+  CG_SITE_EVO_PA,            /* :817                             a=device             */
+  CG_SITE_SHUFFLE,           /* volt_typhoon_env.py:359          a=device (sort key)  */
+  CG_SITE_DET_COIN,          /* CDSimulator.py:716               a=window pos b=scan  */
+  CG_SITE_LAZY,              /* CDSimulator.py:328 (no observable effect)             */
+  CG_SITE_ACTGEN = 64        /* synthetic action script of bench.py (not reference)   */
+};
+
+/* ---- Philox4x32-10 (Salmon et al., SC'11), counter-based ----
+ * key  = (seed_lo, seed_hi)
+ * ctr  = (global_env_id, rng_tick, site, a | (b << 16))
+ * A draw is word 0 of the output; words 1..3 are used only where stated.  */
+#define CG_PHILOX_M0 0xD2511F53u
+#define CG_PHILOX_M1 0xCD9E8D57u
+#define CG_PHILOX_W0 0x9E3779B9u
+#define CG_PHILOX_W1 0xBB67AE85u
+
+typedef struct { uint32_t v[4]; } cg_u32x4;
+
+CYGYM_HD cg_u32x4 cg_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                   uint32_t k0, uint32_t k1) {
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)CG_PHILOX_M0 * c0;
+    uint64_t p1 = (uint64_t)CG_PHILOX_M1 * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += CG_PHILOX_W0; k1 += CG_PHILOX_W1;
+  }
+  cg_u32x4 o; o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+  return o;
+}
+
+/* one 32-bit draw for (env, tick, site, a, b) */
+CYGYM_HD uint32_t cg_draw(uint64_t seed, uint32_t env, uint32_t tick, uint32_t site,
+                          uint32_t a, uint32_t b) {
+  return cg_philox4x32_10(env, tick, site, (a & 0xFFFFu) | (b << 16),
+                          (uint32_t)seed, (uint32_t)(seed >> 32)).v[0];
+}
+
+/* index in [0, n): multiply-high (n < 2^32, n > 0) */
+CYGYM_HD uint32_t cg_index(uint32_t u, uint32_t n) {
+  return (uint32_t)(((uint64_t)u * (uint64_t)n) >> 32);
+}
+/* random.randint(lo, hi) inclusive */
+CYGYM_HD int cg_randint(uint32_t u, int lo, int hi) {
+  return lo + (int)cg_index(u, (uint32_t)(hi - lo + 1));
+}
+/* `random.random() < p`  <=>  u < thr  with thr = ceil(p * 2^32) (u64) */
+CYGYM_HD int cg_bernoulli(uint32_t u, uint64_t thr) { return (uint64_t)u < thr; }
+/* inverse-CDF lookup on an ascending table of u64 thresholds ceil(cdf_k * 2^32):
+ * returns the number of thresholds <= u, i.e. the smallest k with u < thr[k]. */
+CYGYM_HD int cg_cdf_lookup(uint32_t u, const uint64_t* thr, int n) {
+  int k = 0;
+  for (int j = 0; j < n; ++j) k += ((uint64_t)u >= thr[j]) ? 1 : 0;
+  return k;
+}
+
+#define CG_POISSON_TABLE 16   /* thresholds kept for np.random.poisson       */
+#define CG_TRI_TABLE 8        /* thresholds kept for ceil(triangular(0,m,h)) */
+#define CG_MAX_EXPLOITS 6     /* CyberDefenseEnv.py:48 (MaxExploits)         */
+#define CG_MAX_EVENTS 16      /* evolve events per call (Poisson table cap)  */
+
+#endif /* CYGYM_SPEC_H */

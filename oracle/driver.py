@@ -1,0 +1,164 @@
+"""ctypes driver for the CPU oracle (oracle/libcygym_oracle.so).
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Holds env state in numpy arrays with the same struct-of-arrays
+layout the HIP library uses (include/cygym_abi.h) and steps it with the scalar C
+restatement.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from cygym_amd import abi
+from cygym_amd import spec as S
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "libcygym_oracle.so")
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(HERE, "cygym_oracle.c")
+    deps = [src, os.path.join(HERE, "..", "include", "cygym_abi.h"), os.path.join(HERE, "..", "include", "cygym_spec.h")]
+    if force or not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-std=c11", "-I" + os.path.join(HERE, "..", "include"),
+                               "-shared", "-o", SO, src])
+    return SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(SO)
+        L.cgo_step.argtypes = [C.POINTER(abi.Topology), C.POINTER(abi.Config), C.POINTER(abi.Buffers),
+                               C.POINTER(abi.Actions), C.POINTER(abi.Outputs), C.POINTER(abi.Buffers),
+                               C.c_int32, C.c_int32]
+        L.cgo_reset.argtypes = [C.POINTER(abi.Topology), C.POINTER(abi.Config), C.POINTER(abi.Buffers),
+                                C.POINTER(abi.Buffers), C.c_void_p, C.c_int32]
+        L.cgo_randomize.argtypes = [C.POINTER(abi.Topology), C.POINTER(abi.Config), C.POINTER(abi.Buffers),
+                                    C.c_void_p, C.c_int32]
+        L.cgo_observe.argtypes = [C.POINTER(abi.Topology), C.POINTER(abi.Config), C.POINTER(abi.Buffers),
+                                  C.c_int32, C.c_void_p, C.c_int32]
+        _lib = L
+    return _lib
+
+
+STATE_SHAPES = {
+    "flags": ("M", np.uint8), "busy": ("M", np.uint8), "wl": ("M", np.uint8), "comp_by": ("M", np.uint8),
+    "st_flags": ("M", np.uint8), "st_busy": ("M", np.uint8), "st_wl": ("M", np.uint8), "st_comp_by": ("M", np.uint8),
+    "blocked": ("EW", np.uint32), "ring": ("R", np.uint16), "ienv": ("I", np.int32), "fenv": ("D", np.float64),
+}
+
+
+def alloc_state(n, M, EW):
+    dims = {"M": (M,), "EW": (EW,), "R": (S.LOG_RING, 2), "I": (S.I_COUNT,), "D": (S.D_COUNT,)}
+    st = {k: np.zeros((n,) + dims[d], dt) for k, (d, dt) in STATE_SHAPES.items()}
+    st["ring"][:] = 0xFFFF
+    return st
+
+
+def state_struct(st) -> abi.Buffers:
+    b = abi.Buffers()
+    for k in STATE_SHAPES:
+        a = st[k]
+        assert a.flags["C_CONTIGUOUS"] and a.dtype == STATE_SHAPES[k][1], k
+        setattr(b, k, a.ctypes.data)
+    b.n_envs = st["flags"].shape[0]
+    return b
+
+
+def alloc_actions(n, G, L):
+    return dict(mode=np.zeros(n, np.int32), n_groups=np.zeros(n, np.int32), atype=np.zeros((n, G), np.int32),
+                n_exploit=np.zeros((n, G), np.int32), exploit=np.full((n, G, S.MAX_EXPLOITS), -1, np.int32),
+                app=np.full((n, G), -1, np.int32), dev_cnt=np.zeros((n, G), np.int32),
+                dev_idx=np.zeros((n, L), np.int16))
+
+
+def actions_struct(act) -> abi.Actions:
+    a = abi.Actions()
+    for k in ("mode", "n_groups", "atype", "n_exploit", "exploit", "app", "dev_cnt", "dev_idx"):
+        assert act[k].flags["C_CONTIGUOUS"], k
+        setattr(a, k, act[k].ctypes.data)
+    a.max_groups = act["atype"].shape[1]
+    a.max_devs = act["dev_idx"].shape[1]
+    return a
+
+
+class OracleBatch:
+    """N envs over one shared topology, stepped by the C oracle."""
+
+    def __init__(self, topo: abi.TopologyArrays, cfg: abi.EnvConfig, n_envs: int):
+        self.topo = topo.normalised()
+        self.topo.validate()
+        self.cfg = cfg
+        self.N = n_envs
+        self.M = self.topo.M
+        self.state = alloc_state(n_envs, self.M, self.topo.EW)
+        self.snapshot = None
+        self.obs = np.zeros((n_envs, self.M, 6), np.float32)
+        self.raw = np.zeros(n_envs, np.float64)
+        self.shaped = np.zeros(n_envs, np.float64)
+        self.done = np.zeros(n_envs, np.uint8)
+        self._t = self.topo.to_c()
+
+    def load_state(self, init: dict, broadcast=True):
+        """init: dict of arrays with leading dim 1 or N (planes may be wider ints)."""
+        for k, (_, dt) in STATE_SHAPES.items():
+            src = np.asarray(init[k])
+            if k == "blocked" and src.shape[-1] != self.topo.EW:
+                src = abi.pack_blocked(src, self.topo.EW)
+            if k == "ring":
+                src = np.where(src < 0, 0xFFFF, src)
+            self.state[k][...] = src.astype(dt) if src.shape[0] == self.N else np.broadcast_to(src.astype(dt), self.state[k].shape)
+        self.snapshot = {k: v.copy() for k, v in self.state.items()}
+
+    def step(self, act: dict, begin=0, end=None):
+        c = self.cfg.to_c()
+        b = state_struct(self.state)
+        a = actions_struct(act)
+        o = abi.Outputs()
+        o.obs, o.raw, o.shaped, o.done = (self.obs.ctypes.data, self.raw.ctypes.data,
+                                          self.shaped.ctypes.data, self.done.ctypes.data)
+        snap = state_struct(self.snapshot) if self.snapshot is not None else None
+        rc = lib().cgo_step(C.byref(self._t), C.byref(c), C.byref(b), C.byref(a), C.byref(o),
+                            C.byref(snap) if snap is not None else None, begin, self.N if end is None else end)
+        if rc != 0:
+            raise RuntimeError(f"cgo_step failed: {rc}")
+        return self.obs, self.raw, self.shaped, self.done
+
+    def randomize(self, env_ids=None):
+        c = self.cfg.to_c()
+        b = state_struct(self.state)
+        if env_ids is None:
+            rc = lib().cgo_randomize(C.byref(self._t), C.byref(c), C.byref(b), None, self.N)
+        else:
+            ids = np.ascontiguousarray(env_ids, np.int32)
+            rc = lib().cgo_randomize(C.byref(self._t), C.byref(c), C.byref(b), ids.ctypes.data, len(ids))
+        assert rc == 0
+
+    def reset(self, env_ids=None):
+        c = self.cfg.to_c()
+        b = state_struct(self.state)
+        s = state_struct(self.snapshot)
+        if env_ids is None:
+            rc = lib().cgo_reset(C.byref(self._t), C.byref(c), C.byref(b), C.byref(s), None, self.N)
+        else:
+            ids = np.ascontiguousarray(env_ids, np.int32)
+            rc = lib().cgo_reset(C.byref(self._t), C.byref(c), C.byref(b), C.byref(s), ids.ctypes.data, len(ids))
+        assert rc == 0
+
+    def observe(self, role: int):
+        c = self.cfg.to_c()
+        b = state_struct(self.state)
+        width = 6 * self.M if role in (0, 1) else 4 * self.M + self.cfg.max_exploits
+        out = np.zeros((self.N, width), np.float32)
+        rc = lib().cgo_observe(C.byref(self._t), C.byref(c), C.byref(b), role, out.ctypes.data, self.N)
+        assert rc == 0
+        return out

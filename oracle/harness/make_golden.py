@@ -1,0 +1,217 @@
+"""Generate tests/golden/*.npz by running the reference itself (see ref_harness.py).
+
+Run in the build container only:   python oracle/harness/make_golden.py [name ...]
+The fixtures are plain arrays: exported topology, initial struct-of-arrays state,
+the action script, and the expected state / rewards / observations after every tick.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_harness as H          # noqa: E402
+from cygym_amd import spec as S  # noqa: E402
+
+GOLDEN = os.path.join(H.REPO, "tests", "golden")
+
+DEF, ATT = S.MODE_DEFENDER, S.MODE_ATTACKER
+
+
+def dev_list(rs, M, kmax, unique=True):
+    k = int(rs.randint(1, max(2, kmax + 1)))
+    if unique:
+        return [int(x) for x in rs.choice(M, size=min(k, M), replace=False)]
+    return [int(x) for x in rs.randint(0, M, size=k)]
+
+
+def mixed_actions(M, def_types, att_types, kmax, X=2, unique=True):
+    def fn(e, t, env, rs):
+        mode = DEF if (t % 2 == 0) else ATT
+        if mode == DEF:
+            at = int(rs.choice(def_types))
+            if at == 5 and env.simulator.detector.trained:
+                at = 8  # trained (IsolationForest) detector mode is outside the pinned scope
+            dv = dev_list(rs, M, kmax, unique)
+            if at in (2, 3, 8) and rs.rand() < 0.3:
+                dv = []
+            if at == 10 and rs.rand() < 0.5:
+                dv = []
+            app = int(rs.randint(-1, 9))
+            return mode, (at, np.array([int(rs.randint(0, X))]), dv, app)
+        at = int(rs.choice(att_types))
+        ne = 1 if rs.rand() < 0.8 else 2
+        ex = np.array([int(rs.randint(0, X + 1)) for _ in range(ne)])
+        return mode, (at, ex, dev_list(rs, M, 3), 0)
+    return fn
+
+
+ALL_DEF = [1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 13]
+ALL_ATT = [1, 1, 2, 3]
+
+SCENARIOS = {}
+
+
+def scenario(name):
+    def deco(f):
+        SCENARIOS[name] = f
+        return f
+    return deco
+
+
+@scenario("s16_mixed")
+def s16_mixed():
+    env0 = H.build_env(16, 12, init_seed=3, strip_vuln_frac=0.4, extra_reachable=1)
+    return H.run_scenario(env0, 3, 300, mixed_actions(16, ALL_DEF, ALL_ATT, 5), seed=11), 1
+
+
+@scenario("s64_mixed")
+def s64_mixed():
+    env0 = H.build_env(64, 48, init_seed=5, strip_vuln_frac=0.5, extra_reachable=3)
+    return H.run_scenario(env0, 3, 300, mixed_actions(64, ALL_DEF, ALL_ATT, 8), seed=12, env_id_base=1000), 1
+
+
+@scenario("s256_mixed")
+def s256_mixed():
+    env0 = H.build_env(256, 200, init_seed=7, strip_vuln_frac=0.5, extra_reachable=6)
+    return H.run_scenario(env0, 2, 90, mixed_actions(256, ALL_DEF, ALL_ATT, 32), seed=13, env_id_base=7), 1
+
+
+@scenario("s16_train")
+def s16_train():
+    """Action 10 (detector training) present; scans stop once the detector is trained."""
+    env0 = H.build_env(16, 14, init_seed=9, strip_vuln_frac=0.3)
+    return H.run_scenario(env0, 2, 120, mixed_actions(16, ALL_DEF + [10, 10], ALL_ATT, 4), seed=14), 1
+
+
+@scenario("s32_grouped")
+def s32_grouped():
+    """step_grouped (IPPO/MAPPO style) interleaved with single-action steps."""
+    M = 32
+    env0 = H.build_env(M, 24, init_seed=21, strip_vuln_frac=0.4, extra_reachable=2)
+    single = mixed_actions(M, ALL_DEF, ALL_ATT, 6)
+
+    def fn(e, t, env, rs):
+        if (t // 3) % 2 == 0 or rs.rand() < 0.3:
+            mode = DEF if (t % 2 == 0) else ATT
+            ng = int(rs.randint(1, 5))
+            groups = []
+            for _ in range(ng):
+                if mode == DEF:
+                    at = int(rs.choice([0, 1, 1, 1, 2, 3, 4, 5, 7, 8, 11, 13]))
+                    dv = dev_list(rs, M, 6, unique=(rs.rand() < 0.7))
+                else:
+                    at = int(rs.choice([0, 1, 2, 3]))
+                    dv = dev_list(rs, M, 3)
+                groups.append((at, np.array([0]), dv, 0))
+            return mode, groups
+        return single(e, t, env, rs)
+    return H.run_scenario(env0, 2, 240, fn, seed=15, env_id_base=50), 4
+
+
+@scenario("s24_norng")
+def s24_norng():
+    """RNG-free: lambda_events = 0, workload_cap = 0, no stalling / picking actions."""
+    env0 = H.build_env(24, 20, init_seed=31, strip_vuln_frac=0.4, extra_reachable=2,
+                       overrides=dict(lambda_events=0.0, workload_cap=0))
+    return H.run_scenario(env0, 2, 150, mixed_actions(24, [2, 7, 8, 10, 11, 12], [1, 1, 3], 4), seed=16), 1
+
+
+@scenario("s16_dups")
+def s16_dups():
+    """Duplicate / unsorted device lists and out-of-range action types."""
+    M = 16
+    env0 = H.build_env(M, 13, init_seed=41, strip_vuln_frac=0.3, extra_reachable=1)
+    base = mixed_actions(M, ALL_DEF, ALL_ATT, 10, unique=False)
+
+    def fn(e, t, env, rs):
+        mode, (at, ex, dv, app) = base(e, t, env, rs)
+        if rs.rand() < 0.08:
+            at = int(rs.choice([-1, 14, 99])) if mode == DEF else int(rs.choice([-2, 0, 4, 5, 9]))
+        return mode, (at, ex, dv, app)
+    return H.run_scenario(env0, 3, 300, fn, seed=17, env_id_base=3), 1
+
+
+@scenario("s16_baselines")
+def s16_baselines():
+    """base_line != "Nash": defender forced to no-op (:913), "No Attack" gates the attacker (:1130)."""
+    out = None
+    M = 16
+    res = []
+    for i, bl in enumerate(["No Defense", "No Attack", "Preset"]):
+        env0 = H.build_env(M, 12, init_seed=51, strip_vuln_frac=0.3, overrides=dict(base_line=bl))
+        r = H.run_scenario(env0, 1, 80, mixed_actions(M, ALL_DEF, ALL_ATT, 4), seed=18, env_id_base=i)
+        res.append((bl, r))
+    return res, 1
+
+
+@scenario("s600_sparse")
+def s600_sparse():
+    """len(net) > 500: sparse attacker connect (:1344) and the lazy workload path (CDSimulator.py:325)."""
+    M = 600
+    env0 = H.build_env(M, 520, init_seed=61, strip_vuln_frac=0.5, extra_reachable=5, prewarm_star=True)
+    return H.run_scenario(env0, 1, 70, mixed_actions(M, ALL_DEF, ALL_ATT, 40), seed=19), 1
+
+
+@scenario("s16_randomize")
+def s16_randomize():
+    # several attacker-owned devices: after the reshuffle the reference adds star edges at the
+    # next evolve (CyberDefenseEnv.py:738-774) -> topo_same drops and parity ends there
+    """randomize_compromise_and_ownership() before the episode (do_agent.py:189)."""
+    M = 16
+    env0 = H.build_env(M, 13, init_seed=71, strip_vuln_frac=0.3, overrides=dict(sv_attacker_fraction=0.25))
+
+    def pre(e, env, rs):
+        env.randomize_compromise_and_ownership()
+        return True
+    return H.run_scenario(env0, 3, 60, mixed_actions(M, ALL_DEF, ALL_ATT, 4), seed=20, pre_fn=pre), 1
+
+
+@scenario("s16_coin")
+def s16_coin():
+    """Detector in random-detection mode (Detector.train([]) CDSimulator.py:688-690)."""
+    M = 16
+    env0 = H.build_env(M, 14, init_seed=81, strip_vuln_frac=0.2, extra_reachable=1)
+
+    def pre(e, env, rs):
+        env.simulator.detector.train([])
+        return False
+    return H.run_scenario(env0, 2, 200, mixed_actions(M, [5, 5, 5, 1, 8, 6], [1, 1, 2], 5), seed=21, pre_fn=pre), 1
+
+
+@scenario("s12_episode")
+def s12_episode():
+    """Crosses the 1000-tick episode cap (CyberDefenseEnv.py:549)."""
+    M = 12
+    env0 = H.build_env(M, 10, init_seed=91, strip_vuln_frac=0.3)
+    return H.run_scenario(env0, 1, 1004, mixed_actions(M, ALL_DEF, ALL_ATT, 3), seed=22), 1
+
+
+@scenario("s16_zeroday")
+def s16_zeroday():
+    M = 16
+    env0 = H.build_env(M, 12, init_seed=101, strip_vuln_frac=0.2,
+                       overrides=dict(zero_day=True, k_known=1, j_private=1))
+    return H.run_scenario(env0, 2, 120, mixed_actions(M, ALL_DEF, ALL_ATT, 4, X=3), seed=23), 1
+
+
+def main(names):
+    os.makedirs(GOLDEN, exist_ok=True)
+    for name in names:
+        res, G = SCENARIOS[name]()
+        if isinstance(res, list):
+            for bl, r in res:
+                path = os.path.join(GOLDEN, f"{name}_{bl.replace(' ', '_').lower()}.npz")
+                n, t = H.save_fixture(path, r, G)
+                print(f"{path}: N={n} T={t} {os.path.getsize(path) / 1024:.1f} KiB")
+        else:
+            path = os.path.join(GOLDEN, f"{name}.npz")
+            n, t = H.save_fixture(path, res, G)
+            print(f"{path}: N={n} T={t} {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:] or list(SCENARIOS))

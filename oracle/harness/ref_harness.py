@@ -1,0 +1,687 @@
+"""Oracle harness: run the UNMODIFIED reference environment in this container and
+export flat golden fixtures for the batched tick.
+
+TEST INFRASTRUCTURE ONLY.  Runs only where /root/reference exists (the build
+container); nothing here travels to the GPU box except the .npz fixtures it wrote
+under tests/golden/.  No reference source is copied: the reference modules are
+imported from where they lie, with
+  * stand-ins for the three absent third-party packages (oracle/harness/standins:
+    gym, igraph, pymetis -- this repo's own code),
+  * a synthetic CVE.csv (the real one is a Kaggle download, unavailable offline),
+  * the reference's RNG call sites (`random.*`, `numpy.random.*` module attributes)
+    fed from the build's Philox stream (cygym_amd/rng.py), addressed by
+    (env, tick, site, a, b) -- see include/cygym_spec.h.  The call site is
+    recovered from the caller's frame; reference files are untouched.
+
+Canonicalisations applied by the injected functions (documented in DESIGN.md):
+  * choice() over a *set* (evolve's pick_from, zero-day owned indices) picks from
+    the sorted elements -- CPython set order is an implementation artefact;
+  * sample(pop, k) returns the k elements with the smallest (philox key, id);
+  * shuffle(list of devices) orders by (philox key, id).
+"""
+from __future__ import annotations
+
+import copy
+import math
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REFERENCE = os.environ.get("CYGYM_REFERENCE", "/root/reference")
+
+sys.dont_write_bytecode = True  # /root/reference must stay untouched (no __pycache__)
+
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+from cygym_amd import rng as R          # noqa: E402
+from cygym_amd import spec as S         # noqa: E402
+
+
+def reference_available() -> bool:
+    return os.path.isfile(os.path.join(REFERENCE, "volt_typhoon_env.py"))
+
+
+# --------------------------------------------------------------------------
+# environment bootstrap
+# --------------------------------------------------------------------------
+_SCRATCH = None
+_MODS = None
+
+
+def _write_cve_csv(path: str):
+    """Synthetic CVE table with the columns the path reads (parse_json.py:37-53)."""
+    import random as _r
+    rr = _r.Random(1234)
+    rows = ["matchCriteriaId,exploitabilityScore,impactScore,baseSeverity"]
+    rows.append("ED3A999C-9184-4D27-A62E-3D8A3F0D4F27,3.9,5.9,CRITICAL")
+    rows.append("0A5713AE-B7C5-4599-8E4F-9C235E73E5F6,6.0,5.9,HIGH")
+    for i in range(200):
+        rid = "%08X-%04X-%04X-%04X-%012X" % (rr.getrandbits(32), rr.getrandbits(16), rr.getrandbits(16),
+                                            rr.getrandbits(16), rr.getrandbits(48))
+        rows.append(f"{rid},{rr.choice([1.2, 1.8, 2.8, 3.9])},{rr.choice([1.4, 3.6, 5.9])},MEDIUM")
+    with open(path, "w") as f:
+        f.write("\n".join(rows) + "\n")
+
+
+def load_reference():
+    """Import the reference modules (once). Returns the module namespace dict."""
+    global _SCRATCH, _MODS
+    if _MODS is not None:
+        return _MODS
+    if not reference_available():
+        raise RuntimeError(f"reference not found at {REFERENCE}")
+    _SCRATCH = tempfile.mkdtemp(prefix="cygym_oracle_")
+    _write_cve_csv(os.path.join(_SCRATCH, "CVE.csv"))
+    os.chdir(_SCRATCH)  # the reference opens its log + CVE.csv + snapshots in CWD
+    sys.path.insert(0, os.path.join(HERE, "standins"))
+    sys.path.insert(0, REFERENCE)
+    import logging
+    import random
+    import volt_typhoon_env as vte
+    import CyberDefenseEnv as cde
+    import CDSimulator as cds
+    import CDSimulatorComponents as cdc
+    logging.disable(logging.CRITICAL)
+    _MODS = dict(vte=vte, cde=cde, cds=cds, cdc=cdc, random=random, np=np)
+    return _MODS
+
+
+# --------------------------------------------------------------------------
+# RNG injection
+# --------------------------------------------------------------------------
+class DrawContext:
+    """Addresses draws: set .seed/.env/.tick before each reference call."""
+
+    def __init__(self):
+        self.seed = 0
+        self.env = 0
+        self.tick = 0
+        self.active = False
+        self.occ = {}            # (site, a) -> next occurrence number
+        self.scan_base = 0       # env.scan_cnt at tick start
+        self.poisson_tab = None
+        self.trace = []          # (site, a, b, u32) of every draw this tick
+
+    def begin(self, seed, env_id, tick, env_obj=None):
+        self.seed, self.env, self.tick = seed, env_id, tick
+        self.occ = {}
+        self.trace = []
+        self.scan_base = getattr(env_obj, "scan_cnt", 0) if env_obj is not None else 0
+        self.active = True
+
+    def end(self):
+        self.active = False
+
+    def next_occ(self, site, a):
+        k = (site, a)
+        v = self.occ.get(k, 0)
+        self.occ[k] = v + 1
+        return v
+
+    def draw(self, site, a=0, b=0):
+        u = R.draw(self.seed, self.env, self.tick, site, a, b)
+        self.trace.append((site, a, b, u))
+        return u
+
+
+CTX = DrawContext()
+_ORIG = {}
+
+
+def _frames(depth=8):
+    f = sys._getframe(2)
+    out = []
+    while f is not None and len(out) < depth:
+        out.append(f)
+        f = f.f_back
+    return out
+
+
+def _find(frames, name):
+    for f in frames:
+        if f.f_code.co_name == name:
+            return f
+    return None
+
+
+def _inj_randint(lo, hi):
+    if not CTX.active:
+        return _ORIG["randint"](lo, hi)
+    fr = _frames()
+    if fr[0].f_code.co_name != "_stall":
+        raise RuntimeError(f"unmapped randint site: {fr[0].f_code.co_name}:{fr[0].f_lineno}")
+    caller = fr[1]
+    loc = caller.f_locals
+    at = loc.get("action_type")
+    env = loc.get("self")
+    if at == 3:
+        site, a = S.SITE_STALL_REVERT, loc["device"].id
+        b = 0
+    elif at == 1:
+        site, a = S.SITE_STALL_CLEAN, loc["device"].id
+        b = CTX.next_occ(site, a)
+    elif at == 4:
+        site, a = S.SITE_STALL_PATCH, loc["device"].id
+        b = CTX.next_occ(site, a)
+    elif at == 5:
+        site = S.SITE_STALL_SCAN
+        a = loc["dev_id"] if "dev_id" in loc and getattr(env, "fast_scan", True) else loc["dsrc"].id
+        b = int(env.scan_cnt) - CTX.scan_base - 1
+    elif at == 13:
+        site, a = S.SITE_STALL_ISOLATE, int(loc["dev_id"])
+        b = CTX.next_occ(site, a)
+    else:
+        raise RuntimeError(f"unmapped _stall caller: action_type={at} at {caller.f_code.co_name}:{caller.f_lineno}")
+    return R.randint(CTX.draw(site, a, b), lo, hi)
+
+
+def _inj_choice(seq):
+    if not CTX.active:
+        return _ORIG["choice"](seq)
+    fr = _frames()
+    name = fr[0].f_code.co_name
+    if name == "_random_incident_unblocked_edge":
+        a = fr[0].f_locals["device_name"]
+        site = S.SITE_PICK_BLOCK
+        b = CTX.next_occ(site, a)
+        return seq[R.index(CTX.draw(site, a, b), len(seq))]
+    if name == "_random_incident_blocked_edge":
+        a = fr[0].f_locals["device_name"]
+        site = S.SITE_PICK_UNBLOCK
+        b = CTX.next_occ(site, a)
+        return seq[R.index(CTX.draw(site, a, b), len(seq))]
+    if name == "pick_from":
+        evo = _find(fr, "evolve_network")
+        env = evo.f_locals["self"]
+        s = fr[0].f_locals["s"]
+        site = S.SITE_EVO_PICK_IN if s is env._inactive_ids else S.SITE_EVO_PICK_ACT
+        ev = evo.f_locals["_"]
+        canon = sorted(seq)
+        return canon[R.index(CTX.draw(site, ev, 0), len(canon))]
+    if name == "step":
+        loc = fr[0].f_locals
+        if "probe_from_device_id" not in loc and loc.get("action_type") == 1:
+            site = S.SITE_ZERODAY
+            a = CTX.next_occ(site, 0)
+            canon = sorted(seq)
+            return canon[R.index(CTX.draw(site, a, 0), len(canon))]
+        if loc.get("action_type") == 2:
+            return seq[R.index(CTX.draw(S.SITE_PROBE_SRC, 0, 0), len(seq))]
+    if name == "<listcomp>" and fr[1].f_code.co_name == "batch_predict":
+        step = _find(fr, "step")
+        env = step.f_locals["self"]
+        b = int(env.scan_cnt) - CTX.scan_base - 1
+        a = CTX.next_occ(S.SITE_DET_COIN, b)
+        return seq[R.index(CTX.draw(S.SITE_DET_COIN, a, b), len(seq))]
+    raise RuntimeError(f"unmapped choice site: {name}:{fr[0].f_lineno}")
+
+
+def _inj_random():
+    if not CTX.active:
+        return _ORIG["random"]()
+    fr = _frames()
+    name = fr[0].f_code.co_name
+    if name == "evolve_network":
+        ev = fr[0].f_locals["_"]
+        k = CTX.next_occ(S.SITE_EVO_COIN, ev)
+        site = S.SITE_EVO_COIN if k == 0 else S.SITE_EVO_ATT
+        return CTX.draw(site, ev, 0) / 4294967296.0
+    if name == "generate_workloads":
+        return CTX.draw(S.SITE_LAZY, fr[0].f_locals["did"], 0) / 4294967296.0
+    raise RuntimeError(f"unmapped random() site: {name}:{fr[0].f_lineno}")
+
+
+def _keyed_order(site, ids):
+    keyed = sorted((CTX.draw(site, int(i), 0), int(i)) for i in ids)
+    return [i for _, i in keyed]
+
+
+def _inj_sample(population, k):
+    if not CTX.active:
+        return _ORIG["sample"](population, k)
+    fr = _frames()
+    if fr[0].f_code.co_name != "generate_workloads":
+        raise RuntimeError(f"unmapped sample site: {fr[0].f_code.co_name}:{fr[0].f_lineno}")
+    wtype = fr[0].f_locals["wtype"]
+    site = S.SITE_ARR_CLIENT if wtype == "client" else S.SITE_ARR_SERVER
+    if k > len(population):
+        raise ValueError("sample larger than population")
+    return _keyed_order(site, population)[:k]
+
+
+def _inj_shuffle(lst):
+    if not CTX.active:
+        return _ORIG["shuffle"](lst)
+    fr = _frames()
+    if fr[0].f_code.co_name != "randomize_compromise_and_ownership":
+        raise RuntimeError(f"unmapped shuffle site: {fr[0].f_code.co_name}:{fr[0].f_lineno}")
+    by_id = {d.id: d for d in lst}
+    order = _keyed_order(S.SITE_SHUFFLE, by_id.keys())
+    lst[:] = [by_id[i] for i in order]
+
+
+def _inj_uniform(a, b):
+    if not CTX.active:
+        return _ORIG["uniform"](a, b)
+    fr = _frames()
+    evo = _find(fr, "evolve_network")
+    if evo is None:
+        raise RuntimeError(f"unmapped uniform site: {fr[0].f_code.co_name}:{fr[0].f_lineno}")
+    nid = evo.f_locals["nid"]
+    return a + (b - a) * (CTX.draw(S.SITE_EVO_PA, int(nid), 0) / 4294967296.0)
+
+
+def _inj_poisson(lam=1.0, size=None):
+    if not CTX.active:
+        return _ORIG["poisson"](lam, size)
+    tab = R.poisson_table(float(lam), S.POISSON_TABLE)
+    return R.cdf_lookup(CTX.draw(S.SITE_EVO_POISSON, 0, 0), tab)
+
+
+def _inj_triangular(left, mode, right, size=None):
+    if not CTX.active:
+        return _ORIG["triangular"](left, mode, right, size)
+    fr = _frames()
+    if fr[0].f_code.co_name != "generate_workloads" or left != 0:
+        raise RuntimeError(f"unmapped triangular site: {fr[0].f_code.co_name}:{fr[0].f_lineno}")
+    did = fr[0].f_locals["did"]
+    tab = R.triangular_ceil_table(float(mode), float(right), S.TRI_TABLE)
+    val = 1 + R.cdf_lookup(CTX.draw(S.SITE_ARR_TIME, int(did), 0), tab)
+    return np.array([float(val)])
+
+
+def install_rng():
+    mods = load_reference()
+    rnd = mods["random"]
+    if _ORIG:
+        return
+    _ORIG.update(randint=rnd.randint, choice=rnd.choice, random=rnd.random, sample=rnd.sample,
+                 shuffle=rnd.shuffle, uniform=rnd.uniform,
+                 poisson=np.random.poisson, triangular=np.random.triangular)
+    rnd.randint = _inj_randint
+    rnd.choice = _inj_choice
+    rnd.random = _inj_random
+    rnd.sample = _inj_sample
+    rnd.shuffle = _inj_shuffle
+    rnd.uniform = _inj_uniform
+    np.random.poisson = _inj_poisson
+    np.random.triangular = _inj_triangular
+
+
+# --------------------------------------------------------------------------
+# building an environment and flattening it
+# --------------------------------------------------------------------------
+def build_env(M, n_active, *, init_seed=1, overrides=None, strip_vuln_frac=0.0,
+              extra_reachable=0, prewarm_star=False):
+    """Construct and initialise a reference environment (init uses plain seeded MT;
+    initialisation is outside the parity path -- the harness exports its result)."""
+    mods = load_reference()
+    rnd = mods["random"]
+    rnd.seed(init_seed)
+    np.random.seed(init_seed)
+    import io
+    import contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        env = mods["vte"].Volt_Typhoon_CyberDefenseEnv()
+        env.numOfDevice = int(n_active)
+        env.Max_network_size = int(M)
+        env.base_line = "Nash"
+        env.tech = "DO"
+        env.mode = "defender"
+        env.zero_day = False
+        env.its = 0
+        for k, v in (overrides or {}).items():
+            setattr(env, k, v)
+        env.initialize_environment()
+        env._rebuild_graph_cache()      # what DoubleOracle.restore does (do_agent.py:893)
+    # scenario diversification through the reference's own object API
+    rr = np.random.RandomState(init_seed + 77)
+    devs = list(env.simulator.subnet.net.values())
+    if strip_vuln_frac > 0:
+        for d in devs:
+            if d.attacker_owned:
+                continue
+            if rr.rand() < strip_vuln_frac:
+                for app in d.apps.values():
+                    app.vulnerabilities.clear()
+    for _ in range(extra_reachable):
+        d = devs[rr.randint(len(devs))]
+        d.reachable_by_attacker = True
+    if prewarm_star:
+        # let the reference's own evolve_network() materialise the attacker star edges
+        # (CyberDefenseEnv.py:738-774) once, with no Poisson events, before the export
+        lam = env.lambda_events
+        env.lambda_events = 0.0
+        env.evolve_network()
+        env.lambda_events = lam
+        env._rebuild_graph_cache()
+    return env
+
+
+def exploit_index_map(env):
+    ids = [e.id for e in env.simulator.exploits]
+    return {eid: i for i, eid in reversed(list(enumerate(ids)))}
+
+
+def flatten_static(env):
+    """Topology + static per-device columns, as the kernels consume them."""
+    net = env.simulator.subnet.net
+    ids = list(net.keys())
+    M = len(ids)
+    assert ids == list(range(M)), "device ids must be 0..M-1 in dict order"
+    exps = env.simulator.exploits
+    X = len(exps)
+    dstatic = np.zeros(M, np.uint8)
+    vuln = np.zeros(M, np.uint8)
+    napps = np.zeros(M, np.uint8)
+    os_val = np.zeros(M, np.float32)
+    version = np.zeros(M, np.float32)
+    anomaly = np.zeros(M, np.float32)
+    for i, d in net.items():
+        if getattr(d, "device_type", None) == "DomainController":
+            dstatic[i] |= S.D_DC
+        if d.wtype == "server":
+            dstatic[i] |= S.D_SERVER
+        napps[i] = min(255, len(d.apps))
+        for e, ex in enumerate(exps):
+            hit = any(v.id in ex.target for app in d.apps.values() for v in app.vulnerabilities.values())
+            if hit:
+                vuln[i] |= (1 << e)
+        os_val[i] = env.os_to_float(d.OS)
+        try:
+            version[i] = float(d.version)
+        except Exception:
+            version[i] = -1.0
+        a = d.anomaly_score
+        anomaly[i] = -1.0 if a is None else float(a)
+    out_ptr = np.zeros(M + 1, np.int32)
+    out_col = []
+    for u in range(M):
+        nb = env._outnbrs.get(u, [])
+        out_col.extend(int(v) for v in nb)
+        out_ptr[u + 1] = len(out_col)
+    out_col = np.asarray(out_col, np.int32)
+    # in-CSR in the order of env._innbrs, each entry mapped to an out-CSR slot
+    in_ptr = np.zeros(M + 1, np.int32)
+    in_col, in_eid = [], []
+    used = {}
+    for v in range(M):
+        for u in env._innbrs.get(v, []):
+            u = int(u)
+            k = used.get((u, v), 0)
+            row = out_col[out_ptr[u]:out_ptr[u + 1]]
+            pos = [j for j, w in enumerate(row) if w == v]
+            assert k < len(pos), f"in-edge ({u},{v}) has no matching out entry"
+            in_col.append(u)
+            in_eid.append(int(out_ptr[u]) + pos[k])
+            used[(u, v)] = k + 1
+        in_ptr[v + 1] = len(in_col)
+    return dict(M=M, X=X, dstatic=dstatic, vuln=vuln, napps=napps, os_val=os_val, version=version,
+                anomaly=anomaly, out_ptr=out_ptr, out_col=out_col, in_ptr=in_ptr,
+                in_col=np.asarray(in_col, np.int32), in_eid=np.asarray(in_eid, np.int32))
+
+
+def flatten_config(env):
+    return dict(
+        num_of_device=int(env.numOfDevice), min_network_size=int(env.Min_network_size),
+        max_exploits=int(env.MaxExploits), evolve_period=int(env._evolve_period),
+        work_scale=float(env.work_scale), comp_scale=float(env.comp_scale), def_scale=float(env.def_scale),
+        gamma=float(env.γ), lambda_events=float(env.lambda_events), p_add=float(env.p_add),
+        p_attacker=float(env.p_attacker),
+        workload_cap=(-1 if env.workload_cap is None else int(env.workload_cap)),
+        workload_period_base=int(env.workload_period_base), workload_period_max=int(env.workload_period_max),
+        scaling_vulnerability=int(bool(env.scaling_vulnerability)), fast_scan=int(bool(env.fast_scan)),
+        n_att_actions=int(env.attacker_action_space.n), n_def_actions=int(env.defender_action_space.n),
+        zero_day=int(bool(env.zero_day)), default_high=int(env.default_high),
+        baseline={"Nash": 0, "No Defense": 1, "Preset": 2, "No Attack": 3}[env.base_line],
+        zero_day_owned_mask=zero_day_mask(env),
+    )
+
+
+def zero_day_mask(env):
+    if not getattr(env, "zero_day", False):
+        return 0
+    m = 0
+    for i in set(env.common_exploit_indices) | set(env.private_exploit_indices):
+        m |= (1 << int(i))
+    return m
+
+
+def flatten_dynamic(env, static):
+    """Per-env mutable state as the SoA planes of include/cygym_spec.h."""
+    net = env.simulator.subnet.net
+    M = static["M"]
+    emap = exploit_index_map(env)
+    flags = np.zeros(M, np.uint8)
+    busy = np.zeros(M, np.int32)
+    wl = np.zeros(M, np.int32)
+    comp_by = np.zeros(M, np.uint8)
+    st_flags = np.zeros(M, np.uint8)
+    st_busy = np.zeros(M, np.int32)
+    st_wl = np.zeros(M, np.int32)
+    st_comp_by = np.zeros(M, np.uint8)
+    active_ids = getattr(env, "_active_ids", None)
+    busy_set = env._busy_devices
+    busy_ids = {d.id for d in busy_set} if not isinstance(busy_set, dict) else {d.id for d in busy_set.keys()}
+    for i, d in net.items():
+        f = 0
+        if d.isCompromised: f |= S.F_COMP
+        if d.attacker_owned: f |= S.F_OWNED
+        if d.Known_to_attacker: f |= S.F_KNOWN
+        if d.reachable_by_attacker: f |= S.F_REACH
+        if d.Not_yet_added: f |= S.F_NYA
+        if active_ids is not None and i in active_ids: f |= S.F_EVOACT
+        if i in busy_ids: f |= S.F_BUSYC
+        w = d.workload
+        if w is not None:
+            pt = int(w.processing_time or 0)
+            wl[i] = pt
+            if getattr(w, "adversarial", False): f |= S.F_WLADV
+        flags[i] = f
+        busy[i] = int(d.busy_time or 0)
+        for eid in d.compromised_by:
+            comp_by[i] |= (1 << emap[eid])
+        st = env._device_ckpts.get(i)
+        if st is not None:
+            sf = S.S_VALID
+            if st["isCompromised"]: sf |= S.F_COMP
+            if st["Known_to_attacker"]: sf |= S.F_KNOWN
+            if st["reachable_by_attacker"]: sf |= S.F_REACH
+            if st["Not_yet_added"]: sf |= S.F_NYA
+            sw = st["workload"]
+            if sw:
+                st_wl[i] = int(sw["processing_time"])
+                if sw["adversarial"]: sf |= S.F_WLADV
+            st_flags[i] = sf
+            st_busy[i] = int(st["busy_time"])
+            for eid in st["compromised_by"]:
+                st_comp_by[i] |= (1 << emap[eid])
+    E = len(static["out_col"])
+    blocked = np.zeros(E, np.uint8)
+    for (u, v) in env._blocked:
+        lo, hi = static["out_ptr"][u], static["out_ptr"][u + 1]
+        for j in range(lo, hi):
+            if static["out_col"][j] == v:
+                blocked[j] = 1
+    logs = env.simulator.logger.logs
+    ring = np.full((S.LOG_RING, 2), -1, np.int32)
+    tail = logs[-S.LOG_RING:]
+    base = len(logs) - len(tail)
+    for k, l in enumerate(tail):
+        ring[(base + k) % S.LOG_RING] = (int(l["from_device"]), int(l["to_device"]))
+    ienv = np.zeros(S.I_COUNT, np.int64)
+    ienv[S.I_STEP_NUM] = env.step_num
+    ienv[S.I_DEF_STEP] = env.defender_step
+    ienv[S.I_ATT_STEP] = env.attacker_step
+    ienv[S.I_WORK_DONE] = env.work_done
+    ienv[S.I_CKPT_CNT] = env.checkpoint_count
+    ienv[S.I_REVERT_CNT] = env.revert_count
+    ienv[S.I_SCAN_CNT] = env.scan_cnt
+    ienv[S.I_COMP_CNT] = env.compromised_devices_cnt
+    ienv[S.I_EDGES_BLOCKED] = env.edges_blocked
+    ienv[S.I_EDGES_ADDED] = env.edges_added
+    ef = 0
+    if env.checkpoint is not None: ef |= S.E_HAS_CKPT
+    if active_ids is not None: ef |= S.E_EVO_INIT
+    det = env.simulator.detector
+    if det.trained: ef |= S.E_DET_TRAIN
+    if det.random_detection: ef |= S.E_DET_RANDOM
+    if getattr(env, "_prev_att_potential", None) is not None: ef |= S.E_PREV_SET
+    ienv[S.I_FLAGS] = ef
+    ienv[S.I_LOG_TOTAL] = len(logs)
+    disc = 0
+    for e, ex in enumerate(env.simulator.exploits):
+        if getattr(ex, "discovered", False):
+            disc |= (1 << e)
+    ienv[S.I_DISCOVERED] = disc
+    fenv = np.zeros(S.D_COUNT, np.float64)
+    fenv[S.D_DEF_COST] = env.defensive_cost
+    fenv[S.D_CLEAN_COST] = env.clearning_cost
+    pp = getattr(env, "_prev_att_potential", None)
+    fenv[S.D_PREV_ATT_POT] = 0.0 if pp is None else float(pp)
+    return dict(flags=flags, busy=busy, wl=wl, comp_by=comp_by, st_flags=st_flags, st_busy=st_busy,
+                st_wl=st_wl, st_comp_by=st_comp_by, blocked=blocked, ring=ring, ienv=ienv, fenv=fenv)
+
+
+def topology_signature(env):
+    return tuple((u, tuple(v)) for u, v in sorted(env._outnbrs.items()))
+
+
+# --------------------------------------------------------------------------
+# scenario runner
+# --------------------------------------------------------------------------
+def run_scenario(env0, n_envs, n_ticks, action_fn, *, seed=0, env_id_base=0, pre_fn=None,
+                 record_draws=False):
+    """Deep-copy `env0` n_envs times, drive each with `action_fn(e, t, env, rs)` ->
+    (mode, action) and record the flattened state after every tick.
+
+    `action` is whatever the reference's step() accepts (None, a 4-tuple, or a list of
+    4-tuples for step_grouped).  Returns a dict of stacked arrays."""
+    install_rng()
+    static = flatten_static(env0)
+    config = flatten_config(env0)
+    sig0 = topology_signature(env0)
+    M = static["M"]
+    per_env = []
+    for e in range(n_envs):
+        env = copy.deepcopy(env0)
+        env._rebuild_graph_cache()
+        rs = np.random.RandomState(10007 * (seed + 1) + e)
+        env_id = env_id_base + e
+        rng_tick = 0
+        pre_dyn = flatten_dynamic(env, static)
+        if pre_fn is not None:
+            CTX.begin(seed, env_id, rng_tick, env)
+            try:
+                if pre_fn(e, env, rs):
+                    rng_tick += 1
+            finally:
+                CTX.end()
+        init_dyn = flatten_dynamic(env, static)
+        init_dyn["ienv"][S.I_RNG_TICK] = rng_tick
+        ticks = []
+        acts = []
+        for t in range(n_ticks):
+            mode, action = action_fn(e, t, env, rs)
+            env.mode = "defender" if mode == S.MODE_DEFENDER else "attacker"
+            CTX.begin(seed, env_id, rng_tick, env)
+            err = None
+            try:
+                state, raw, shaped, done, info, logs = env.step(action)
+            except ValueError as ex:   # malformed 11/12/13 actions raise in the reference
+                err = str(ex)
+            finally:
+                CTX.end()
+            if err is not None:
+                raise RuntimeError(f"scenario produced a reference exception at env {e} tick {t}: {err}")
+            rng_tick += 1
+            dyn = flatten_dynamic(env, static)
+            dyn["ienv"][S.I_RNG_TICK] = rng_tick
+            dyn["ienv"][S.I_LAST_ATYPE] = int(info.get("executed_atype", -1)) if isinstance(info, dict) else -1
+            dyn["raw"] = float(raw)
+            dyn["shaped"] = float(shaped)
+            dyn["done"] = int(bool(done))
+            dyn["obs"] = np.asarray(state, np.float64).reshape(M, 6).astype(np.float32)
+            dyn["obs_def"] = np.asarray(env._get_defender_state(), np.float64).astype(np.float32)
+            dyn["obs_att"] = np.asarray(env._get_attacker_state(), np.float32)
+            dyn["topo_same"] = int(topology_signature(env) == sig0)
+            if record_draws:
+                dyn["draws"] = list(CTX.trace)
+            ticks.append(dyn)
+            acts.append((mode, action))
+        per_env.append(dict(init=init_dyn, pre=pre_dyn, ticks=ticks, acts=acts))
+    return dict(static=static, config=config, envs=per_env, seed=seed, env_id_base=env_id_base)
+
+
+def encode_actions(acts, M, max_groups=1):
+    """Encode reference-style actions into the flat form of the C ABI.
+    Returns dict(mode[T], n_groups[T], atype[T,G], exploit[T,G,X], n_exploit[T,G],
+    dev_ptr / dev_idx (ragged), app[T,G])."""
+    T = len(acts)
+    G = max_groups
+    mode = np.zeros(T, np.int32)
+    ng = np.zeros(T, np.int32)
+    atype = np.zeros((T, G), np.int32)
+    nexp = np.zeros((T, G), np.int32)
+    expl = np.full((T, G, S.MAX_EXPLOITS), -1, np.int32)
+    app = np.full((T, G), -1, np.int32)
+    dev_cnt = np.zeros((T, G), np.int32)
+    dev_flat = []
+    for t, (m, a) in enumerate(acts):
+        mode[t] = m
+        groups = a if (isinstance(a, (list, tuple)) and a and isinstance(a[0], (list, tuple))) else [a]
+        grouped = groups is a
+        ng[t] = len(groups) if grouped else 0      # 0 => single-action step()
+        assert len(groups) <= G
+        for g, (at, ex, dv, ap) in enumerate(groups):
+            atype[t, g] = int(at)
+            ex = [] if ex is None else list(np.asarray(ex).reshape(-1))
+            assert len(ex) <= S.MAX_EXPLOITS
+            nexp[t, g] = len(ex)
+            for j, x in enumerate(ex):
+                expl[t, g, j] = int(x)
+            dv = [] if dv is None else [int(x) for x in np.asarray(dv).reshape(-1)]
+            dev_cnt[t, g] = len(dv)
+            dev_flat.extend(dv)
+            app[t, g] = int(ap) if isinstance(ap, int) and not isinstance(ap, bool) else -1
+    return dict(mode=mode, n_groups=ng, atype=atype, n_exploit=nexp, exploit=expl, app=app,
+                dev_cnt=dev_cnt, dev_flat=np.asarray(dev_flat, np.int32))
+
+
+def save_fixture(path, result, max_groups=1):
+    """Write one scenario as a compressed .npz of plain arrays (no pickles)."""
+    st, cfg = result["static"], result["config"]
+    out = {f"static_{k}": np.asarray(v) for k, v in st.items()}
+    out["config_keys"] = np.array(sorted(cfg.keys()))
+    out["config_vals"] = np.array([float(cfg[k]) for k in sorted(cfg.keys())], np.float64)
+    out["seed"] = np.int64(result["seed"])
+    out["env_id_base"] = np.int64(result["env_id_base"])
+    envs = result["envs"]
+    N = len(envs)
+    T = len(envs[0]["ticks"])
+    keys = ["flags", "busy", "wl", "comp_by", "st_flags", "st_busy", "st_wl", "st_comp_by",
+            "blocked", "ring", "ienv", "fenv"]
+    for k in keys:
+        out[f"init_{k}"] = np.stack([e["init"][k] for e in envs])
+        out[f"pre_{k}"] = np.stack([e["pre"][k] for e in envs])
+        out[f"exp_{k}"] = np.stack([np.stack([tk[k] for tk in e["ticks"]]) for e in envs])
+    for k in ["raw", "shaped", "done", "obs", "obs_def", "obs_att", "topo_same"]:
+        out[f"exp_{k}"] = np.stack([np.stack([np.asarray(tk[k]) for tk in e["ticks"]]) for e in envs])
+    enc = [encode_actions(e["acts"], st["M"], max_groups) for e in envs]
+    for k in ["mode", "n_groups", "atype", "n_exploit", "exploit", "app", "dev_cnt"]:
+        out[f"act_{k}"] = np.stack([a[k] for a in enc])
+    out["act_dev_ptr"] = np.cumsum([0] + [len(a["dev_flat"]) for a in enc]).astype(np.int64)
+    out["act_dev_flat"] = np.concatenate([a["dev_flat"] for a in enc]) if enc else np.zeros(0, np.int32)
+    # narrow dtypes for size
+    for k in list(out.keys()):
+        v = out[k]
+        if isinstance(v, np.ndarray) and v.dtype == np.int64 and k not in ("act_dev_ptr",):
+            if v.size and np.abs(v).max() < 2 ** 31:
+                out[k] = v.astype(np.int32)
+    np.savez_compressed(path, **out)
+    return N, T

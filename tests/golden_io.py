@@ -1,0 +1,131 @@
+"""Load tests/golden/*.npz (written by oracle/harness/make_golden.py from runs of
+the reference itself) into the structures the oracle / HIP library consume."""
+from __future__ import annotations
+
+import glob
+import os
+
+import numpy as np
+
+from cygym_amd import abi
+from cygym_amd import spec as S
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+STATE_KEYS = ["flags", "busy", "wl", "comp_by", "st_flags", "st_busy", "st_wl", "st_comp_by",
+              "blocked", "ring", "ienv", "fenv"]
+
+
+def fixture_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+
+
+class Fixture:
+    def __init__(self, name):
+        z = np.load(os.path.join(GOLDEN, name + ".npz"))
+        self.name = name
+        self.z = z
+        st = {k[len("static_"):]: z[k] for k in z.files if k.startswith("static_")}
+        self.topo = abi.TopologyArrays(
+            M=int(st["M"]), X=int(st["X"]), dstatic=st["dstatic"], vuln=st["vuln"], napps=st["napps"],
+            os_val=st["os_val"], version=st["version"], anomaly=st["anomaly"], out_ptr=st["out_ptr"],
+            out_col=st["out_col"], in_ptr=st["in_ptr"], in_col=st["in_col"], in_eid=st["in_eid"]).normalised()
+        cfg = dict(zip([str(k) for k in z["config_keys"]], z["config_vals"]))
+        inv = {v: k for k, v in abi.BASELINES.items()}
+        self.cfg = abi.EnvConfig(
+            seed=int(z["seed"]), env_id_base=int(z["env_id_base"]),
+            num_of_device=int(cfg["num_of_device"]), min_network_size=int(cfg["min_network_size"]),
+            max_exploits=int(cfg["max_exploits"]), evolve_period=int(cfg["evolve_period"]),
+            workload_cap=int(cfg["workload_cap"]), workload_period_base=int(cfg["workload_period_base"]),
+            workload_period_max=int(cfg["workload_period_max"]),
+            scaling_vulnerability=int(cfg["scaling_vulnerability"]), fast_scan=int(cfg["fast_scan"]),
+            n_att_actions=int(cfg["n_att_actions"]), n_def_actions=int(cfg["n_def_actions"]),
+            zero_day=int(cfg["zero_day"]), zero_day_owned_mask=int(cfg["zero_day_owned_mask"]),
+            default_high=int(cfg["default_high"]), baseline=inv[int(cfg["baseline"])],
+            work_scale=cfg["work_scale"], comp_scale=cfg["comp_scale"], def_scale=cfg["def_scale"],
+            gamma=cfg["gamma"], lambda_events=cfg["lambda_events"], p_add=cfg["p_add"],
+            p_attacker=cfg["p_attacker"])
+        self.N = z["init_flags"].shape[0]
+        self.T = z["exp_flags"].shape[1]
+        self.M = self.topo.M
+        self.G = z["act_atype"].shape[2]
+        self.init = {k: z["init_" + k] for k in STATE_KEYS}
+        self.pre = {k: z["pre_" + k] for k in STATE_KEYS} if "pre_flags" in z.files else None
+        self.exp = {k: z["exp_" + k] for k in STATE_KEYS}
+        for k in ("raw", "shaped", "done", "obs", "obs_def", "obs_att", "topo_same"):
+            self.exp[k] = z["exp_" + k]
+        # per-env flat device lists -> padded [N][T][L]
+        ptr = z["act_dev_ptr"]
+        cnt = z["act_dev_cnt"]            # [N][T][G]
+        self.L = max(1, int(cnt.sum(axis=2).max()))
+        self.dev = np.zeros((self.N, self.T, self.L), np.int16)
+        flat = z["act_dev_flat"]
+        for e in range(self.N):
+            row = flat[ptr[e]:ptr[e + 1]]
+            per_t = cnt[e].sum(axis=1)
+            off = np.concatenate([[0], np.cumsum(per_t)])
+            for t in range(self.T):
+                self.dev[e, t, :per_t[t]] = row[off[t]:off[t + 1]]
+
+    def actions(self, t, alloc):
+        """Fill an action dict (oracle.driver.alloc_actions / torch mirror) for tick t."""
+        z = self.z
+        alloc["mode"][:] = z["act_mode"][:, t]
+        alloc["n_groups"][:] = z["act_n_groups"][:, t]
+        alloc["atype"][:] = z["act_atype"][:, t]
+        alloc["n_exploit"][:] = z["act_n_exploit"][:, t]
+        alloc["exploit"][:] = z["act_exploit"][:, t]
+        alloc["app"][:] = z["act_app"][:, t]
+        alloc["dev_cnt"][:] = z["act_dev_cnt"][:, t]
+        alloc["dev_idx"][:] = self.dev[:, t]
+        return alloc
+
+    def expected_state(self, t):
+        out = {}
+        for k in STATE_KEYS:
+            v = self.exp[k][:, t]
+            if k == "blocked":
+                v = abi.pack_blocked(v, self.topo.EW)
+            if k == "ring":
+                v = np.where(v < 0, 0xFFFF, v).astype(np.uint16)
+            out[k] = v
+        return out
+
+
+def compare_state(got: dict, exp: dict, label: str, ring_total=None):
+    """Bit-exact comparison of the integer planes; returns list of mismatch strings."""
+    bad = []
+    for k in ["flags", "busy", "wl", "comp_by", "st_flags", "st_busy", "st_wl", "st_comp_by", "blocked"]:
+        g = np.asarray(got[k]).astype(np.int64)
+        x = np.asarray(exp[k]).astype(np.int64)
+        if not np.array_equal(g, x):
+            idx = np.argwhere(g != x)[0]
+            bad.append(f"{label}: {k} differs at {tuple(idx)}: got {g[tuple(idx)]} exp {x[tuple(idx)]}")
+    gi = np.asarray(got["ienv"]).astype(np.int64)
+    xi = np.asarray(exp["ienv"]).astype(np.int64)
+    cols = [c for c in range(S.I_COUNT) if c not in (S.I_LAST_NCOMP,)]
+    # TOPO_OVF / BUSY_SAT are build-side diagnostics the reference does not have
+    mask = ~(S.E_TOPO_OVF | S.E_BUSY_SAT)
+    gi2, xi2 = gi.copy(), xi.copy()
+    gi2[:, S.I_FLAGS] &= mask
+    xi2[:, S.I_FLAGS] &= mask
+    for c in cols:
+        if not np.array_equal(gi2[:, c], xi2[:, c]):
+            e = int(np.argwhere(gi2[:, c] != xi2[:, c])[0][0])
+            bad.append(f"{label}: ienv[{c}] env {e}: got {gi2[e, c]} exp {xi2[e, c]}")
+    # ring: only the valid window (last min(total, R) entries) is defined
+    gr = np.asarray(got["ring"]).astype(np.int64).reshape(gi.shape[0], S.LOG_RING, 2)
+    xr = np.asarray(exp["ring"]).astype(np.int64).reshape(gi.shape[0], S.LOG_RING, 2)
+    for e in range(gi.shape[0]):
+        tot = int(xi[e, S.I_LOG_TOTAL])
+        n = min(tot, S.LOG_RING)
+        for j in range(tot - n, tot):
+            if not np.array_equal(gr[e, j % S.LOG_RING], xr[e, j % S.LOG_RING]):
+                bad.append(f"{label}: ring env {e} slot {j % S.LOG_RING}: got {gr[e, j % S.LOG_RING]} exp {xr[e, j % S.LOG_RING]}")
+                break
+    gf = np.asarray(got["fenv"], np.float64)
+    xf = np.asarray(exp["fenv"], np.float64)
+    if not np.allclose(gf, xf, rtol=0, atol=1e-9):
+        idx = np.argwhere(~np.isclose(gf, xf, rtol=0, atol=1e-9))[0]
+        bad.append(f"{label}: fenv differs at {tuple(idx)}: got {gf[tuple(idx)]} exp {xf[tuple(idx)]}")
+    return bad
