@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of the batched CyGym tick on MI355X.
+
+One "step" = one tick (cygym_step) of every env of the batch, on synthetic input:
+the fixed-topology generator (cygym_amd/topology.py) and the alternating
+defender/attacker action script, pre-generated on device so
+that all inputs are resident in HBM when the timed region starts.
+
+Contract (see the task description): `python bench.py --gpus N --steps K --warmup W`;
+for N > 1 the driver launches one rank per GPU with torch.distributed.run.  Envs are
+independent, so ranks shard the batch by env id (weak scaling: per-GPU envs fixed) and
+there is NO collective on the step path; the only collectives are the barrier and the
+MAX-over-ranks of the timing.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (envs per GPU, devices, blocks, description)
+    "target": (4096, 256, 1, "north-star target: 4096 envs x 256 devices, Volt-Typhoon roles"),
+    "cfg2": (4096, 64, 4, "BASELINE configs[1]: 4096 envs x 64 devices / 4 subnets"),
+    "cfg3": (16384, 256, 1, "BASELINE configs[2]: 16384 envs x 256 devices"),
+    "cfg5": (4096, 2048, 32, "BASELINE configs[4]: 4096 envs x 2048 devices / 32 subnets"),
+}
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(M: int, E: int) -> float:
+    """B(M,E) = M*(S_r+S_w) + M*O_w + 2*ceil(E/8) + A, S_r=S_w=8, O_w=24, A=M/8+16."""
+    return M * 16.0 + M * 24.0 + 2.0 * ((E + 7) // 8) + (M / 8.0 + 16.0)
+
+
+def layout_bytes(M: int, E: int) -> float:
+    """What this build's layout must move per env-step at minimum: 3 live planes r+w (flags, busy, wl),
+    comp_by read, obs write, env scalars r+w, action header + mean list; blocked bitmask only on
+    attacker / edge ticks (counted at 1/2)."""
+    return M * 3 * 2 + M + M * 24.0 + 2 * (16 * 4 + 3 * 8) + 48 + M / 8.0 + 0.5 * 4 * ((E + 31) // 32)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="target", choices=sorted(WORKLOADS))
+    ap.add_argument("--envs", type=int, default=0, help="override envs per GPU")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from cygym_amd import abi
+    from cygym_amd.batched_env import BatchedCyberDefenseEnv
+    from cygym_amd.topology import make_topology
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+
+    n_per_gpu, M, blocks, desc = WORKLOADS[args.workload]
+    if args.envs:
+        n_per_gpu = args.envs
+    topo, init, ck = make_topology(M, blocks, seed=args.seed)
+    # fixed-topology roofline run: lambda_events = 0; everything else at reference defaults
+    cfg = abi.EnvConfig(seed=args.seed, env_id_base=rank * n_per_gpu, auto_reset=1, lambda_events=0.0, **ck)
+    L = max(1, M // 8)
+    env = BatchedCyberDefenseEnv(topo, cfg, n_per_gpu, init, device=dev, max_groups=1, max_devs=L)
+
+    K, W = args.steps, args.warmup
+    # pre-generate the action script for every tick: inputs resident in HBM before timing
+    scripts = []
+    for t in range(W + K):
+        act = {k: torch.empty_like(v) for k, v in env.act.items()}
+        env.gen_actions(t, act)
+        scripts.append(act)
+    torch.cuda.synchronize(dev)
+
+    for t in range(W):
+        env.step(scripts[t])
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    env.timer_start()
+    for t in range(W, W + K):
+        env.step(scripts[t])
+    ev_ms = env.timer_stop()          # HIP events on the stream the kernels were launched on
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([wall, ev_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall, ev_ms = float(tt[0]), float(tt[1])
+
+    total_envs = n_per_gpu * world
+    value = total_envs * K / wall
+    launch_s = (ev_ms / 1e3) / K      # average launch duration over the timed region (incl. inter-kernel gaps)
+    B = algorithmic_bytes(M, topo.E)
+    achieved = n_per_gpu * B / launch_s / 1e9
+    ret_sum = float(env.raw.sum())
+
+    out = {
+        "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": wall / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {desc}", "envs_per_gpu": n_per_gpu, "devices": M, "edges": topo.E,
+                   "exploits": topo.X, "lambda_events": 0.0, "parallelism": f"env-batch split x{world}, no step-path collective"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "bytes_per_env_step": B, "layout_bytes_per_env_step": layout_bytes(M, topo.E),
+                     "kernel": "step_kernel", "launch_us": launch_s * 1e6},
+        "check": {"last_raw_reward_sum": ret_sum},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(topo, init, cfg, M, L, scripts, W, args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(out))
+    env.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(topo, init, cfg, M, L, scripts, W, budget_s):
+    """The CPU oracle (C restatement, single thread) on a bounded sample of the same workload:
+    the first n envs, replaying the same pre-generated script from the initial state until the
+    time budget is spent."""
+    from oracle import driver as od
+    n = min(1024, scripts[0]["mode"].shape[0])
+    ob = od.OracleBatch(topo, cfg, n)
+    acts = [{k: np.ascontiguousarray(v[:n].cpu().numpy()) for k, v in act.items()} for act in scripts]
+    steps = 0
+    t0 = time.perf_counter()
+    while True:
+        ob.load_state(init)
+        for a in acts:
+            ob.step(a)
+            steps += n
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"oracle/cygym_oracle.c, 1 thread: first {n} envs x {len(acts)} ticks of the same script, "
+                      f"replayed {steps // (n * len(acts))}x ({steps} env-steps in {dt:.1f} s)",
+            "host_cores_available": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,66 @@
+"""ctypes binding of libcygym_hip.so (the product's only compute path).
+
+There is NO CPU fallback: if the shared library is missing or a call fails, this
+module raises.  The CPU oracle under oracle/ is never imported from here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "libcygym_hip.so")
+
+EXPORTS = [
+    "cygym_version", "cygym_last_error", "cygym_create", "cygym_destroy", "cygym_set_config", "cygym_bind",
+    "cygym_set_snapshot", "cygym_reset", "cygym_randomize", "cygym_step", "cygym_observe", "cygym_gen_actions",
+    "cygym_timer_start", "cygym_timer_stop",
+]
+
+
+class CygymError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raise loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO):
+        raise CygymError(
+            f"{SO} is missing: build it with `python -m cygym_amd.build` (hipcc --offload-arch=gfx950). "
+            "cygym_amd has no CPU fallback.")
+    L = C.CDLL(SO)
+    H = C.c_void_p
+    L.cygym_version.restype = C.c_int
+    L.cygym_last_error.restype = C.c_char_p
+    L.cygym_last_error.argtypes = [H]
+    L.cygym_create.argtypes = [C.POINTER(abi.Topology), C.POINTER(abi.Config), C.c_int32, C.c_int32, C.POINTER(H)]
+    L.cygym_destroy.argtypes = [H]
+    L.cygym_destroy.restype = None
+    L.cygym_set_config.argtypes = [H, C.POINTER(abi.Config)]
+    L.cygym_bind.argtypes = [H, C.POINTER(abi.Buffers)]
+    L.cygym_set_snapshot.argtypes = [H, C.POINTER(abi.Buffers)]
+    L.cygym_reset.argtypes = [H, C.POINTER(abi.Buffers), C.c_void_p, C.c_int32, C.c_void_p]
+    L.cygym_randomize.argtypes = [H, C.c_void_p, C.c_int32, C.c_void_p]
+    L.cygym_step.argtypes = [H, C.POINTER(abi.Actions), C.POINTER(abi.Outputs), C.c_void_p]
+    L.cygym_observe.argtypes = [H, C.c_int32, C.c_void_p, C.c_void_p]
+    L.cygym_gen_actions.argtypes = [H, C.c_int32] + [C.c_void_p] * 8 + [C.c_int32, C.c_void_p]
+    L.cygym_timer_start.argtypes = [H, C.c_void_p]
+    L.cygym_timer_stop.argtypes = [H, C.c_void_p, C.POINTER(C.c_float)]
+    if L.cygym_version() != abi.ABI_VERSION:
+        raise CygymError(f"ABI mismatch: library {L.cygym_version()} vs python {abi.ABI_VERSION}")
+    _lib = L
+    return L
+
+
+def check(rc: int, handle=None, what: str = ""):
+    if rc != 0:
+        msg = load().cygym_last_error(handle)
+        raise CygymError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,1610 @@
+// cygym_hip.hip -- MI355X (gfx950, wave64) kernels + C ABI of the batched CyGym tick.
+//
+// Execution model: ONE WAVEFRONT PER ENVIRONMENT.  A workgroup of WPB waves stages
+// the shared topology (out-CSR row pointers + columns, static per-device columns)
+// into LDS once, then every wave stages its own env's struct-of-arrays state
+// (4 live byte planes + blocked-edge bitmask + log ring) into its private LDS
+// region, runs the whole tick there, streams the observation out with 16-byte
+// coalesced stores and writes the dirty planes back.  No MFMA: the path is
+// integer / bit / index / RNG work bound by HBM traffic.
+//
+// Parallel restatements of the reference's sequential loops (each checked
+// bit-for-bit against oracle/cygym_oracle.c, which keeps the reference's order):
+//   * attacker spread (volt_typhoon_env.py:1126-1185): sources are processed
+//     "in ascending id order, each seeing what earlier sources compromised".
+//     Here: every source picks its target in parallel against a per-device
+//     first-compromise time T[v] (atomicMin in LDS); iterate to the unique fix
+//     point (== the sequential result; proof sketch in DESIGN.md).  Long rows
+//     (attacker-owned hubs) are scanned 64 entries per step with ballot/ffs.
+//   * "r-th element of a list in dict order" (random.choice over devices):
+//     ballot + popcount ranking.
+//   * random.sample(candidates, k) (CDSimulator.py:298): k smallest
+//     (philox key, id) by a wave-wide radix select.
+//   * per-device defender actions: multiplicity counts via LDS atomics, so
+//     duplicate / unsorted device lists give the sequential result.
+//
+// Reference citations are relative to the reference checkout.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <new>
+#include "cygym_abi.h"
+
+#define CG_E_STAR_OK 0x80  // kernel-private: star edges verified for the current owned set
+
+namespace {
+
+constexpr int WAVE = 64;
+
+struct DevTopo {
+  int M, X, E, EW, MC, Mp;
+  const uint8_t *dstatic, *vuln, *napps;
+  const float *os_val, *version, *anomaly;
+  const uint16_t *out_ptr, *out_col;   // u16: E <= 65535, M <= 2048
+  const uint16_t *in_ptr, *in_col, *in_eid;
+};
+
+struct KParams {
+  DevTopo t;
+  cygym_config c;
+  cygym_buffers b;
+  cygym_buffers snap;   // snap.flags == nullptr when absent
+  cygym_actions a;
+  cygym_outputs o;
+  int n_envs;
+  int wave_lds;         // bytes of LDS per wave
+  int shared_lds;       // bytes of the workgroup-shared LDS section
+};
+
+// ---------------- wave-level helpers ----------------
+__device__ __forceinline__ void wsync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
+__device__ __forceinline__ int below(uint64_t m) {  // set bits of m below this lane
+  return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ int wave_or(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int n = __shfl_up(v, o);
+    if (lane >= o) v += n;
+  }
+  return v;
+}
+__device__ __forceinline__ int nth_bit(uint64_t m, int r) {  // position of the r-th set bit (uniform)
+  for (int i = 0; i < r; ++i) m &= m - 1;
+  return __builtin_ctzll(m);
+}
+
+// ---------------- per-wave environment view ----------------
+struct Env {
+  // LDS
+  uint8_t *flags, *busy, *wl, *cby;
+  uint32_t* scr;     // [2*Mp] scratch (8 bytes per device)
+  uint32_t* blk;     // [EWp]
+  uint16_t* ring;    // [2*CG_LOG_RING]
+  uint32_t* marks;   // [Mp/32 + 1]
+  // shared LDS (topology)
+  const uint16_t *optr, *ocol;
+  const uint8_t *dst, *vul;
+  const float *osv, *ver, *ano;
+  // misc
+  int M, MC, lane, env;
+  uint32_t env_id, tick;
+  uint64_t seed;
+  int eflags;        // CG_I_FLAGS (uniform)
+  bool blk_loaded, blk_dirty, ring_loaded, ring_dirty, cby_dirty;
+  int log_total;
+
+  __device__ __forceinline__ uint32_t draw(uint32_t site, uint32_t a, uint32_t b) const {
+    return cg_draw(seed, env_id, tick, site, a, b);
+  }
+  __device__ __forceinline__ bool blocked(int slot) const { return (blk[slot >> 5] >> (slot & 31)) & 1u; }
+  __device__ __forceinline__ void set_busy(int d, int v) {
+    if (v > 255) { v = 255; eflags |= CG_E_BUSY_SAT; }   // per-lane; OR-reduced at write-back
+    busy[d] = (uint8_t)v;
+  }
+};
+
+__device__ __forceinline__ void byte_or(uint8_t* base, int d, uint32_t bits) {
+  atomicOr((unsigned int*)(base + (d & ~3)), bits << ((d & 3) * 8));
+}
+
+// Stage / write back one [M]-byte plane (global <-> LDS), dword-wide when aligned.
+__device__ __forceinline__ void plane_load(uint8_t* dst, const uint8_t* src, int M, int lane) {
+  if ((M & 3) == 0) {
+    const uint32_t* s = (const uint32_t*)src;
+    uint32_t* d = (uint32_t*)dst;
+    for (int w = lane; w < (M >> 2); w += WAVE) d[w] = s[w];
+  } else {
+    for (int i = lane; i < M; i += WAVE) dst[i] = src[i];
+  }
+}
+__device__ __forceinline__ void plane_store(uint8_t* dst, const uint8_t* src, int M, int lane) {
+  if ((M & 3) == 0) {
+    const uint32_t* s = (const uint32_t*)src;
+    uint32_t* d = (uint32_t*)dst;
+    for (int w = lane; w < (M >> 2); w += WAVE) d[w] = s[w];
+  } else {
+    for (int i = lane; i < M; i += WAVE) dst[i] = src[i];
+  }
+}
+
+__device__ void ensure_blocked(Env& e, const KParams& P) {
+  if (e.blk_loaded) return;
+  const uint32_t* g = P.b.blocked + (size_t)e.env * P.t.EW;
+  for (int w = e.lane; w < P.t.EW; w += WAVE) e.blk[w] = g[w];
+  e.blk_loaded = true;
+  wsync();
+}
+__device__ void ensure_ring(Env& e, const KParams& P) {
+  if (e.ring_loaded) return;
+  const uint32_t* g = (const uint32_t*)(P.b.ring + (size_t)e.env * CG_LOG_RING * 2);
+  if (e.lane < CG_LOG_RING) ((uint32_t*)e.ring)[e.lane] = g[e.lane];
+  e.ring_loaded = true;
+  wsync();
+}
+
+// multiplicity of every device in a list -> bytes in scr (as uint8 [Mp]); ids >= M ignored.
+// returns (uniform) true when some device occurs more than 255 times (caller treats as unsupported)
+__device__ void list_counts(Env& e, const int16_t* dev, int L) {
+  uint32_t* w = e.scr;
+  for (int i = e.lane; i < (e.MC * WAVE) / 4; i += WAVE) w[i] = 0;
+  wsync();
+  for (int p = e.lane; p < L; p += WAVE) {
+    int d = dev[p];
+    if (d >= 0 && d < e.M) atomicAdd(&w[d >> 2], 1u << ((d & 3) * 8));
+  }
+  wsync();
+}
+
+// ---------------- defender ----------------
+__device__ void def_global(Env& e, const KParams& P, int at, const int16_t* dev, int L, double& cost,
+                           bool& dirty, bool grouped, int32_t* ie, double* fe) {
+  const double ds = P.c.def_scale;
+  const int M = e.M;
+  if (at == 2) {  // :918-926
+    ie[CG_I_CKPT_CNT] += 1;
+    e.eflags |= CG_E_HAS_CKPT;
+    cost += -0.5 * L * ds;
+    fe[CG_D_DEF_COST] += 0.5 * L * ds;
+    for (int d = e.lane; d < M; d += WAVE) if (e.busy[d] > 0) e.set_busy(d, e.busy[d] + 1);
+  } else if (at == 3) {  // :928-943
+    ie[CG_I_REVERT_CNT] += 1;
+    if (e.eflags & CG_E_HAS_CKPT) {
+      for (int d = e.lane; d < M; d += WAVE) {
+        e.busy[d] = (uint8_t)cg_randint(e.draw(CG_SITE_STALL_REVERT, d, 0), 0, P.c.default_high);
+        e.wl[d] = 0;
+        e.flags[d] &= (uint8_t)~CG_F_WLADV;
+      }
+      cost += -1.0 * L * ds;
+      dirty = true;
+    }
+  } else if (at == 10) {  // :945-962
+    if (!grouped) {
+      if (L > 0) {
+        int d = dev[0];
+        if (d >= 0 && d < M && e.lane == 0) e.set_busy(d, e.busy[d] + 1);
+      } else {
+        for (int d = e.lane; d < M; d += WAVE) if (e.busy[d] > 0) e.set_busy(d, e.busy[d] + 1);
+      }
+    }
+    cost += -1.0 * ds;
+    if (e.log_total > 0) { e.eflags |= CG_E_DET_TRAIN; e.eflags &= ~CG_E_DET_RANDOM; }
+  } else if (at == 11) {  // :964-976, _device_state :419-428
+    if (L > 0) {
+      int d = dev[0];
+      if (d >= 0 && d < M && e.lane == 0) {
+        size_t o = (size_t)e.env * M + d;
+        P.b.st_flags[o] = (uint8_t)(CG_S_VALID | (e.flags[d] & CG_S_KEEP));
+        P.b.st_busy[o] = e.busy[d];
+        P.b.st_wl[o] = e.wl[d];
+        P.b.st_comp_by[o] = e.cby[d];
+      }
+    }
+    ie[CG_I_CKPT_CNT] += 1;
+    cost += -0.1 * ds;
+    fe[CG_D_DEF_COST] += 0.1 * ds;
+  }
+  wsync();
+}
+
+// action 1 over one device list; `occ` (u8 [Mp], LDS) carries stall occurrence numbers across
+// the groups of one step_grouped tick (nullptr for single-action steps).
+__device__ void def_clean(Env& e, const KParams& P, const int16_t* dev, int L, double& cost, int32_t* ie,
+                          double* fe, uint8_t* occ) {
+  list_counts(e, dev, L);
+  const uint8_t* cnt = (const uint8_t*)e.scr;
+  int n_first_comp = 0, n_first_clean = 0, n_rest = 0;
+  int disc = 0;
+  for (int c = 0; c < e.MC; ++c) {
+    int d = c * WAVE + e.lane;
+    bool hit = false;
+    int k = 0;
+    uint8_t f = 0;
+    if (d < e.M) {
+      k = cnt[d];
+      f = e.flags[d];
+      hit = k > 0 && !(f & CG_F_NYA) && !(f & CG_F_OWNED);
+    }
+    if (hit) {
+      if (f & CG_F_COMP) ++n_first_comp; else ++n_first_clean;
+      n_rest += k - 1;
+      disc |= e.cby[d];
+      e.cby[d] = 0;
+      e.flags[d] = (uint8_t)(f & ~(CG_F_COMP | CG_F_WLADV));
+      int b0 = occ ? occ[d] : 0;
+      if (occ) occ[d] = (uint8_t)(b0 + k);
+      e.busy[d] = (uint8_t)cg_randint(e.draw(CG_SITE_STALL_CLEAN, d, b0 + k - 1), 0, P.c.default_high);
+      e.wl[d] = 0;
+    }
+  }
+  int a = wave_sum(n_first_comp), b = wave_sum(n_first_clean) + wave_sum(n_rest);
+  disc = wave_or(disc);
+  const double ds = P.c.def_scale;
+  cost += (0.3 * a - 0.01 * b) * ds;
+  fe[CG_D_CLEAN_COST] += (0.3 * a + 0.01 * b) * ds;
+  fe[CG_D_DEF_COST] += (0.3 * a + 0.01 * b) * ds;
+  ie[CG_I_DISCOVERED] |= disc;
+  if (a + b > 0) e.cby_dirty = true;
+  wsync();
+}
+
+// Pool pick for actions 6 / 9 (volt_typhoon_env.py:501-511): r-th edge with the wanted
+// blocked state among out-entries (row order) then in-entries (in-row order) of device d.
+__device__ bool pick_incident(Env& e, const KParams& P, int d, bool want, uint32_t site, int occ_b,
+                              int& su, int& sv) {
+  const int o0 = e.optr[d], o1 = e.optr[d + 1];
+  const int i0 = P.t.in_ptr[d], i1 = P.t.in_ptr[d + 1];
+  int n = 0;
+  for (int k0 = o0; k0 < o1; k0 += WAVE) {
+    int k = k0 + e.lane;
+    bool p = (k < o1) && (e.blocked(k) == want);
+    n += __popcll(ballot(p));
+  }
+  int n_out = n;
+  for (int k0 = i0; k0 < i1; k0 += WAVE) {
+    int k = k0 + e.lane;
+    bool p = (k < i1) && (e.blocked(P.t.in_eid[k]) == want);
+    n += __popcll(ballot(p));
+  }
+  if (n == 0) return false;
+  int r = (int)cg_index(e.draw(site, d, occ_b), (uint32_t)n);
+  if (r < n_out) {
+    int seen = 0;
+    for (int k0 = o0; k0 < o1; k0 += WAVE) {
+      int k = k0 + e.lane;
+      bool p = (k < o1) && (e.blocked(k) == want);
+      uint64_t m = ballot(p);
+      int c = __popcll(m);
+      if (r < seen + c) { int pos = nth_bit(m, r - seen); su = d; sv = e.ocol[k0 + pos]; return true; }
+      seen += c;
+    }
+  } else {
+    r -= n_out;
+    int seen = 0;
+    for (int k0 = i0; k0 < i1; k0 += WAVE) {
+      int k = k0 + e.lane;
+      bool p = (k < i1) && (e.blocked(P.t.in_eid[k]) == want);
+      uint64_t m = ballot(p);
+      int c = __popcll(m);
+      if (r < seen + c) { int pos = nth_bit(m, r - seen); su = P.t.in_col[k0 + pos]; sv = d; return true; }
+      seen += c;
+    }
+  }
+  return false;
+}
+
+__device__ void set_blocked_pair(Env& e, int u, int v, bool val) {
+  const int o0 = e.optr[u], o1 = e.optr[u + 1];
+  for (int k = o0 + e.lane; k < o1; k += WAVE) {
+    if (e.ocol[k] == v) {
+      if (val) atomicOr(&e.blk[k >> 5], 1u << (k & 31));
+      else atomicAnd(&e.blk[k >> 5], ~(1u << (k & 31)));
+    }
+  }
+  e.blk_dirty = true;
+  wsync();
+}
+
+__device__ void def_per_device(Env& e, const KParams& P, int at, const int16_t* dev, int L, int app,
+                               double& cost, bool& dirty, int32_t* ie, double* fe) {
+  const double ds = P.c.def_scale;
+  const int M = e.M;
+  if (at == 1) { def_clean(e, P, dev, L, cost, ie, fe, nullptr); return; }
+  if (at == 6 || at == 9) {  // sequential over the list, wave-parallel inside (:1071-1100)
+    ensure_blocked(e, P);
+    // occurrence numbers: kept in scr as bytes
+    for (int i = e.lane; i < (e.MC * WAVE) / 4; i += WAVE) e.scr[i] = 0;
+    wsync();
+    uint8_t* occ = (uint8_t*)e.scr;
+    for (int p = 0; p < L; ++p) {
+      int d = dev[p];
+      if (d < 0 || d >= M) continue;
+      if (e.flags[d] & CG_F_NYA) continue;
+      cost += -0.5 * ds;
+      fe[CG_D_DEF_COST] += 0.5 * ds;
+      int su = 0, sv = 0;
+      int b = occ[d];
+      if (pick_incident(e, P, d, at == 9, at == 6 ? CG_SITE_PICK_BLOCK : CG_SITE_PICK_UNBLOCK, b, su, sv)) {
+        wsync();
+        if (e.lane == 0) occ[d] = (uint8_t)(b + 1);
+        set_blocked_pair(e, su, sv, at == 6);
+        if (at == 6) ie[CG_I_EDGES_BLOCKED] += 1; else ie[CG_I_EDGES_ADDED] += 1;
+        dirty = true;
+      }
+    }
+    return;
+  }
+  if (at == 12) {  // :1102-1109: the reference restores device_indices[0] once per listed active device
+    int d0 = dev[0];
+    bool ok = d0 >= 0 && d0 < M;
+    size_t o = (size_t)e.env * M + (ok ? d0 : 0);
+    uint8_t sf = ok ? P.b.st_flags[o] : 0;
+    if (!(sf & CG_S_VALID)) return;
+    uint8_t sb = P.b.st_busy[o], sw = P.b.st_wl[o], sc = P.b.st_comp_by[o];
+    int n_iter = 0;
+    for (int p = 0; p < L; ++p) {   // uniform scalar walk: restoring d0 may change ITS Not_yet_added
+      int d = dev[p];
+      if (d < 0 || d >= M) continue;
+      if (e.flags[d] & CG_F_NYA) continue;
+      ++n_iter;
+      if (e.lane == 0) {
+        e.flags[d0] = (uint8_t)((e.flags[d0] & ~CG_S_KEEP) | (sf & CG_S_KEEP));
+        e.busy[d0] = sb; e.wl[d0] = sw; e.cby[d0] = sc;
+      }
+      wsync();
+    }
+    if (n_iter > 0) e.cby_dirty = true;
+    cost += -1.0 * n_iter * ds;
+    fe[CG_D_DEF_COST] += 1.0 * n_iter * ds;
+    return;
+  }
+  // count-based actions: multiplicities over the list
+  list_counts(e, dev, L);
+  const uint8_t* cnt = (const uint8_t*)e.scr;
+  int n_mult = 0, n_dist = 0;
+  for (int c = 0; c < e.MC; ++c) {
+    int d = c * WAVE + e.lane;
+    if (d < M) {
+      int k = cnt[d];
+      uint8_t f = e.flags[d];
+      if (k > 0 && !(f & CG_F_NYA)) {
+        n_mult += k; n_dist += 1;
+        if (at == 4) {  // :1013-1018
+          if (app >= 0 && app < P.t.napps[d])
+            e.busy[d] = (uint8_t)cg_randint(e.draw(CG_SITE_STALL_PATCH, d, k - 1), 0, P.c.default_high);
+        } else if (at == 7) {  // :1082-1089
+          e.flags[d] = (uint8_t)((f | CG_F_NYA) & ~(CG_F_COMP | CG_F_WLADV));
+          e.cby[d] = 0;
+          e.wl[d] = 0;
+        }
+      }
+    }
+  }
+  n_mult = wave_sum(n_mult);
+  n_dist = wave_sum(n_dist);
+  wsync();
+  if (at == 4) {
+    cost += -1.0 * n_mult * ds;
+  } else if (at == 7) {
+    cost += -0.5 * n_dist * ds;   // a repeated entry finds the device already removed (:992)
+    if (n_dist > 0) { dirty = true; e.cby_dirty = true; }
+  } else if (at == 5) {  // fast scan :1020-1069
+    ie[CG_I_SCAN_CNT] += n_mult;
+    int w = e.log_total < CG_SCAN_WINDOW ? e.log_total : CG_SCAN_WINDOW;
+    if (w > 0 && n_mult > 0) {
+      cost += -0.5 * n_mult * ds;
+      fe[CG_D_DEF_COST] += 0.5 * n_mult * ds;
+      if (e.eflags & CG_E_DET_RANDOM) {  // Detector.batch_predict coin mode CDSimulator.py:715-716
+        ensure_ring(e, P);
+        const int majority = w / 2 + 1;
+        for (int s = 0; s < n_mult; ++s) {
+          bool anom = false;
+          if (e.lane < w) anom = cg_index(e.draw(CG_SITE_DET_COIN, e.lane, s), 2) == 0;
+          uint64_t m = ballot(anom);
+          if (__popcll(m) >= majority && anom) {
+            uint32_t idx = (uint32_t)(e.log_total - w + e.lane);
+            int snd = e.ring[2 * (idx % CG_LOG_RING)];
+            atomicAnd((unsigned int*)(e.flags + (snd & ~3)), ~((uint32_t)CG_F_COMP << ((snd & 3) * 8)));
+            e.busy[snd] = (uint8_t)cg_randint(e.draw(CG_SITE_STALL_SCAN, snd, s), 0, P.c.default_high);
+          }
+          wsync();
+        }
+      }
+      // untrained detector: all "D" (CDSimulator.py:718-719); trained mode is outside the pinned scope
+    }
+  } else if (at == 13) {  // :1111-1123 -- acts on device_indices[0] once per listed active device
+    int d0 = dev[0];
+    if (n_mult > 0 && d0 >= 0 && d0 < M && e.lane == 0) {
+      e.flags[d0] &= (uint8_t)~(CG_F_COMP | CG_F_WLADV);
+      e.cby[d0] = 0;
+      e.wl[d0] = 0;
+      e.busy[d0] = (uint8_t)cg_randint(e.draw(CG_SITE_STALL_ISOLATE, d0, n_mult - 1), 3, P.c.default_high + 3);
+    }
+    if (n_mult > 0) e.cby_dirty = true;
+    cost += -3.0 * n_mult * ds;
+    fe[CG_D_CLEAN_COST] += 3.0 * n_mult * ds;
+    fe[CG_D_DEF_COST] += 3.0 * n_mult * ds;
+    wsync();
+  }
+}
+
+// ---------------- attacker ----------------
+// One source's pick: first unblocked out-entry that (DC source) exists, or whose target is
+// reachable, or is known+vulnerable and not compromised before this source's turn.
+// Returns the CSR slot or -1.  `coop`: the whole wave scans one row (uniform s); otherwise each
+// lane walks its own (short) row.
+#define T_INF 0xFFFFFFFFu
+
+__device__ __forceinline__ bool spread_eligible(const Env& e, const uint32_t* T, int v, int s, uint8_t ebit) {
+  uint8_t f = e.flags[v];
+  if (f & CG_F_REACH) return true;
+  return (f & CG_F_KNOWN) && (e.vul[v] & ebit) && (T[v] >= (uint32_t)(s + 1));
+}
+
+__device__ int spread_pick_lane(const Env& e, const uint32_t* T, int s, uint8_t ebit) {
+  const bool dc = e.dst[s] & CG_D_DC;
+  for (int k = e.optr[s]; k < e.optr[s + 1]; ++k) {
+    if (e.blocked(k)) continue;
+    if (dc) return k;
+    if (spread_eligible(e, T, e.ocol[k], s, ebit)) return k;
+  }
+  return -1;
+}
+__device__ int spread_pick_coop(const Env& e, const uint32_t* T, int s, uint8_t ebit) {
+  const bool dc = e.dst[s] & CG_D_DC;
+  const int o0 = e.optr[s], o1 = e.optr[s + 1];
+  for (int k0 = o0; k0 < o1; k0 += WAVE) {
+    int k = k0 + e.lane;
+    bool p = false;
+    if (k < o1 && !e.blocked(k)) p = dc || spread_eligible(e, T, e.ocol[k], s, ebit);
+    uint64_t m = ballot(p);
+    if (m) return k0 + __builtin_ctzll(m);
+  }
+  return -1;
+}
+
+constexpr int LONG_ROW = 8;
+
+__device__ void attacker_spread(Env& e, const KParams& P, const int32_t* expl, int n_expl, uint64_t* srcb,
+                                int32_t* ie) {
+  const int M = e.M, MC = e.MC;
+  uint32_t* T = e.scr;                          // [Mp] first-compromise time (source id + 1)
+  uint16_t* pick = (uint16_t*)(e.scr + MC * WAVE);  // [Mp] chosen CSR slot (0xFFFF none)
+  uint16_t* cntv = pick + MC * WAVE;            // [Mp] log entries of each source
+  int zocc = 0;
+  for (int j = 0; j < n_expl; ++j) {
+    int raw = expl[j];
+    if (P.c.zero_day) {  // :1131-1146
+      uint32_t mask = (uint32_t)P.c.zero_day_owned_mask;
+      bool in = raw >= 0 && raw < 32 && ((mask >> raw) & 1u);
+      if (!in) {
+        int cnt = __popc(mask);
+        if (cnt == 0) continue;
+        int r = (int)cg_index(e.draw(CG_SITE_ZERODAY, zocc++, 0), (uint32_t)cnt);
+        uint32_t m = mask;
+        for (int i = 0; i < r; ++i) m &= m - 1;
+        raw = __builtin_ctz(m);
+      }
+    }
+    if (raw < 0 || raw >= P.t.X) continue;
+    const uint8_t ebit = (uint8_t)(1u << raw);
+    // init T from the live compromise bits
+    for (int d = e.lane; d < MC * WAVE; d += WAVE) {
+      T[d] = (d < M && (e.flags[d] & CG_F_COMP)) ? 0u : T_INF;
+      pick[d] = 0xFFFF;
+    }
+    wsync();
+    // fix-point rounds
+    for (int round = 0; round <= M + 1; ++round) {
+      bool changed = false;
+      for (int c = 0; c < MC; ++c) {
+        const uint64_t sm = srcb[c];
+        if (!sm) continue;
+        int s = c * WAVE + e.lane;
+        bool is_src = (sm >> e.lane) & 1ull;
+        int len = is_src ? (e.optr[s + 1] - e.optr[s]) : 0;
+        if (is_src && len <= LONG_ROW) {
+          int k = spread_pick_lane(e, T, s, ebit);
+          uint16_t nk = k < 0 ? 0xFFFF : (uint16_t)k;
+          if (nk != pick[s]) { pick[s] = nk; changed = true; }
+          if (k >= 0) atomicMin(&T[e.ocol[k]], (uint32_t)(s + 1));
+        }
+        uint64_t lm = ballot(is_src && len > LONG_ROW);
+        while (lm) {
+          int ls = c * WAVE + __builtin_ctzll(lm);
+          lm &= lm - 1;
+          int k = spread_pick_coop(e, T, ls, ebit);
+          uint16_t nk = k < 0 ? 0xFFFF : (uint16_t)k;
+          if (nk != pick[ls]) changed = true;   // uniform
+          wsync();
+          if (e.lane == 0) {
+            pick[ls] = nk;
+            if (k >= 0) atomicMin(&T[e.ocol[k]], (uint32_t)(ls + 1));
+          }
+          wsync();
+        }
+      }
+      wsync();
+      if (!__any(changed)) break;
+    }
+    // log entries of every source: unblocked out-entries up to and including its pick
+    int total_new = 0;
+    for (int c = 0; c < MC; ++c) {
+      const uint64_t sm = srcb[c];
+      int s = c * WAVE + e.lane;
+      bool is_src = (sm >> e.lane) & 1ull;
+      int n = 0;
+      if (is_src) {
+        int o0 = e.optr[s], o1 = e.optr[s + 1];
+        int last = pick[s] == 0xFFFF ? o1 - 1 : (int)pick[s];
+        if (o1 - o0 <= LONG_ROW) {
+          for (int k = o0; k <= last; ++k) n += !e.blocked(k);
+        }
+      }
+      uint64_t lm = ballot(is_src && (e.optr[s + 1] - e.optr[s]) > LONG_ROW);
+      while (lm) {
+        int ll = __builtin_ctzll(lm);
+        lm &= lm - 1;
+        int ls = c * WAVE + ll;
+        int o0 = e.optr[ls], o1 = e.optr[ls + 1];
+        int last = pick[ls] == 0xFFFF ? o1 - 1 : (int)pick[ls];
+        int acc = 0;
+        for (int k0 = o0; k0 <= last; k0 += WAVE) {
+          int k = k0 + e.lane;
+          acc += __popcll(ballot(k <= last && !e.blocked(k)));
+        }
+        if (e.lane == ll) n = acc;
+      }
+      if (s < MC * WAVE) cntv[s] = (uint16_t)n;
+      total_new += wave_sum(n);
+    }
+    wsync();
+    // ring: only the last CG_LOG_RING entries (global order: source id, then row order) matter
+    if (total_new > 0) {
+      ensure_ring(e, P);
+      const uint32_t base = (uint32_t)e.log_total;
+      const uint32_t end = base + (uint32_t)total_new;
+      const uint32_t lo = end > CG_LOG_RING ? end - CG_LOG_RING : 0;
+      uint32_t run = base;
+      for (int c = 0; c < MC; ++c) {
+        int s = c * WAVE + e.lane;
+        int n = cntv[s];
+        int incl = wave_incl_scan(n, e.lane);
+        uint32_t off = run + (uint32_t)(incl - n);
+        int chunk_total = __shfl(incl, 63);
+        bool mine = n > 0 && off + (uint32_t)n > lo;
+        bool is_long = mine && (e.optr[s + 1] - e.optr[s]) > LONG_ROW;
+        if (mine && !is_long) {
+          uint32_t idx = off;
+          int last = pick[s] == 0xFFFF ? e.optr[s + 1] - 1 : (int)pick[s];
+          for (int k = e.optr[s]; k <= last; ++k) {
+            if (e.blocked(k)) continue;
+            if (idx >= lo) { e.ring[2 * (idx % CG_LOG_RING)] = (uint16_t)s; e.ring[2 * (idx % CG_LOG_RING) + 1] = e.ocol[k]; }
+            ++idx;
+          }
+        }
+        uint64_t lm = ballot(is_long);
+        while (lm) {
+          int ll = __builtin_ctzll(lm);
+          lm &= lm - 1;
+          int ls = c * WAVE + ll;
+          uint32_t idx0 = __shfl(off, ll);
+          int o0 = e.optr[ls], o1 = e.optr[ls + 1];
+          int last = pick[ls] == 0xFFFF ? o1 - 1 : (int)pick[ls];
+          for (int k0 = o0; k0 <= last; k0 += WAVE) {
+            int k = k0 + e.lane;
+            bool p = k <= last && !e.blocked(k);
+            uint64_t m = ballot(p);
+            uint32_t idx = idx0 + (uint32_t)below(m);
+            if (p && idx >= lo) { e.ring[2 * (idx % CG_LOG_RING)] = (uint16_t)ls; e.ring[2 * (idx % CG_LOG_RING) + 1] = e.ocol[k]; }
+            idx0 += (uint32_t)__popcll(m);
+          }
+        }
+        run += (uint32_t)chunk_total;
+      }
+      e.log_total = (int)end;
+      e.ring_dirty = true;
+    }
+    wsync();
+    // apply: compromise flags + DC attribution (:1163-1185)
+    for (int c = 0; c < MC; ++c) {
+      int d = c * WAVE + e.lane;
+      if (d < M && T[d] != T_INF && T[d] != 0u) e.flags[d] |= CG_F_COMP;
+    }
+    wsync();
+    for (int c = 0; c < MC; ++c) {
+      const uint64_t sm = srcb[c];
+      int s = c * WAVE + e.lane;
+      if (((sm >> e.lane) & 1ull) && (e.dst[s] & CG_D_DC) && pick[s] != 0xFFFF) {
+        byte_or(e.cby, e.ocol[pick[s]], ebit);
+        e.cby_dirty = true;
+      }
+    }
+    e.cby_dirty = __any(e.cby_dirty);
+    wsync();
+  }
+}
+
+__device__ void attacker_probe(Env& e, const KParams& P, const uint64_t* srcb, double& cost) {
+  int n_src = 0;
+  for (int c = 0; c < e.MC; ++c) n_src += __popcll(srcb[c]);
+  if (n_src == 0) return;
+  int r = (int)cg_index(e.draw(CG_SITE_PROBE_SRC, 0, 0), (uint32_t)n_src);
+  int s = -1;
+  for (int c = 0; c < e.MC; ++c) {
+    int k = __popcll(srcb[c]);
+    if (r < k) { s = c * WAVE + nth_bit(srcb[c], r); break; }
+    r -= k;
+  }
+  const int o0 = e.optr[s], o1 = e.optr[s + 1];
+  for (int k0 = o0; k0 < o1; k0 += WAVE) {
+    int k = k0 + e.lane;
+    bool p = k < o1 && !e.blocked(k) && !(e.flags[e.ocol[k]] & CG_F_KNOWN);
+    uint64_t m = ballot(p);
+    if (m) {
+      int v = e.ocol[k0 + __builtin_ctzll(m)];
+      if (e.lane == 0) e.flags[v] |= CG_F_KNOWN;
+      cost += 0.1;   // :1199 (not scaled)
+      break;
+    }
+  }
+  wsync();
+}
+
+// ---------------- arrivals: CDSimulator.generate_workloads :244-348 ----------------
+__device__ void gen_workloads(Env& e, const KParams& P, int num, bool server) {
+  const int M = e.M, MC = e.MC;
+  int n_active = 0;
+  for (int c = 0; c < MC; ++c) {
+    int d = c * WAVE + e.lane;
+    n_active += __popcll(ballot(d < M && !(e.flags[d] & CG_F_NYA)));
+  }
+  if (n_active <= 0) return;
+  if (P.c.workload_cap >= 0 && num > P.c.workload_cap) num = P.c.workload_cap;
+  if (num > n_active) num = n_active;
+  if (num <= 0) return;
+  const uint32_t site = server ? CG_SITE_ARR_SERVER : CG_SITE_ARR_CLIENT;
+  uint32_t* key = e.scr;                     // [Mp]
+  uint32_t* candb = e.scr + MC * WAVE;       // candidate bit per device as ballots [2*MC]
+  int n = 0;
+  for (int c = 0; c < MC; ++c) {
+    int d = c * WAVE + e.lane;
+    bool cand = false;
+    if (d < M) {
+      uint8_t f = e.flags[d];
+      cand = !(f & CG_F_NYA) && e.wl[d] == 0 && e.busy[d] == 0 && (((e.dst[d] & CG_D_SERVER) != 0) == server);
+    }
+    uint64_t m = ballot(cand);
+    if (e.lane == 0) { candb[2 * c] = (uint32_t)m; candb[2 * c + 1] = (uint32_t)(m >> 32); }
+    n += __popcll(m);
+  }
+  wsync();
+  if (n == 0) return;
+  int k = num < n ? num : n;
+  bool all = (k == n);
+  uint32_t thr_key = 0xFFFFFFFFu;
+  int n_less = 0;
+  if (!all) {
+    for (int c = 0; c < MC; ++c) {
+      int d = c * WAVE + e.lane;
+      uint64_t m = (uint64_t)candb[2 * c] | ((uint64_t)candb[2 * c + 1] << 32);
+      if ((m >> e.lane) & 1ull) key[d] = e.draw(site, d, 0);
+    }
+    wsync();
+    // radix select: value of the k-th smallest key
+    uint32_t prefix = 0;
+    int kk = k;   // 1-based rank still to locate among matching candidates
+    for (int bit = 31; bit >= 0; --bit) {
+      uint32_t hi_mask = bit == 31 ? 0u : (0xFFFFFFFFu << (bit + 1));
+      int cnt0 = 0;
+      for (int c = 0; c < MC; ++c) {
+        int d = c * WAVE + e.lane;
+        uint64_t m = (uint64_t)candb[2 * c] | ((uint64_t)candb[2 * c + 1] << 32);
+        bool p = ((m >> e.lane) & 1ull) && ((key[d] & hi_mask) == prefix) && !((key[d] >> bit) & 1u);
+        cnt0 += __popcll(ballot(p));
+      }
+      if (kk > cnt0) { kk -= cnt0; prefix |= (1u << bit); }
+    }
+    thr_key = prefix;
+    for (int c = 0; c < MC; ++c) {
+      int d = c * WAVE + e.lane;
+      uint64_t m = (uint64_t)candb[2 * c] | ((uint64_t)candb[2 * c + 1] << 32);
+      n_less += __popcll(ballot(((m >> e.lane) & 1ull) && key[d] < thr_key));
+    }
+  }
+  // select: key < thr, plus the first (k - n_less) candidates with key == thr in id order
+  int need_eq = k - n_less;
+  int seen_eq = 0;
+  for (int c = 0; c < MC; ++c) {
+    int d = c * WAVE + e.lane;
+    uint64_t m = (uint64_t)candb[2 * c] | ((uint64_t)candb[2 * c + 1] << 32);
+    bool cand = (m >> e.lane) & 1ull;
+    bool take = false;
+    if (all) take = cand;
+    else {
+      bool eq = cand && key[d] == thr_key;
+      uint64_t em = ballot(eq);
+      take = (cand && key[d] < thr_key) || (eq && (seen_eq + below(em)) < need_eq);
+      seen_eq += __popcll(em);
+    }
+    if (take) {
+      e.wl[d] = (uint8_t)(1 + cg_cdf_lookup(e.draw(CG_SITE_ARR_TIME, d, 0), P.c.tri_thr, CG_TRI_TABLE));
+      e.flags[d] &= (uint8_t)~CG_F_WLADV;
+    }
+  }
+  wsync();
+}
+
+__device__ void arrivals(Env& e, const KParams& P, int step_num) {  // volt_typhoon_env.py:575-596
+  const int M = e.M;
+  int n_active = 0, idle = 0, free_s = 0;
+  for (int c = 0; c < e.MC; ++c) {
+    int d = c * WAVE + e.lane;
+    bool act = false, idl = false, srv = false;
+    if (d < M) {
+      act = !(e.flags[d] & CG_F_NYA);
+      idl = act && e.busy[d] == 0 && e.wl[d] == 0;
+      srv = e.dst[d] & CG_D_SERVER;
+    }
+    n_active += __popcll(ballot(act));
+    idle += __popcll(ballot(idl));
+    free_s += __popcll(ballot(idl && srv));
+  }
+  int free_c = idle - free_s;
+  int n1 = n_active > 1 ? n_active : 1;
+  int half = 0;
+  while (4 * (half + 1) * (half + 1) <= n1) ++half;   // int(0.5*sqrt(n)) (:141-145)
+  int period = P.c.workload_period_base + half;
+  if (period < 10) period = 10;
+  if (period > P.c.workload_period_max) period = P.c.workload_period_max;
+  if (step_num % period != 0) return;
+  if (n_active == 0 || 10 * idle < n_active) return;   // _idle_fraction() < 0.10
+  int nC, nS;
+  if (P.c.scaling_vulnerability) {   // _scaled_numloads(100, 10), anchor 50 (:266-293)
+    int req_c = 2 * n_active;                       // round(100*n/50)
+    int q = n_active / 5, r = n_active % 5;          // round(10*n/50) = round(n/5); no exact halves
+    int req_s = q + (2 * r > 5 ? 1 : 0);
+    if (req_c < 1) req_c = 1;
+    if (req_s < 1) req_s = 1;
+    int cap_c = free_c > 1 ? free_c : 1, cap_s = free_s > 1 ? free_s : 1;
+    nC = req_c < cap_c ? req_c : cap_c;
+    nS = req_s < cap_s ? req_s : cap_s;
+  } else { nC = 100; nS = 10; }
+  if (P.c.workload_cap > 0) {
+    int total = nC + nS;
+    if (total > P.c.workload_cap) {
+      double ratio = (double)P.c.workload_cap / (double)total;
+      nC = (int)(nC * ratio); if (nC < 0) nC = 0;
+      nS = (int)(nS * ratio); if (nS < 0) nS = 0;
+    }
+  }
+  gen_workloads(e, P, nC, false);
+  gen_workloads(e, P, nS, true);
+}
+
+// ---------------- evolve_network: CyberDefenseEnv.py:583-875 ----------------
+__device__ int rank_select(const Env& e, uint8_t mask, uint8_t want, int r) {
+  for (int c = 0; c < e.MC; ++c) {
+    int d = c * WAVE + e.lane;
+    uint64_t m = ballot(d < e.M && (e.flags[d] & mask) == want);
+    int k = __popcll(m);
+    if (r < k) return c * WAVE + nth_bit(m, r);
+    r -= k;
+  }
+  return -1;
+}
+__device__ bool has_edge(const Env& e, int u, int v) {
+  const int o0 = e.optr[u], o1 = e.optr[u + 1];
+  for (int k0 = o0; k0 < o1; k0 += WAVE) {
+    int k = k0 + e.lane;
+    if (ballot(k < o1 && e.ocol[k] == v)) return true;
+  }
+  return false;
+}
+
+__device__ void evolve(Env& e, const KParams& P) {
+  const int M = e.M, MC = e.MC;
+  if (!(e.eflags & CG_E_EVO_INIT)) {   // :654-659
+    for (int d = e.lane; d < M; d += WAVE) {
+      uint8_t f = e.flags[d];
+      e.flags[d] = (f & CG_F_NYA) ? (uint8_t)(f & ~CG_F_EVOACT) : (uint8_t)(f | CG_F_EVOACT);
+    }
+    e.eflags |= CG_E_EVO_INIT;
+    wsync();
+  }
+  uint32_t* newly = e.marks;   // bit per device
+  for (int i = e.lane; i <= (MC * WAVE) / 32; i += WAVE) newly[i] = 0;
+  wsync();
+  bool any_new = false;
+  int n_ev = cg_cdf_lookup(e.draw(CG_SITE_EVO_POISSON, 0, 0), P.c.poisson_thr, CG_POISSON_TABLE);
+  const int floor_n = P.c.num_of_device > P.c.min_network_size ? P.c.num_of_device : P.c.min_network_size;
+  for (int ev = 0; ev < n_ev; ++ev) {
+    if (cg_bernoulli(e.draw(CG_SITE_EVO_COIN, ev, 0), P.c.p_add_thr)) {
+      int n_in = 0;
+      for (int c = 0; c < MC; ++c) {
+        int d = c * WAVE + e.lane;
+        n_in += __popcll(ballot(d < M && !(e.flags[d] & CG_F_EVOACT)));
+      }
+      if (n_in > 0) {
+        int d = rank_select(e, CG_F_EVOACT, 0, (int)cg_index(e.draw(CG_SITE_EVO_PICK_IN, ev, 0), (uint32_t)n_in));
+        bool att = cg_bernoulli(e.draw(CG_SITE_EVO_ATT, ev, 0), P.c.p_attacker_thr);
+        const uint8_t f0 = e.flags[d];
+        wsync();
+        if (e.lane == 0) {
+          uint8_t f = (uint8_t)((f0 & ~CG_F_NYA) | CG_F_EVOACT);
+          if (att) f |= (CG_F_COMP | CG_F_OWNED | CG_F_KNOWN);
+          e.flags[d] = f;
+          newly[d >> 5] |= 1u << (d & 31);
+        }
+        if (att || (f0 & CG_F_OWNED)) e.eflags &= ~CG_E_STAR_OK;
+        any_new = true;
+      }
+    } else {
+      int n_act = 0;
+      for (int c = 0; c < MC; ++c) {
+        int d = c * WAVE + e.lane;
+        n_act += __popcll(ballot(d < M && (e.flags[d] & CG_F_EVOACT)));
+      }
+      if (n_act > floor_n) {
+        int d = rank_select(e, CG_F_EVOACT, CG_F_EVOACT, (int)cg_index(e.draw(CG_SITE_EVO_PICK_ACT, ev, 0), (uint32_t)n_act));
+        const uint8_t f0 = e.flags[d];
+        wsync();
+        if (f0 & CG_F_OWNED) e.eflags &= ~CG_E_STAR_OK;
+        if (e.lane == 0) {
+          e.flags[d] = (uint8_t)((f0 | CG_F_NYA) & ~(CG_F_EVOACT | CG_F_WLADV));
+          e.wl[d] = 0;
+          e.busy[d] = 0;
+          newly[d >> 5] &= ~(1u << (d & 31));
+        }
+      }
+    }
+    wsync();
+  }
+  // star reconnection (:738-774) would ADD edges when hub<->owner links are missing: detect + flag.
+  if (!(e.eflags & CG_E_STAR_OK)) {
+    int hub = rank_select(e, CG_F_OWNED | CG_F_EVOACT, CG_F_OWNED | CG_F_EVOACT, 0);
+    bool ok = true;
+    if (hub >= 0) {
+      for (int c = 0; c < MC && ok; ++c) {
+        int d = c * WAVE + e.lane;
+        uint64_t m = ballot(d < M && d != hub && (e.flags[d] & (CG_F_OWNED | CG_F_EVOACT)) == (CG_F_OWNED | CG_F_EVOACT));
+        while (m && ok) {
+          int o = c * WAVE + __builtin_ctzll(m);
+          m &= m - 1;
+          if (!has_edge(e, hub, o) || !has_edge(e, o, hub)) ok = false;
+        }
+      }
+    }
+    if (ok) e.eflags |= CG_E_STAR_OK; else e.eflags |= CG_E_TOPO_OVF;
+  }
+  // preferential attachment of isolated newcomers (:776-843) would add an edge: detect + flag.
+  if (any_new) {
+    bool iso = false;
+    for (int c = 0; c < MC; ++c) {
+      int d = c * WAVE + e.lane;
+      if (d < M && ((newly[d >> 5] >> (d & 31)) & 1u) && !(e.flags[d] & (CG_F_NYA | CG_F_OWNED))) {
+        int deg = (e.optr[d + 1] - e.optr[d]) + (P.t.in_ptr[d + 1] - P.t.in_ptr[d]);
+        if (deg < 1) iso = true;
+      }
+    }
+    if (__any(iso)) e.eflags |= CG_E_TOPO_OVF;
+  }
+  wsync();
+}
+
+// ---------------- the tick ----------------
+template <int WPB>
+__global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  const int M = P.t.M, MC = P.t.MC, Mp = MC * WAVE, E = P.t.E;
+  // ---- shared section: topology ----
+  uint16_t* s_optr = (uint16_t*)smem;                      // [M+1] (padded to even count)
+  uint16_t* s_ocol = s_optr + ((M + 2) & ~1);              // [E]
+  float* s_os = (float*)(smem + (((size_t)((M + 2) & ~1) * 2 + (size_t)E * 2 + 15) & ~(size_t)15));
+  float* s_ver = s_os + Mp;
+  float* s_ano = s_ver + Mp;
+  uint8_t* s_dst = (uint8_t*)(s_ano + Mp);
+  uint8_t* s_vul = s_dst + Mp;
+  for (int i = threadIdx.x; i <= M; i += WPB * WAVE) s_optr[i] = P.t.out_ptr[i];
+  for (int i = threadIdx.x; i < E; i += WPB * WAVE) s_ocol[i] = P.t.out_col[i];
+  for (int i = threadIdx.x; i < M; i += WPB * WAVE) {
+    s_os[i] = P.t.os_val[i]; s_ver[i] = P.t.version[i]; s_ano[i] = P.t.anomaly[i];
+    s_dst[i] = P.t.dstatic[i]; s_vul[i] = P.t.vuln[i];
+  }
+  __syncthreads();   // the only workgroup barrier: waves diverge per env from here on
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int env = uni(blockIdx.x * WPB + wave);
+  if (env >= P.n_envs) return;
+
+  uint8_t* wb = smem + P.shared_lds + (size_t)wave * P.wave_lds;
+  Env e;
+  e.flags = wb; e.busy = wb + Mp; e.wl = wb + 2 * Mp; e.cby = wb + 3 * Mp;
+  e.scr = (uint32_t*)(wb + 4 * Mp);
+  e.blk = e.scr + 2 * Mp;
+  e.ring = (uint16_t*)(e.blk + ((P.t.EW + 3) & ~3));
+  e.marks = (uint32_t*)(e.ring + 2 * CG_LOG_RING);
+  uint64_t* srcb = (uint64_t*)(e.marks + ((Mp / 32 + 2) & ~1));
+  e.optr = s_optr; e.ocol = s_ocol; e.dst = s_dst; e.vul = s_vul; e.osv = s_os; e.ver = s_ver; e.ano = s_ano;
+  e.M = M; e.MC = MC; e.lane = lane; e.env = env;
+  e.env_id = (uint32_t)(P.c.env_id_base + env);
+  e.seed = P.c.seed;
+  e.blk_loaded = e.blk_dirty = e.ring_loaded = e.ring_dirty = e.cby_dirty = false;
+
+  // ---- per-env scalars (uniform) ----
+  int32_t ie[CG_I_COUNT];
+  double fe[CG_D_COUNT];
+  {
+    const int32_t* g = P.b.ienv + (size_t)env * CG_I_COUNT;
+#pragma unroll
+    for (int i = 0; i < CG_I_COUNT; ++i) ie[i] = g[i];
+    const double* gf = P.b.fenv + (size_t)env * CG_D_COUNT;
+#pragma unroll
+    for (int i = 0; i < CG_D_COUNT; ++i) fe[i] = gf[i];
+  }
+  e.tick = (uint32_t)ie[CG_I_RNG_TICK];
+  e.eflags = ie[CG_I_FLAGS];
+  e.log_total = ie[CG_I_LOG_TOTAL];
+
+  // ---- stage the live planes ----
+  const size_t so = (size_t)env * M;
+  plane_load(e.flags, P.b.flags + so, M, lane);
+  plane_load(e.busy, P.b.busy + so, M, lane);
+  plane_load(e.wl, P.b.wl + so, M, lane);
+  plane_load(e.cby, P.b.comp_by + so, M, lane);
+  wsync();
+
+  const int G = P.a.max_groups, L = P.a.max_devs;
+  const int mode = P.a.mode[env];
+  const int ng = P.a.n_groups[env];
+  const int16_t* devs = P.a.dev_idx + (size_t)env * L;
+  double cost = 0.0;
+  bool dirty = false;
+  int last_atype = -1;
+
+  if (ng == 0) {   // ---- step(action) volt_typhoon_env.py:818-1333 ----
+    int at = P.a.atype[(size_t)env * G];
+    int Ld = P.a.dev_cnt[(size_t)env * G];
+    if (Ld > L) Ld = L;
+    if (Ld < 0) Ld = 0;
+    if (mode == CG_MODE_DEFENDER) { if (!(at >= 0 && at < P.c.n_def_actions)) at = 8; }
+    else                          { if (!(at >= 0 && at < P.c.n_att_actions)) at = 3; }
+    for (int d = lane; d < M; d += WAVE)   // :904-908 decay of the cached busy set
+      if ((e.flags[d] & CG_F_BUSYC) && e.busy[d] > 0) e.busy[d]--;
+    wsync();
+    if (mode == CG_MODE_DEFENDER) {
+      if (P.c.baseline != 0) at = 8;   // :913-914
+      def_global(e, P, at, devs, Ld, cost, dirty, false, ie, fe);
+      if (at == 1 || at == 4 || at == 5 || at == 6 || at == 7 || at == 9 || at == 12 || at == 13)
+        if (Ld > 0) def_per_device(e, P, at, devs, Ld, P.a.app[(size_t)env * G], cost, dirty, ie, fe);
+    } else if (P.c.baseline != 3 && (at == 1 || at == 2)) {
+      for (int c = 0; c < MC; ++c) {   // :1127 snapshot of the sources
+        int d = c * WAVE + lane;
+        uint64_t m = ballot(d < M && (e.flags[d] & (CG_F_COMP | CG_F_OWNED)));
+        if (lane == 0) srcb[c] = m;
+      }
+      wsync();
+      ensure_blocked(e, P);
+      if (at == 1) {
+        int ne = P.a.n_exploit[(size_t)env * G];
+        if (ne > CG_MAX_EXPLOITS) ne = CG_MAX_EXPLOITS;
+        attacker_spread(e, P, P.a.exploit + (size_t)env * G * CG_MAX_EXPLOITS, ne, srcb, ie);
+      } else {
+        attacker_probe(e, P, srcb, cost);
+      }
+    }
+    last_atype = at;
+  } else {   // ---- step_grouped(groups) :694-779 via _step_apply_only :612-692 ----
+    uint8_t* occ = (uint8_t*)(e.scr + Mp);   // second scratch half: clean-stall occurrence numbers
+    for (int i = lane; i < Mp / 4; i += WAVE) ((uint32_t*)occ)[i] = 0;
+    wsync();
+    const int16_t* dp = devs;
+    int used = 0;
+    for (int g = 0; g < ng && g < G; ++g) {
+      int at = P.a.atype[(size_t)env * G + g];
+      int Ld = P.a.dev_cnt[(size_t)env * G + g];
+      if (Ld < 0) Ld = 0;
+      if (used + Ld > L) Ld = L - used;
+      if (mode == CG_MODE_DEFENDER && at == 0) at = 8;
+      else if (mode == CG_MODE_ATTACKER && at == 0) at = 3;
+      if (mode == CG_MODE_DEFENDER) {
+        if (P.c.baseline != 0) at = 8;
+        def_global(e, P, at, dp, Ld, cost, dirty, true, ie, fe);
+        if (at == 1 && Ld > 0) def_clean(e, P, dp, Ld, cost, ie, fe, occ);
+      }
+      dp += Ld; used += Ld;
+    }
+    for (int d = lane; d < M; d += WAVE) if (e.busy[d] > 0) e.busy[d]--;   // _tick_busy_time_once :607
+    wsync();
+  }
+
+  // ---- workload advance (:1242-1261 / :705-725) ----
+  int current_work = 0;
+  for (int c = 0; c < MC; ++c) {
+    int d = c * WAVE + lane;
+    bool fin = false;
+    if (d < M && e.busy[d] == 0 && !(e.flags[d] & CG_F_NYA) && e.wl[d] > 0) {
+      uint8_t w = (uint8_t)(e.wl[d] - 1);
+      e.wl[d] = w;
+      if (w == 0) {
+        if (e.flags[d] & CG_F_WLADV) e.flags[d] &= (uint8_t)~CG_F_WLADV; else fin = true;
+      }
+    }
+    current_work += __popcll(ballot(fin));
+  }
+  ie[CG_I_WORK_DONE] += current_work;
+  wsync();
+  arrivals(e, P, ie[CG_I_STEP_NUM]);
+
+  // ---- counts + rewards (:1267-1304 / :732-748) ----
+  int n_comp = 0, n_comp_dc = 0;
+  for (int c = 0; c < MC; ++c) {
+    int d = c * WAVE + lane;
+    bool p = false, q = false;
+    if (d < M) {
+      uint8_t f = e.flags[d];
+      p = (f & CG_F_COMP) && !(f & CG_F_NYA) && !(f & CG_F_OWNED);
+      q = p && (e.dst[d] & CG_D_DC);
+    }
+    n_comp += __popcll(ballot(p));
+    n_comp_dc += __popcll(ballot(q));
+  }
+  if (ng == 0) ie[CG_I_COMP_CNT] += n_comp;
+  ie[CG_I_LAST_NCOMP] = n_comp;
+  double raw, shaped;
+  {
+    double def_work = P.c.work_scale * current_work;
+    if (mode == CG_MODE_DEFENDER) {
+      raw = cost + def_work - n_comp * P.c.comp_scale;
+      shaped = raw;
+    } else {
+      double r = cost + P.c.comp_scale * (n_comp + 10 * n_comp_dc);
+      double phi = (double)n_comp / (double)M;
+      if (!(e.eflags & CG_E_PREV_SET)) { fe[CG_D_PREV_ATT_POT] = phi; e.eflags |= CG_E_PREV_SET; }
+      double inc = P.c.gamma * phi - fe[CG_D_PREV_ATT_POT];
+      double bonus = 0.1 * inc + 0.0;
+      fe[CG_D_PREV_ATT_POT] = P.c.gamma * phi;
+      raw = r;
+      shaped = r + bonus;
+    }
+  }
+
+  // ---- observation (_get_state CyberDefenseEnv.py:146-191), before evolve; 16-B coalesced stores ----
+  {
+    float* out = P.o.obs + (size_t)env * M * 6;
+    const int n4 = (M * 6) >> 2;   // M*6 is a multiple of 4 when M is even; tail handled below
+    for (int i4 = lane; i4 < n4; i4 += WAVE) {
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int i = i4 * 4 + j;
+        int d = i / 6, col = i - d * 6;
+        uint8_t f = e.flags[d];
+        float x;
+        switch (col) {
+          case 0: x = e.osv[d]; break;
+          case 1: x = e.ver[d]; break;
+          case 2: x = (f & CG_F_COMP) ? 1.f : 0.f; break;
+          case 3: x = e.ano[d]; break;
+          case 4: x = (f & CG_F_KNOWN) ? 1.f : 0.f; break;
+          default: x = (f & CG_F_NYA) ? 1.f : 0.f; break;
+        }
+        v[j] = x;
+      }
+      *(float4*)(out + i4 * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    for (int i = n4 * 4 + lane; i < M * 6; i += WAVE) {
+      int d = i / 6, col = i - d * 6;
+      uint8_t f = e.flags[d];
+      float x = col == 0 ? e.osv[d] : col == 1 ? e.ver[d] : col == 2 ? ((f & CG_F_COMP) ? 1.f : 0.f)
+              : col == 3 ? e.ano[d] : col == 4 ? ((f & CG_F_KNOWN) ? 1.f : 0.f) : ((f & CG_F_NYA) ? 1.f : 0.f);
+      out[i] = x;
+    }
+  }
+
+  ie[CG_I_STEP_NUM] += 1;
+  if (mode == CG_MODE_ATTACKER) ie[CG_I_ATT_STEP] += 1; else ie[CG_I_DEF_STEP] += 1;
+  const bool done = ie[CG_I_STEP_NUM] > P.c.episode_limit;
+  if (dirty || (ie[CG_I_STEP_NUM] % P.c.evolve_period) == 0) evolve(e, P);
+  if (ng == 0) {   // :1330 rebuild of the cached busy set
+    for (int d = lane; d < M; d += WAVE) {
+      uint8_t f = e.flags[d];
+      e.flags[d] = e.busy[d] > 0 ? (uint8_t)(f | CG_F_BUSYC) : (uint8_t)(f & ~CG_F_BUSYC);
+    }
+  }
+  wsync();
+  ie[CG_I_RNG_TICK] += 1;
+  ie[CG_I_LAST_ATYPE] = last_atype;
+  ie[CG_I_LOG_TOTAL] = e.log_total;
+  ie[CG_I_FLAGS] = wave_or(e.eflags);
+
+  if (lane == 0) {
+    P.o.raw[env] = raw;
+    P.o.shaped[env] = shaped;
+    P.o.done[env] = done ? 1 : 0;
+  }
+
+  if (done && P.c.auto_reset && P.snap.flags) {   // reload the initial snapshot; RNG tick stays monotone
+    const int si = P.snap.n_envs == 1 ? 0 : env;
+    const size_t ss = (size_t)si * M;
+    plane_store(P.b.flags + so, P.snap.flags + ss, M, lane);
+    plane_store(P.b.busy + so, P.snap.busy + ss, M, lane);
+    plane_store(P.b.wl + so, P.snap.wl + ss, M, lane);
+    plane_store(P.b.comp_by + so, P.snap.comp_by + ss, M, lane);
+    plane_store(P.b.st_flags + so, P.snap.st_flags + ss, M, lane);
+    plane_store(P.b.st_busy + so, P.snap.st_busy + ss, M, lane);
+    plane_store(P.b.st_wl + so, P.snap.st_wl + ss, M, lane);
+    plane_store(P.b.st_comp_by + so, P.snap.st_comp_by + ss, M, lane);
+    for (int w = lane; w < P.t.EW; w += WAVE) P.b.blocked[(size_t)env * P.t.EW + w] = P.snap.blocked[(size_t)si * P.t.EW + w];
+    if (lane < CG_LOG_RING)
+      ((uint32_t*)(P.b.ring + (size_t)env * CG_LOG_RING * 2))[lane] = ((const uint32_t*)(P.snap.ring + (size_t)si * CG_LOG_RING * 2))[lane];
+    if (lane < CG_I_COUNT) {
+      int32_t v = P.snap.ienv[(size_t)si * CG_I_COUNT + lane];
+      if (lane == CG_I_RNG_TICK) v = ie[CG_I_RNG_TICK];
+      P.b.ienv[(size_t)env * CG_I_COUNT + lane] = v;
+    }
+    if (lane < CG_D_COUNT) P.b.fenv[(size_t)env * CG_D_COUNT + lane] = P.snap.fenv[(size_t)si * CG_D_COUNT + lane];
+    return;
+  }
+
+  // ---- write back ----
+  plane_store(P.b.flags + so, e.flags, M, lane);
+  plane_store(P.b.busy + so, e.busy, M, lane);
+  plane_store(P.b.wl + so, e.wl, M, lane);
+  if (e.cby_dirty) plane_store(P.b.comp_by + so, e.cby, M, lane);
+  if (e.blk_dirty) for (int w = lane; w < P.t.EW; w += WAVE) P.b.blocked[(size_t)env * P.t.EW + w] = e.blk[w];
+  if (e.ring_dirty && lane < CG_LOG_RING)
+    ((uint32_t*)(P.b.ring + (size_t)env * CG_LOG_RING * 2))[lane] = ((const uint32_t*)e.ring)[lane];
+  if (lane == 0) {
+    int32_t* g = P.b.ienv + (size_t)env * CG_I_COUNT;
+#pragma unroll
+    for (int i = 0; i < CG_I_COUNT; ++i) g[i] = ie[i];
+    double* gf = P.b.fenv + (size_t)env * CG_D_COUNT;
+#pragma unroll
+    for (int i = 0; i < CG_D_COUNT; ++i) gf[i] = fe[i];
+  }
+}
+
+// ---------------- reset / randomize / observe / action script ----------------
+__global__ void reset_kernel(KParams P, const int32_t* env_ids, int n) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= n) return;
+  const int env = env_ids ? env_ids[wave] : wave;
+  if (env < 0 || env >= P.n_envs) return;
+  const int M = P.t.M;
+  const int si = P.snap.n_envs == 1 ? 0 : env;
+  const size_t so = (size_t)env * M, ss = (size_t)si * M;
+  int32_t tick = P.b.ienv[(size_t)env * CG_I_COUNT + CG_I_RNG_TICK];
+  plane_store(P.b.flags + so, P.snap.flags + ss, M, lane);
+  plane_store(P.b.busy + so, P.snap.busy + ss, M, lane);
+  plane_store(P.b.wl + so, P.snap.wl + ss, M, lane);
+  plane_store(P.b.comp_by + so, P.snap.comp_by + ss, M, lane);
+  plane_store(P.b.st_flags + so, P.snap.st_flags + ss, M, lane);
+  plane_store(P.b.st_busy + so, P.snap.st_busy + ss, M, lane);
+  plane_store(P.b.st_wl + so, P.snap.st_wl + ss, M, lane);
+  plane_store(P.b.st_comp_by + so, P.snap.st_comp_by + ss, M, lane);
+  for (int w = lane; w < P.t.EW; w += WAVE) P.b.blocked[(size_t)env * P.t.EW + w] = P.snap.blocked[(size_t)si * P.t.EW + w];
+  if (lane < CG_LOG_RING)
+    ((uint32_t*)(P.b.ring + (size_t)env * CG_LOG_RING * 2))[lane] = ((const uint32_t*)(P.snap.ring + (size_t)si * CG_LOG_RING * 2))[lane];
+  if (lane < CG_I_COUNT) {
+    int32_t v = P.snap.ienv[(size_t)si * CG_I_COUNT + lane];
+    if (lane == CG_I_RNG_TICK) v = tick;   // the draw counter is monotone across episodes
+    P.b.ienv[(size_t)env * CG_I_COUNT + lane] = v;
+  }
+  if (lane < CG_D_COUNT) P.b.fenv[(size_t)env * CG_D_COUNT + lane] = P.snap.fenv[(size_t)si * CG_D_COUNT + lane];
+}
+
+// randomize_compromise_and_ownership volt_typhoon_env.py:330-383; wave per env, global memory only.
+__global__ void randomize_kernel(KParams P, const int32_t* env_ids, int n, uint32_t* keybuf) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= n) return;
+  const int env = env_ids ? env_ids[wave] : wave;
+  if (env < 0 || env >= P.n_envs) return;
+  const int M = P.t.M, MC = P.t.MC;
+  uint8_t* flags = P.b.flags + (size_t)env * M;
+  int32_t* ie = P.b.ienv + (size_t)env * CG_I_COUNT;
+  const uint32_t tick = (uint32_t)ie[CG_I_RNG_TICK];
+  const uint32_t env_id = (uint32_t)(P.c.env_id_base + env);
+  uint32_t* key = keybuf + (size_t)wave * MC * WAVE;
+  int cnt = 0, k_owned = 0, k_comp = 0;
+  for (int c = 0; c < MC; ++c) {
+    int d = c * WAVE + lane;
+    bool el = d < M && !(flags[d] & CG_F_NYA) && !(P.t.dstatic[d] & CG_D_DC);
+    if (d < MC * WAVE) key[d] = el ? cg_draw(P.c.seed, env_id, tick, CG_SITE_SHUFFLE, d, 0) : 0u;
+    cnt += __popcll(ballot(el));
+    k_owned += __popcll(ballot(el && (flags[d] & CG_F_OWNED)));
+    k_comp += __popcll(ballot(el && (flags[d] & CG_F_COMP)));
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  if (lane == 0) ie[CG_I_RNG_TICK] = (int32_t)(tick + 1);
+  if (lane == 0) ie[CG_I_FLAGS] &= ~CG_E_STAR_OK;
+  if (cnt == 0 || (k_owned == 0 && k_comp == 0)) return;
+  int extra = k_comp - k_owned; if (extra < 0) extra = 0;
+  for (int c = 0; c < MC; ++c) {
+    int d = c * WAVE + lane;
+    bool el = d < M && !(flags[d] & CG_F_NYA) && !(P.t.dstatic[d] & CG_D_DC);
+    if (!el) continue;
+    uint32_t kd = key[d];
+    int rank = 0;
+    for (int o = 0; o < M; ++o) {
+      bool eo = !(flags[o] & CG_F_NYA) && !(P.t.dstatic[o] & CG_D_DC);
+      uint32_t ko = key[o];
+      rank += (eo && (ko < kd || (ko == kd && o < d))) ? 1 : 0;
+    }
+    uint8_t f = (uint8_t)(flags[d] & ~(CG_F_OWNED | CG_F_COMP | CG_F_KNOWN));
+    if (rank < k_owned) f |= (CG_F_OWNED | CG_F_COMP | CG_F_KNOWN);
+    else if (rank < k_owned + extra) f |= (CG_F_COMP | CG_F_KNOWN);
+    // flags are rewritten after every lane has read the eligibility bits (NYA/DC do not change)
+    flags[d] = f;
+  }
+}
+
+// role views: CyberDefenseEnv.py:146-257
+__global__ void observe_kernel(KParams P, int role, float* out) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= P.n_envs) return;
+  const int env = wave, M = P.t.M;
+  const uint8_t* flags = P.b.flags + (size_t)env * M;
+  if (role == 0 || role == 1) {
+    float* o = out + (size_t)env * 6 * M;
+    for (int i = lane; i < 6 * M; i += WAVE) {
+      int d = i / 6, col = i - d * 6;
+      uint8_t f = flags[d];
+      float x = col == 0 ? P.t.os_val[d] : col == 1 ? P.t.version[d] : col == 2 ? ((f & CG_F_COMP) ? 1.f : 0.f)
+              : col == 3 ? P.t.anomaly[d] : col == 4 ? ((f & CG_F_KNOWN) ? 1.f : 0.f) : ((f & CG_F_NYA) ? 1.f : 0.f);
+      if (role == 1 && ((f & CG_F_NYA) || !(f & CG_F_OWNED) || col == 2)) x = -1.f;
+      o[i] = x;
+    }
+  } else {
+    const int W = 4 * M + P.c.max_exploits;
+    float* o = out + (size_t)env * W;
+    for (int i = lane; i < W; i += WAVE) {
+      float x;
+      if (i < 4 * M) {
+        int d = i >> 2, col = i & 3;
+        uint8_t f = flags[d];
+        bool vis = (f & CG_F_KNOWN) && !(f & CG_F_NYA) && (f & CG_F_OWNED);
+        x = !vis ? -1.f : col == 0 ? P.t.os_val[d] : col == 1 ? P.t.version[d]
+          : col == 2 ? ((f & CG_F_COMP) ? 1.f : 0.f) : ((f & CG_F_KNOWN) ? 1.f : 0.f);
+      } else {
+        x = (i - 4 * M) < P.t.X ? 1.f : 0.f;
+      }
+      o[i] = x;
+    }
+  }
+}
+
+// Synthetic action script of bench.py: alternating defender / attacker turns.
+// Mirrored in numpy by cygym_amd/actions.py (tests check equality).
+__global__ void gen_actions_kernel(KParams P, int tick, int32_t* mode, int32_t* n_groups, int32_t* atype,
+                                   int32_t* n_exploit, int32_t* exploit, int32_t* app, int32_t* dev_cnt,
+                                   int16_t* dev_idx, int max_devs) {
+  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= P.n_envs) return;
+  const int M = P.t.M;
+  const uint32_t env_id = (uint32_t)(P.c.env_id_base + env);
+  cg_u32x4 r = cg_philox4x32_10(env_id, (uint32_t)tick, CG_SITE_ACTGEN, 0u, (uint32_t)P.c.seed, (uint32_t)(P.c.seed >> 32));
+  const int m = tick & 1;
+  mode[env] = m;
+  n_groups[env] = 0;
+  n_exploit[env] = 1;
+  for (int j = 0; j < CG_MAX_EXPLOITS; ++j) exploit[(size_t)env * CG_MAX_EXPLOITS + j] = -1;
+  exploit[(size_t)env * CG_MAX_EXPLOITS] = (int)cg_index(r.v[1], (uint32_t)(P.t.X > 0 ? P.t.X : 1));
+  app[env] = (int)cg_index(r.v[2], 4u);
+  int k = 0;
+  if (m == CG_MODE_DEFENDER) {
+    const int types[11] = {1, 4, 5, 6, 7, 8, 9, 11, 12, 13, 2};
+    atype[env] = types[cg_index(r.v[0], 11u)];
+    int kmax = M / 8 > 1 ? M / 8 : 1;
+    if (kmax > max_devs) kmax = max_devs;
+    k = 1 + (int)cg_index(r.v[3], (uint32_t)kmax);
+    cg_u32x4 q = cg_philox4x32_10(env_id, (uint32_t)tick, CG_SITE_ACTGEN, 1u, (uint32_t)P.c.seed, (uint32_t)(P.c.seed >> 32));
+    int a = (int)cg_index(q.v[0], (uint32_t)M);
+    int stride = ((M & (M - 1)) == 0 && M > 1) ? (int)(2u * cg_index(q.v[1], (uint32_t)(M / 2)) + 1u) : 1;
+    for (int j = 0; j < k; ++j) dev_idx[(size_t)env * max_devs + j] = (int16_t)((a + (long long)j * stride) % M);
+  } else {
+    atype[env] = 1 + (int)cg_index(r.v[0], 3u);
+  }
+  dev_cnt[env] = k;
+}
+
+}  // namespace
+
+// =====================================================================
+// C ABI
+// =====================================================================
+struct cygym_handle {
+  int device_id;
+  int n_envs;
+  DevTopo t;
+  cygym_config c;
+  cygym_buffers b;
+  cygym_buffers snap;
+  bool bound, has_snap;
+  void* dev_blob;       // one allocation holding the topology copies
+  uint32_t* keybuf;     // randomize scratch [n_envs][Mp]
+  int wpb;
+  int wave_lds, shared_lds;
+  hipEvent_t ev0, ev1;
+  char err[256];
+};
+
+static char g_err[256] = "";
+
+static int fail(cygym_handle* h, int code, const char* fmt, const char* detail) {
+  char* dst = h ? h->err : g_err;
+  snprintf(dst, 256, fmt, detail ? detail : "");
+  if (h) snprintf(g_err, 256, "%s", dst);
+  return code;
+}
+#define HIPCHK(h, call)                                                         \
+  do {                                                                          \
+    hipError_t _e = (call);                                                     \
+    if (_e != hipSuccess) return fail(h, CYGYM_EHIP, #call ": %s", hipGetErrorString(_e)); \
+  } while (0)
+
+extern "C" {
+
+int cygym_version(void) { return CYGYM_ABI_VERSION; }
+const char* cygym_last_error(const cygym_handle* h) { return h ? h->err : g_err; }
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static int choose_launch(cygym_handle* h) {
+  const int M = h->t.M, Mp = h->t.Mp, E = h->t.E, EW = h->t.EW;
+  size_t shared = align_up((size_t)((M + 2) & ~1) * 2 + (size_t)E * 2, 16) + (size_t)Mp * 4 * 3 + (size_t)Mp * 2;
+  shared = align_up(shared, 16);
+  size_t wave = (size_t)Mp * 4 + (size_t)Mp * 8 + (size_t)((EW + 3) & ~3) * 4 + CG_LOG_RING * 4 +
+                (size_t)((Mp / 32 + 2) & ~1) * 4 + (size_t)h->t.MC * 8;
+  wave = align_up(wave, 16);
+  const size_t lds_cap = 160 * 1024;
+  int wpb = 8;
+  while (wpb > 1 && shared + wave * wpb > lds_cap) wpb >>= 1;
+  if (shared + wave * wpb > lds_cap) return -1;
+  h->wpb = wpb; h->wave_lds = (int)wave; h->shared_lds = (int)shared;
+  return 0;
+}
+
+int cygym_create(const cygym_topology* topo, const cygym_config* cfg, int32_t n_envs, int32_t device_id,
+                 cygym_handle** out) {
+  if (!topo || !cfg || !out || n_envs <= 0) return fail(nullptr, CYGYM_EINVAL, "cygym_create: bad argument%s", "");
+  const int M = topo->n_devices, E = topo->n_edges, X = topo->n_exploits;
+  if (M < 1 || M > 2048) return fail(nullptr, CYGYM_EUNSUPPORTED, "n_devices must be in [1, 2048]%s", "");
+  if (E < 0 || E > 65535) return fail(nullptr, CYGYM_EUNSUPPORTED, "n_edges must be <= 65535%s", "");
+  if (X < 0 || X > CG_MAX_EXPLOITS) return fail(nullptr, CYGYM_EINVAL, "n_exploits out of range%s", "");
+  if (!cfg->fast_scan) return fail(nullptr, CYGYM_EUNSUPPORTED, "fast_scan=False (per-log scan path) is not implemented%s", "");
+  if (cfg->num_of_device > 5000) return fail(nullptr, CYGYM_EUNSUPPORTED, "numOfDevice > 5000 (ready-set path) is not implemented%s", "");
+  // host-side validation of the CSR: a malformed topology must never reach a kernel
+  for (int i = 0; i <= M; ++i) {
+    if (topo->out_ptr[i] < 0 || topo->out_ptr[i] > E || topo->in_ptr[i] < 0 || topo->in_ptr[i] > E ||
+        (i && (topo->out_ptr[i] < topo->out_ptr[i - 1] || topo->in_ptr[i] < topo->in_ptr[i - 1])))
+      return fail(nullptr, CYGYM_EINVAL, "malformed CSR row pointers%s", "");
+  }
+  if (topo->out_ptr[0] != 0 || topo->out_ptr[M] != E || topo->in_ptr[0] != 0 || topo->in_ptr[M] != E)
+    return fail(nullptr, CYGYM_EINVAL, "CSR row pointers do not span the edge array%s", "");
+  for (int k = 0; k < E; ++k) {
+    if (topo->out_col[k] < 0 || topo->out_col[k] >= M || topo->in_col[k] < 0 || topo->in_col[k] >= M ||
+        topo->in_eid[k] < 0 || topo->in_eid[k] >= E)
+      return fail(nullptr, CYGYM_EINVAL, "CSR column / edge id out of range%s", "");
+  }
+  cygym_handle* h = new (std::nothrow) cygym_handle();
+  if (!h) return fail(nullptr, CYGYM_EINVAL, "out of host memory%s", "");
+  memset(h, 0, sizeof(*h));
+  h->device_id = device_id; h->n_envs = n_envs; h->c = *cfg;
+  hipError_t e0 = hipSetDevice(device_id);
+  if (e0 != hipSuccess) { fail(nullptr, CYGYM_EHIP, "hipSetDevice: %s", hipGetErrorString(e0)); delete h; return CYGYM_EHIP; }
+  DevTopo& t = h->t;
+  t.M = M; t.X = X; t.E = E; t.EW = (E + 31) / 32 > 0 ? (E + 31) / 32 : 1;
+  t.MC = (M + WAVE - 1) / WAVE; t.Mp = t.MC * WAVE;
+  if (choose_launch(h) != 0) { delete h; return fail(nullptr, CYGYM_EUNSUPPORTED, "topology does not fit in LDS%s", ""); }
+  // one blob: u8 x3 [M], f32 x3 [M], u16 out_ptr[M+1], out_col[E], in_ptr[M+1], in_col[E], in_eid[E]
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 16); return o; };
+  size_t o_dst = take(M), o_vul = take(M), o_nap = take(M);
+  size_t o_os = take((size_t)M * 4), o_ver = take((size_t)M * 4), o_ano = take((size_t)M * 4);
+  size_t o_op = take((size_t)(M + 1) * 2), o_oc = take((size_t)(E > 0 ? E : 1) * 2);
+  size_t o_ip = take((size_t)(M + 1) * 2), o_ic = take((size_t)(E > 0 ? E : 1) * 2), o_ie = take((size_t)(E > 0 ? E : 1) * 2);
+  uint8_t* host = (uint8_t*)calloc(1, off);
+  if (!host) { delete h; return fail(nullptr, CYGYM_EINVAL, "out of host memory%s", ""); }
+  memcpy(host + o_dst, topo->dstatic, M); memcpy(host + o_vul, topo->vuln, M); memcpy(host + o_nap, topo->napps, M);
+  memcpy(host + o_os, topo->os_val, (size_t)M * 4); memcpy(host + o_ver, topo->version, (size_t)M * 4);
+  memcpy(host + o_ano, topo->anomaly, (size_t)M * 4);
+  for (int i = 0; i <= M; ++i) { ((uint16_t*)(host + o_op))[i] = (uint16_t)topo->out_ptr[i]; ((uint16_t*)(host + o_ip))[i] = (uint16_t)topo->in_ptr[i]; }
+  for (int k = 0; k < E; ++k) {
+    ((uint16_t*)(host + o_oc))[k] = (uint16_t)topo->out_col[k];
+    ((uint16_t*)(host + o_ic))[k] = (uint16_t)topo->in_col[k];
+    ((uint16_t*)(host + o_ie))[k] = (uint16_t)topo->in_eid[k];
+  }
+  hipError_t e1 = hipMalloc(&h->dev_blob, off);
+  if (e1 == hipSuccess) e1 = hipMemcpy(h->dev_blob, host, off, hipMemcpyHostToDevice);
+  free(host);
+  if (e1 == hipSuccess) e1 = hipMalloc((void**)&h->keybuf, (size_t)n_envs * t.Mp * 4);
+  if (e1 == hipSuccess) e1 = hipEventCreate(&h->ev0);
+  if (e1 == hipSuccess) e1 = hipEventCreate(&h->ev1);
+  if (e1 != hipSuccess) { fail(nullptr, CYGYM_EHIP, "cygym_create: %s", hipGetErrorString(e1)); cygym_destroy(h); return CYGYM_EHIP; }
+  uint8_t* d = (uint8_t*)h->dev_blob;
+  t.dstatic = d + o_dst; t.vuln = d + o_vul; t.napps = d + o_nap;
+  t.os_val = (const float*)(d + o_os); t.version = (const float*)(d + o_ver); t.anomaly = (const float*)(d + o_ano);
+  t.out_ptr = (const uint16_t*)(d + o_op); t.out_col = (const uint16_t*)(d + o_oc);
+  t.in_ptr = (const uint16_t*)(d + o_ip); t.in_col = (const uint16_t*)(d + o_ic); t.in_eid = (const uint16_t*)(d + o_ie);
+  // opt in to large dynamic LDS for every instantiation we may launch
+  const int lds = h->shared_lds + h->wave_lds * h->wpb;
+  hipError_t e2 = hipSuccess;
+  if (h->wpb == 8) e2 = hipFuncSetAttribute((const void*)step_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  else if (h->wpb == 4) e2 = hipFuncSetAttribute((const void*)step_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  else if (h->wpb == 2) e2 = hipFuncSetAttribute((const void*)step_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  else e2 = hipFuncSetAttribute((const void*)step_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e2 != hipSuccess) { fail(nullptr, CYGYM_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString(e2)); cygym_destroy(h); return CYGYM_EHIP; }
+  *out = h;
+  return CYGYM_OK;
+}
+
+void cygym_destroy(cygym_handle* h) {
+  if (!h) return;
+  if (h->dev_blob) (void)hipFree(h->dev_blob);
+  if (h->keybuf) (void)hipFree(h->keybuf);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  delete h;
+}
+
+int cygym_set_config(cygym_handle* h, const cygym_config* cfg) {
+  if (!h || !cfg) return fail(h, CYGYM_EINVAL, "cygym_set_config: bad argument%s", "");
+  if (!cfg->fast_scan) return fail(h, CYGYM_EUNSUPPORTED, "fast_scan=False is not implemented%s", "");
+  h->c = *cfg;
+  return CYGYM_OK;
+}
+
+static int check_buffers(cygym_handle* h, const cygym_buffers* b, bool snapshot) {
+  if (!b || !b->flags || !b->busy || !b->wl || !b->comp_by || !b->st_flags || !b->st_busy || !b->st_wl ||
+      !b->st_comp_by || !b->blocked || !b->ring || !b->ienv || !b->fenv)
+    return fail(h, CYGYM_EINVAL, "buffer struct has a null plane%s", "");
+  if (snapshot ? (b->n_envs != 1 && b->n_envs != h->n_envs) : (b->n_envs != h->n_envs))
+    return fail(h, CYGYM_EINVAL, "buffer struct has the wrong leading dimension%s", "");
+  return CYGYM_OK;
+}
+
+int cygym_bind(cygym_handle* h, const cygym_buffers* state) {
+  if (!h) return fail(h, CYGYM_EINVAL, "cygym_bind: null handle%s", "");
+  int rc = check_buffers(h, state, false);
+  if (rc) return rc;
+  h->b = *state;
+  h->bound = true;
+  return CYGYM_OK;
+}
+
+static KParams make_params(cygym_handle* h) {
+  KParams P;
+  memset(&P, 0, sizeof(P));
+  P.t = h->t; P.c = h->c; P.b = h->b; P.n_envs = h->n_envs;
+  P.wave_lds = h->wave_lds; P.shared_lds = h->shared_lds;
+  return P;
+}
+
+int cygym_reset(cygym_handle* h, const cygym_buffers* snapshot, const int32_t* env_ids, int32_t n, void* stream) {
+  if (!h || !h->bound) return fail(h, CYGYM_ENOTBOUND, "cygym_reset: handle not bound%s", "");
+  if (!snapshot) {
+    if (!h->has_snap) return fail(h, CYGYM_EINVAL, "cygym_reset: no snapshot given or registered%s", "");
+    snapshot = &h->snap;
+  }
+  int rc = check_buffers(h, snapshot, true);
+  if (rc) return rc;
+  if (!env_ids) n = h->n_envs;
+  if (n <= 0) return CYGYM_OK;
+  HIPCHK(h, hipSetDevice(h->device_id));
+  KParams P = make_params(h);
+  P.snap = *snapshot;
+  const int threads = 256, waves_per_block = threads / WAVE;
+  hipLaunchKernelGGL(reset_kernel, dim3((n + waves_per_block - 1) / waves_per_block), dim3(threads), 0,
+                     (hipStream_t)stream, P, env_ids, n);
+  HIPCHK(h, hipGetLastError());
+  return CYGYM_OK;
+}
+
+int cygym_randomize(cygym_handle* h, const int32_t* env_ids, int32_t n, void* stream) {
+  if (!h || !h->bound) return fail(h, CYGYM_ENOTBOUND, "cygym_randomize: handle not bound%s", "");
+  if (!env_ids) n = h->n_envs;
+  if (n <= 0) return CYGYM_OK;
+  if (n > h->n_envs) return fail(h, CYGYM_EINVAL, "cygym_randomize: more ids than envs%s", "");
+  HIPCHK(h, hipSetDevice(h->device_id));
+  KParams P = make_params(h);
+  const int threads = 256, waves_per_block = threads / WAVE;
+  hipLaunchKernelGGL(randomize_kernel, dim3((n + waves_per_block - 1) / waves_per_block), dim3(threads), 0,
+                     (hipStream_t)stream, P, env_ids, n, h->keybuf);
+  HIPCHK(h, hipGetLastError());
+  return CYGYM_OK;
+}
+
+int cygym_set_snapshot(cygym_handle* h, const cygym_buffers* snapshot) {
+  if (!h) return fail(h, CYGYM_EINVAL, "cygym_set_snapshot: null handle%s", "");
+  if (!snapshot) { h->has_snap = false; memset(&h->snap, 0, sizeof(h->snap)); return CYGYM_OK; }
+  int rc = check_buffers(h, snapshot, true);
+  if (rc) return rc;
+  h->snap = *snapshot;
+  h->has_snap = true;
+  return CYGYM_OK;
+}
+
+int cygym_step(cygym_handle* h, const cygym_actions* a, const cygym_outputs* o, void* stream) {
+  if (!h || !h->bound) return fail(h, CYGYM_ENOTBOUND, "cygym_step: handle not bound%s", "");
+  if (!a || !o || !a->mode || !a->n_groups || !a->atype || !a->n_exploit || !a->exploit || !a->app ||
+      !a->dev_cnt || !a->dev_idx || !o->obs || !o->raw || !o->shaped || !o->done)
+    return fail(h, CYGYM_EINVAL, "cygym_step: null action / output pointer%s", "");
+  if (a->max_groups < 1 || a->max_devs < 1) return fail(h, CYGYM_EINVAL, "cygym_step: max_groups / max_devs must be >= 1%s", "");
+  if (h->c.auto_reset && !h->has_snap) return fail(h, CYGYM_EINVAL, "auto_reset needs cygym_set_snapshot first%s", "");
+  HIPCHK(h, hipSetDevice(h->device_id));
+  KParams P = make_params(h);
+  P.a = *a; P.o = *o;
+  P.snap = h->snap;
+  const int lds = h->shared_lds + h->wave_lds * h->wpb;
+  const dim3 grid((h->n_envs + h->wpb - 1) / h->wpb), block(h->wpb * WAVE);
+  hipStream_t s = (hipStream_t)stream;
+  switch (h->wpb) {
+    case 8: hipLaunchKernelGGL(step_kernel<8>, grid, block, lds, s, P); break;
+    case 4: hipLaunchKernelGGL(step_kernel<4>, grid, block, lds, s, P); break;
+    case 2: hipLaunchKernelGGL(step_kernel<2>, grid, block, lds, s, P); break;
+    default: hipLaunchKernelGGL(step_kernel<1>, grid, block, lds, s, P); break;
+  }
+  HIPCHK(h, hipGetLastError());
+  return CYGYM_OK;
+}
+
+int cygym_observe(cygym_handle* h, int32_t role, float* out, void* stream) {
+  if (!h || !h->bound) return fail(h, CYGYM_ENOTBOUND, "cygym_observe: handle not bound%s", "");
+  if (!out || role < 0 || role > 2) return fail(h, CYGYM_EINVAL, "cygym_observe: bad argument%s", "");
+  HIPCHK(h, hipSetDevice(h->device_id));
+  KParams P = make_params(h);
+  const int threads = 256, waves_per_block = threads / WAVE;
+  hipLaunchKernelGGL(observe_kernel, dim3((h->n_envs + waves_per_block - 1) / waves_per_block), dim3(threads), 0,
+                     (hipStream_t)stream, P, role, out);
+  HIPCHK(h, hipGetLastError());
+  return CYGYM_OK;
+}
+
+int cygym_gen_actions(cygym_handle* h, int32_t tick, int32_t* mode, int32_t* n_groups, int32_t* atype,
+                      int32_t* n_exploit, int32_t* exploit, int32_t* app, int32_t* dev_cnt, int16_t* dev_idx,
+                      int32_t max_devs, void* stream) {
+  if (!h) return fail(h, CYGYM_EINVAL, "cygym_gen_actions: null handle%s", "");
+  if (!mode || !n_groups || !atype || !n_exploit || !exploit || !app || !dev_cnt || !dev_idx || max_devs < 1)
+    return fail(h, CYGYM_EINVAL, "cygym_gen_actions: bad argument%s", "");
+  HIPCHK(h, hipSetDevice(h->device_id));
+  KParams P = make_params(h);
+  hipLaunchKernelGGL(gen_actions_kernel, dim3((h->n_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, tick,
+                     mode, n_groups, atype, n_exploit, exploit, app, dev_cnt, dev_idx, max_devs);
+  HIPCHK(h, hipGetLastError());
+  return CYGYM_OK;
+}
+
+int cygym_timer_start(cygym_handle* h, void* stream) {
+  if (!h) return fail(h, CYGYM_EINVAL, "null handle%s", "");
+  HIPCHK(h, hipEventRecord(h->ev0, (hipStream_t)stream));
+  return CYGYM_OK;
+}
+int cygym_timer_stop(cygym_handle* h, void* stream, float* ms) {
+  if (!h || !ms) return fail(h, CYGYM_EINVAL, "null argument%s", "");
+  HIPCHK(h, hipEventRecord(h->ev1, (hipStream_t)stream));
+  HIPCHK(h, hipEventSynchronize(h->ev1));
+  HIPCHK(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+  return CYGYM_OK;
+}
+
+}  // extern "C"

