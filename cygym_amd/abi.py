@@ -51,8 +51,7 @@ class Config(C.Structure):
 
 class Buffers(C.Structure):
     _fields_ = [
-        ("flags", C.c_void_p), ("busy", C.c_void_p), ("wl", C.c_void_p), ("comp_by", C.c_void_p),
-        ("st_flags", C.c_void_p), ("st_busy", C.c_void_p), ("st_wl", C.c_void_p), ("st_comp_by", C.c_void_p),
+        ("live", C.c_void_p), ("stash", C.c_void_p),
         ("blocked", C.c_void_p), ("ring", C.c_void_p), ("ienv", C.c_void_p), ("fenv", C.c_void_p),
         ("n_envs", C.c_int32), ("reserved", C.c_int32),
     ]
@@ -72,7 +71,10 @@ class Outputs(C.Structure):
 
 BASELINES = {"Nash": 0, "No Defense": 1, "Preset": 2, "No Attack": 3}
 
-STATE_PLANES = ("flags", "busy", "wl", "comp_by", "st_flags", "st_busy", "st_wl", "st_comp_by")
+LIVE_PLANES = ("flags", "busy", "wl", "comp_by")          # order inside Buffers.live  [N][4][M]
+STASH_PLANES = ("st_flags", "st_busy", "st_wl", "st_comp_by")  # order inside Buffers.stash [N][4][M]
+STATE_PLANES = LIVE_PLANES + STASH_PLANES
+BUFFER_FIELDS = ("live", "stash", "blocked", "ring", "ienv", "fenv")
 
 
 @dataclass

@@ -17,28 +17,31 @@ import torch
 from . import _lib, abi
 from . import spec as S
 
-_STATE_DTYPES = {
-    "flags": torch.uint8, "busy": torch.uint8, "wl": torch.uint8, "comp_by": torch.uint8,
-    "st_flags": torch.uint8, "st_busy": torch.uint8, "st_wl": torch.uint8, "st_comp_by": torch.uint8,
-    "blocked": torch.int32, "ring": torch.int16, "ienv": torch.int32, "fenv": torch.float64,
-}
+_BUF_DTYPES = {"live": torch.uint8, "stash": torch.uint8, "blocked": torch.int32, "ring": torch.int16,
+               "ienv": torch.int32, "fenv": torch.float64}
+_STATE_KEYS = abi.STATE_PLANES + ("blocked", "ring", "ienv", "fenv")
 _NP_VIEW = {"blocked": np.uint32, "ring": np.uint16}
 
 
 def _alloc_state(n, M, EW, device):
-    dims = {"flags": (M,), "busy": (M,), "wl": (M,), "comp_by": (M,), "st_flags": (M,), "st_busy": (M,),
-            "st_wl": (M,), "st_comp_by": (M,), "blocked": (EW,), "ring": (S.LOG_RING, 2),
+    """`live` / `stash` are the [N][4][M] buffers of the ABI; flags/busy/... are VIEWS into them."""
+    dims = {"live": (4, M), "stash": (4, M), "blocked": (EW,), "ring": (S.LOG_RING, 2),
             "ienv": (S.I_COUNT,), "fenv": (S.D_COUNT,)}
-    return {k: torch.zeros((n,) + dims[k], dtype=dt, device=device) for k, dt in _STATE_DTYPES.items()}
+    st = {k: torch.zeros((n,) + dims[k], dtype=dt, device=device) for k, dt in _BUF_DTYPES.items()}
+    for i, k in enumerate(abi.LIVE_PLANES):
+        st[k] = st["live"][:, i]
+    for i, k in enumerate(abi.STASH_PLANES):
+        st[k] = st["stash"][:, i]
+    return st
 
 
 def _buffers_struct(st) -> abi.Buffers:
     b = abi.Buffers()
-    for k in _STATE_DTYPES:
+    for k in abi.BUFFER_FIELDS:
         t = st[k]
         assert t.is_contiguous()
         setattr(b, k, t.data_ptr())
-    b.n_envs = st["flags"].shape[0]
+    b.n_envs = st["live"].shape[0]
     return b
 
 
@@ -117,12 +120,12 @@ class BatchedCyberDefenseEnv:
         self._out.obs, self._out.raw = self.obs.data_ptr(), self.raw.data_ptr()
         self._out.shaped, self._out.done = self.shaped.data_ptr(), self.done.data_ptr()
         # first load is a verbatim copy of the snapshot (reset() keeps the live RNG tick)
-        for k in _STATE_DTYPES:
+        for k in abi.BUFFER_FIELDS:
             self.state[k].copy_(self.snapshot[k].expand_as(self.state[k]))
 
     # ------------------------------------------------------------------
     def _load(self, dst, src):
-        for k, dt in _STATE_DTYPES.items():
+        for k in _STATE_KEYS:
             a = np.asarray(src[k])
             if k == "blocked":
                 if a.shape[-1] != self.EW or a.dtype not in (np.uint32, np.int32):
@@ -169,7 +172,7 @@ class BatchedCyberDefenseEnv:
         else:
             tmp = _alloc_state(1, self.M, self.EW, self.device)
             self._load(tmp, state)
-            for k in _STATE_DTYPES:
+            for k in abi.BUFFER_FIELDS:
                 self.state[k].copy_(tmp[k].expand_as(self.state[k]))
 
     def reset(self, env_ids=None):
@@ -248,11 +251,15 @@ class BatchedCyberDefenseEnv:
     def state_numpy(self) -> dict:
         torch.cuda.synchronize(self.device)
         out = {}
-        for k in _STATE_DTYPES:
+        for k in abi.BUFFER_FIELDS:
             a = self.state[k].cpu().numpy()
             if k in _NP_VIEW:
                 a = a.view(_NP_VIEW[k])
             out[k] = a
+        for i, k in enumerate(abi.LIVE_PLANES):
+            out[k] = out["live"][:, i]
+        for i, k in enumerate(abi.STASH_PLANES):
+            out[k] = out["stash"][:, i]
         return out
 
     def counters(self) -> dict:

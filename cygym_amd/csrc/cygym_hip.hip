@@ -37,8 +37,16 @@ namespace {
 
 constexpr int WAVE = 64;
 
+// The shared topology lives in ONE packed device blob whose layout is also the layout of the
+// workgroup-shared LDS section (copied with 16-byte loads): byte offsets o_* into the blob.
+//   [optr u16 M+1][ocol u16 E][os f32 M][ver f32 M][ano f32 M][dst u8 M][vul u8 M][nap u8 M] | [iptr u16 M+1][icol u16 E][ieid u16 E]
+// The first `lds_bytes` bytes are staged in LDS: everything when it fits (in_lds), else all but the in-CSR.
 struct DevTopo {
   int M, X, E, EW, MC, Mp;
+  const uint8_t* blob;
+  int o_optr, o_ocol, o_os, o_ver, o_ano, o_dst, o_vul, o_nap, o_iptr, o_icol, o_ieid;
+  int blob_bytes, lds_bytes, in_lds;
+  // global views (host-side convenience; kernels outside the tick use them)
   const uint8_t *dstatic, *vuln, *napps;
   const float *os_val, *version, *anomaly;
   const uint16_t *out_ptr, *out_col;   // u16: E <= 65535, M <= 2048
@@ -55,7 +63,14 @@ struct KParams {
   int n_envs;
   int wave_lds;         // bytes of LDS per wave
   int shared_lds;       // bytes of the workgroup-shared LDS section
+  unsigned long long* dbg;   // diagnostic builds (-DCG_STAMPS): [N][16] s_memtime stamps per env
 };
+
+#ifdef CG_STAMPS
+#define STAMP(k) do { if (P.dbg && lane == 0) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); P.dbg[(size_t)env * 16 + (k)] = _t; } } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
 
 // ---------------- wave-level helpers ----------------
 __device__ __forceinline__ void wsync() {
@@ -94,21 +109,25 @@ __device__ __forceinline__ int nth_bit(uint64_t m, int r) {  // position of the 
 // ---------------- per-wave environment view ----------------
 struct Env {
   // LDS
-  uint8_t *flags, *busy, *wl, *cby;
+  uint8_t *flags, *busy, *wl, *cby;   // contiguous [4][M]
   uint32_t* scr;     // [2*Mp] scratch (8 bytes per device)
   uint32_t* blk;     // [EWp]
   uint16_t* ring;    // [2*CG_LOG_RING]
   uint32_t* marks;   // [Mp/32 + 1]
+  int16_t* devl;     // [L] this tick's device lists (all groups, concatenated)
   // shared LDS (topology)
   const uint16_t *optr, *ocol;
-  const uint8_t *dst, *vul;
+  const uint8_t *dst, *vul, *nap;
   const float *osv, *ver, *ano;
+  // in-CSR: LDS when it fits, else the global blob (generic pointers)
+  const uint16_t *iptr, *icol, *ieid;
+  uint8_t* stash;    // global [4][M] of this env
   // misc
   int M, MC, lane, env;
   uint32_t env_id, tick;
   uint64_t seed;
   int eflags;        // CG_I_FLAGS (uniform)
-  bool blk_loaded, blk_dirty, ring_loaded, ring_dirty, cby_dirty;
+  bool blk_dirty, ring_dirty, cby_dirty;
   int log_total;
 
   __device__ __forceinline__ uint32_t draw(uint32_t site, uint32_t a, uint32_t b) const {
@@ -123,41 +142,6 @@ struct Env {
 
 __device__ __forceinline__ void byte_or(uint8_t* base, int d, uint32_t bits) {
   atomicOr((unsigned int*)(base + (d & ~3)), bits << ((d & 3) * 8));
-}
-
-// Stage / write back one [M]-byte plane (global <-> LDS), dword-wide when aligned.
-__device__ __forceinline__ void plane_load(uint8_t* dst, const uint8_t* src, int M, int lane) {
-  if ((M & 3) == 0) {
-    const uint32_t* s = (const uint32_t*)src;
-    uint32_t* d = (uint32_t*)dst;
-    for (int w = lane; w < (M >> 2); w += WAVE) d[w] = s[w];
-  } else {
-    for (int i = lane; i < M; i += WAVE) dst[i] = src[i];
-  }
-}
-__device__ __forceinline__ void plane_store(uint8_t* dst, const uint8_t* src, int M, int lane) {
-  if ((M & 3) == 0) {
-    const uint32_t* s = (const uint32_t*)src;
-    uint32_t* d = (uint32_t*)dst;
-    for (int w = lane; w < (M >> 2); w += WAVE) d[w] = s[w];
-  } else {
-    for (int i = lane; i < M; i += WAVE) dst[i] = src[i];
-  }
-}
-
-__device__ void ensure_blocked(Env& e, const KParams& P) {
-  if (e.blk_loaded) return;
-  const uint32_t* g = P.b.blocked + (size_t)e.env * P.t.EW;
-  for (int w = e.lane; w < P.t.EW; w += WAVE) e.blk[w] = g[w];
-  e.blk_loaded = true;
-  wsync();
-}
-__device__ void ensure_ring(Env& e, const KParams& P) {
-  if (e.ring_loaded) return;
-  const uint32_t* g = (const uint32_t*)(P.b.ring + (size_t)e.env * CG_LOG_RING * 2);
-  if (e.lane < CG_LOG_RING) ((uint32_t*)e.ring)[e.lane] = g[e.lane];
-  e.ring_loaded = true;
-  wsync();
 }
 
 // multiplicity of every device in a list -> bytes in scr (as uint8 [Mp]); ids >= M ignored.
@@ -210,11 +194,10 @@ __device__ void def_global(Env& e, const KParams& P, int at, const int16_t* dev,
     if (L > 0) {
       int d = dev[0];
       if (d >= 0 && d < M && e.lane == 0) {
-        size_t o = (size_t)e.env * M + d;
-        P.b.st_flags[o] = (uint8_t)(CG_S_VALID | (e.flags[d] & CG_S_KEEP));
-        P.b.st_busy[o] = e.busy[d];
-        P.b.st_wl[o] = e.wl[d];
-        P.b.st_comp_by[o] = e.cby[d];
+        e.stash[d] = (uint8_t)(CG_S_VALID | (e.flags[d] & CG_S_KEEP));
+        e.stash[M + d] = e.busy[d];
+        e.stash[2 * M + d] = e.wl[d];
+        e.stash[3 * M + d] = e.cby[d];
       }
     }
     ie[CG_I_CKPT_CNT] += 1;
@@ -270,7 +253,7 @@ __device__ void def_clean(Env& e, const KParams& P, const int16_t* dev, int L, d
 __device__ bool pick_incident(Env& e, const KParams& P, int d, bool want, uint32_t site, int occ_b,
                               int& su, int& sv) {
   const int o0 = e.optr[d], o1 = e.optr[d + 1];
-  const int i0 = P.t.in_ptr[d], i1 = P.t.in_ptr[d + 1];
+  const int i0 = e.iptr[d], i1 = e.iptr[d + 1];
   int n = 0;
   for (int k0 = o0; k0 < o1; k0 += WAVE) {
     int k = k0 + e.lane;
@@ -280,7 +263,7 @@ __device__ bool pick_incident(Env& e, const KParams& P, int d, bool want, uint32
   int n_out = n;
   for (int k0 = i0; k0 < i1; k0 += WAVE) {
     int k = k0 + e.lane;
-    bool p = (k < i1) && (e.blocked(P.t.in_eid[k]) == want);
+    bool p = (k < i1) && (e.blocked(e.ieid[k]) == want);
     n += __popcll(ballot(p));
   }
   if (n == 0) return false;
@@ -300,10 +283,10 @@ __device__ bool pick_incident(Env& e, const KParams& P, int d, bool want, uint32
     int seen = 0;
     for (int k0 = i0; k0 < i1; k0 += WAVE) {
       int k = k0 + e.lane;
-      bool p = (k < i1) && (e.blocked(P.t.in_eid[k]) == want);
+      bool p = (k < i1) && (e.blocked(e.ieid[k]) == want);
       uint64_t m = ballot(p);
       int c = __popcll(m);
-      if (r < seen + c) { int pos = nth_bit(m, r - seen); su = P.t.in_col[k0 + pos]; sv = d; return true; }
+      if (r < seen + c) { int pos = nth_bit(m, r - seen); su = e.icol[k0 + pos]; sv = d; return true; }
       seen += c;
     }
   }
@@ -328,7 +311,6 @@ __device__ void def_per_device(Env& e, const KParams& P, int at, const int16_t* 
   const int M = e.M;
   if (at == 1) { def_clean(e, P, dev, L, cost, ie, fe, nullptr); return; }
   if (at == 6 || at == 9) {  // sequential over the list, wave-parallel inside (:1071-1100)
-    ensure_blocked(e, P);
     // occurrence numbers: kept in scr as bytes
     for (int i = e.lane; i < (e.MC * WAVE) / 4; i += WAVE) e.scr[i] = 0;
     wsync();
@@ -354,10 +336,10 @@ __device__ void def_per_device(Env& e, const KParams& P, int at, const int16_t* 
   if (at == 12) {  // :1102-1109: the reference restores device_indices[0] once per listed active device
     int d0 = dev[0];
     bool ok = d0 >= 0 && d0 < M;
-    size_t o = (size_t)e.env * M + (ok ? d0 : 0);
-    uint8_t sf = ok ? P.b.st_flags[o] : 0;
+    const int o = ok ? d0 : 0;
+    uint8_t sf = ok ? e.stash[o] : 0;
     if (!(sf & CG_S_VALID)) return;
-    uint8_t sb = P.b.st_busy[o], sw = P.b.st_wl[o], sc = P.b.st_comp_by[o];
+    uint8_t sb = e.stash[M + o], sw = e.stash[2 * M + o], sc = e.stash[3 * M + o];
     int n_iter = 0;
     for (int p = 0; p < L; ++p) {   // uniform scalar walk: restoring d0 may change ITS Not_yet_added
       int d = dev[p];
@@ -387,7 +369,7 @@ __device__ void def_per_device(Env& e, const KParams& P, int at, const int16_t* 
       if (k > 0 && !(f & CG_F_NYA)) {
         n_mult += k; n_dist += 1;
         if (at == 4) {  // :1013-1018
-          if (app >= 0 && app < P.t.napps[d])
+          if (app >= 0 && app < e.nap[d])
             e.busy[d] = (uint8_t)cg_randint(e.draw(CG_SITE_STALL_PATCH, d, k - 1), 0, P.c.default_high);
         } else if (at == 7) {  // :1082-1089
           e.flags[d] = (uint8_t)((f | CG_F_NYA) & ~(CG_F_COMP | CG_F_WLADV));
@@ -412,7 +394,6 @@ __device__ void def_per_device(Env& e, const KParams& P, int at, const int16_t* 
       cost += -0.5 * n_mult * ds;
       fe[CG_D_DEF_COST] += 0.5 * n_mult * ds;
       if (e.eflags & CG_E_DET_RANDOM) {  // Detector.batch_predict coin mode CDSimulator.py:715-716
-        ensure_ring(e, P);
         const int majority = w / 2 + 1;
         for (int s = 0; s < n_mult; ++s) {
           bool anom = false;
@@ -578,7 +559,6 @@ __device__ void attacker_spread(Env& e, const KParams& P, const int32_t* expl, i
     wsync();
     // ring: only the last CG_LOG_RING entries (global order: source id, then row order) matter
     if (total_new > 0) {
-      ensure_ring(e, P);
       const uint32_t base = (uint32_t)e.log_total;
       const uint32_t end = base + (uint32_t)total_new;
       const uint32_t lo = end > CG_LOG_RING ? end - CG_LOG_RING : 0;
@@ -900,7 +880,7 @@ __device__ void evolve(Env& e, const KParams& P) {
     for (int c = 0; c < MC; ++c) {
       int d = c * WAVE + e.lane;
       if (d < M && ((newly[d >> 5] >> (d & 31)) & 1u) && !(e.flags[d] & (CG_F_NYA | CG_F_OWNED))) {
-        int deg = (e.optr[d + 1] - e.optr[d]) + (P.t.in_ptr[d + 1] - P.t.in_ptr[d]);
+        int deg = (e.optr[d + 1] - e.optr[d]) + (e.iptr[d + 1] - e.iptr[d]);
         if (deg < 1) iso = true;
       }
     }
@@ -910,78 +890,101 @@ __device__ void evolve(Env& e, const KParams& P) {
 }
 
 // ---------------- the tick ----------------
+// 16-byte copy helper: n16 uint4 items, strided by `stride` threads
+__device__ __forceinline__ void copy16(uint4* dst, const uint4* src, int n16, int tid, int stride) {
+  for (int i = tid; i < n16; i += stride) dst[i] = src[i];
+}
+
 template <int WPB>
 __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
   extern __shared__ __align__(16) uint8_t smem[];
-  const int M = P.t.M, MC = P.t.MC, Mp = MC * WAVE, E = P.t.E;
-  // ---- shared section: topology ----
-  uint16_t* s_optr = (uint16_t*)smem;                      // [M+1] (padded to even count)
-  uint16_t* s_ocol = s_optr + ((M + 2) & ~1);              // [E]
-  float* s_os = (float*)(smem + (((size_t)((M + 2) & ~1) * 2 + (size_t)E * 2 + 15) & ~(size_t)15));
-  float* s_ver = s_os + Mp;
-  float* s_ano = s_ver + Mp;
-  uint8_t* s_dst = (uint8_t*)(s_ano + Mp);
-  uint8_t* s_vul = s_dst + Mp;
-  for (int i = threadIdx.x; i <= M; i += WPB * WAVE) s_optr[i] = P.t.out_ptr[i];
-  for (int i = threadIdx.x; i < E; i += WPB * WAVE) s_ocol[i] = P.t.out_col[i];
-  for (int i = threadIdx.x; i < M; i += WPB * WAVE) {
-    s_os[i] = P.t.os_val[i]; s_ver[i] = P.t.version[i]; s_ano[i] = P.t.anomaly[i];
-    s_dst[i] = P.t.dstatic[i]; s_vul[i] = P.t.vuln[i];
-  }
-  __syncthreads();   // the only workgroup barrier: waves diverge per env from here on
-
+  const int M = P.t.M, MC = P.t.MC, Mp = MC * WAVE;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int env = uni(blockIdx.x * WPB + wave);
-  if (env >= P.n_envs) return;
+  const bool live = env < P.n_envs;
+  const int G = P.a.max_groups, L = P.a.max_devs;
 
+  // ---- per-wave LDS carve ----
   uint8_t* wb = smem + P.shared_lds + (size_t)wave * P.wave_lds;
+  const int live_bytes = (4 * M + 15) & ~15;
   Env e;
-  e.flags = wb; e.busy = wb + Mp; e.wl = wb + 2 * Mp; e.cby = wb + 3 * Mp;
-  e.scr = (uint32_t*)(wb + 4 * Mp);
+  e.flags = wb; e.busy = wb + M; e.wl = wb + 2 * M; e.cby = wb + 3 * M;
+  e.scr = (uint32_t*)(wb + live_bytes);
   e.blk = e.scr + 2 * Mp;
   e.ring = (uint16_t*)(e.blk + ((P.t.EW + 3) & ~3));
   e.marks = (uint32_t*)(e.ring + 2 * CG_LOG_RING);
   uint64_t* srcb = (uint64_t*)(e.marks + ((Mp / 32 + 2) & ~1));
-  e.optr = s_optr; e.ocol = s_ocol; e.dst = s_dst; e.vul = s_vul; e.osv = s_os; e.ver = s_ver; e.ano = s_ano;
+  e.devl = (int16_t*)(srcb + MC);
+  e.optr = (const uint16_t*)(smem + P.t.o_optr); e.ocol = (const uint16_t*)(smem + P.t.o_ocol);
+  e.osv = (const float*)(smem + P.t.o_os); e.ver = (const float*)(smem + P.t.o_ver); e.ano = (const float*)(smem + P.t.o_ano);
+  e.dst = smem + P.t.o_dst; e.vul = smem + P.t.o_vul; e.nap = smem + P.t.o_nap;
+  {
+    const uint8_t* ib = P.t.in_lds ? (const uint8_t*)smem : P.t.blob;
+    e.iptr = (const uint16_t*)(ib + P.t.o_iptr); e.icol = (const uint16_t*)(ib + P.t.o_icol); e.ieid = (const uint16_t*)(ib + P.t.o_ieid);
+  }
   e.M = M; e.MC = MC; e.lane = lane; e.env = env;
   e.env_id = (uint32_t)(P.c.env_id_base + env);
   e.seed = P.c.seed;
-  e.blk_loaded = e.blk_dirty = e.ring_loaded = e.ring_dirty = e.cby_dirty = false;
+  e.blk_dirty = e.ring_dirty = e.cby_dirty = false;
 
-  // ---- per-env scalars (uniform) ----
+  STAMP(0);
+  // ---- issue every global load of this tick up front (one memory latency, not a chain) ----
+  const size_t so = (size_t)(live ? env : 0) * 4 * M;
+  const uint8_t* g_live = P.b.live + so;
+  e.stash = P.b.stash + so;
   int32_t ie[CG_I_COUNT];
   double fe[CG_D_COUNT];
-  {
+  int mode = 0, ng = 0, at0 = 8, cnt0 = 0, nexp0 = 0, app0 = -1;
+  uint4 r0 = make_uint4(0, 0, 0, 0);
+  uint32_t ringw = 0;
+  const bool vec = (M & 3) == 0;
+  const int items = M >> 2;   // uint4 items of the [4][M] live block when M % 4 == 0
+  if (live) {
     const int32_t* g = P.b.ienv + (size_t)env * CG_I_COUNT;
 #pragma unroll
     for (int i = 0; i < CG_I_COUNT; ++i) ie[i] = g[i];
     const double* gf = P.b.fenv + (size_t)env * CG_D_COUNT;
 #pragma unroll
     for (int i = 0; i < CG_D_COUNT; ++i) fe[i] = gf[i];
+    mode = P.a.mode[env];
+    ng = P.a.n_groups[env];
+    at0 = P.a.atype[(size_t)env * G];
+    cnt0 = P.a.dev_cnt[(size_t)env * G];
+    nexp0 = P.a.n_exploit[(size_t)env * G];
+    app0 = P.a.app[(size_t)env * G];
+    if (vec && lane < items) r0 = ((const uint4*)g_live)[lane];
+    if (lane < CG_LOG_RING) ringw = ((const uint32_t*)(P.b.ring + (size_t)env * CG_LOG_RING * 2))[lane];
   }
+  // ---- workgroup-shared topology blob -> LDS (16-byte copies) ----
+  copy16((uint4*)smem, (const uint4*)P.t.blob, P.t.lds_bytes >> 4, threadIdx.x, WPB * WAVE);
+  if (live) {
+    if (vec) {
+      if (lane < items) ((uint4*)e.flags)[lane] = r0;
+      for (int i = lane + WAVE; i < items; i += WAVE) ((uint4*)e.flags)[i] = ((const uint4*)g_live)[i];
+    } else {
+      for (int i = lane; i < 4 * M; i += WAVE) e.flags[i] = g_live[i];
+    }
+    if (lane < CG_LOG_RING) ((uint32_t*)e.ring)[lane] = ringw;
+    const uint32_t* gb = P.b.blocked + (size_t)env * P.t.EW;
+    for (int w = lane; w < P.t.EW; w += WAVE) e.blk[w] = gb[w];
+    const int16_t* gd = P.a.dev_idx + (size_t)env * L;
+    for (int p = lane; p < L; p += WAVE) e.devl[p] = gd[p];
+  }
+  __syncthreads();   // the only workgroup barrier: waves diverge per env from here on
+  if (!live) return;
+  STAMP(1);
+
   e.tick = (uint32_t)ie[CG_I_RNG_TICK];
   e.eflags = ie[CG_I_FLAGS];
   e.log_total = ie[CG_I_LOG_TOTAL];
-
-  // ---- stage the live planes ----
-  const size_t so = (size_t)env * M;
-  plane_load(e.flags, P.b.flags + so, M, lane);
-  plane_load(e.busy, P.b.busy + so, M, lane);
-  plane_load(e.wl, P.b.wl + so, M, lane);
-  plane_load(e.cby, P.b.comp_by + so, M, lane);
-  wsync();
-
-  const int G = P.a.max_groups, L = P.a.max_devs;
-  const int mode = P.a.mode[env];
-  const int ng = P.a.n_groups[env];
-  const int16_t* devs = P.a.dev_idx + (size_t)env * L;
+  const int16_t* devs = e.devl;
   double cost = 0.0;
   bool dirty = false;
   int last_atype = -1;
 
   if (ng == 0) {   // ---- step(action) volt_typhoon_env.py:818-1333 ----
-    int at = P.a.atype[(size_t)env * G];
-    int Ld = P.a.dev_cnt[(size_t)env * G];
+    int at = at0;
+    int Ld = cnt0;
     if (Ld > L) Ld = L;
     if (Ld < 0) Ld = 0;
     if (mode == CG_MODE_DEFENDER) { if (!(at >= 0 && at < P.c.n_def_actions)) at = 8; }
@@ -993,7 +996,7 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
       if (P.c.baseline != 0) at = 8;   // :913-914
       def_global(e, P, at, devs, Ld, cost, dirty, false, ie, fe);
       if (at == 1 || at == 4 || at == 5 || at == 6 || at == 7 || at == 9 || at == 12 || at == 13)
-        if (Ld > 0) def_per_device(e, P, at, devs, Ld, P.a.app[(size_t)env * G], cost, dirty, ie, fe);
+        if (Ld > 0) def_per_device(e, P, at, devs, Ld, app0, cost, dirty, ie, fe);
     } else if (P.c.baseline != 3 && (at == 1 || at == 2)) {
       for (int c = 0; c < MC; ++c) {   // :1127 snapshot of the sources
         int d = c * WAVE + lane;
@@ -1001,9 +1004,8 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
         if (lane == 0) srcb[c] = m;
       }
       wsync();
-      ensure_blocked(e, P);
-      if (at == 1) {
-        int ne = P.a.n_exploit[(size_t)env * G];
+        if (at == 1) {
+        int ne = nexp0;
         if (ne > CG_MAX_EXPLOITS) ne = CG_MAX_EXPLOITS;
         attacker_spread(e, P, P.a.exploit + (size_t)env * G * CG_MAX_EXPLOITS, ne, srcb, ie);
       } else {
@@ -1035,6 +1037,7 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
     wsync();
   }
 
+  STAMP(2);
   // ---- workload advance (:1242-1261 / :705-725) ----
   int current_work = 0;
   for (int c = 0; c < MC; ++c) {
@@ -1053,6 +1056,7 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
   wsync();
   arrivals(e, P, ie[CG_I_STEP_NUM]);
 
+  STAMP(3);
   // ---- counts + rewards (:1267-1304 / :732-748) ----
   int n_comp = 0, n_comp_dc = 0;
   for (int c = 0; c < MC; ++c) {
@@ -1086,6 +1090,7 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
     }
   }
 
+  STAMP(4);
   // ---- observation (_get_state CyberDefenseEnv.py:146-191), before evolve; 16-B coalesced stores ----
   {
     float* out = P.o.obs + (size_t)env * M * 6;
@@ -1119,6 +1124,7 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
     }
   }
 
+  STAMP(5);
   ie[CG_I_STEP_NUM] += 1;
   if (mode == CG_MODE_ATTACKER) ie[CG_I_ATT_STEP] += 1; else ie[CG_I_DEF_STEP] += 1;
   const bool done = ie[CG_I_STEP_NUM] > P.c.episode_limit;
@@ -1141,17 +1147,13 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
     P.o.done[env] = done ? 1 : 0;
   }
 
-  if (done && P.c.auto_reset && P.snap.flags) {   // reload the initial snapshot; RNG tick stays monotone
+  if (done && P.c.auto_reset && P.snap.live) {   // reload the initial snapshot; RNG tick stays monotone
     const int si = P.snap.n_envs == 1 ? 0 : env;
-    const size_t ss = (size_t)si * M;
-    plane_store(P.b.flags + so, P.snap.flags + ss, M, lane);
-    plane_store(P.b.busy + so, P.snap.busy + ss, M, lane);
-    plane_store(P.b.wl + so, P.snap.wl + ss, M, lane);
-    plane_store(P.b.comp_by + so, P.snap.comp_by + ss, M, lane);
-    plane_store(P.b.st_flags + so, P.snap.st_flags + ss, M, lane);
-    plane_store(P.b.st_busy + so, P.snap.st_busy + ss, M, lane);
-    plane_store(P.b.st_wl + so, P.snap.st_wl + ss, M, lane);
-    plane_store(P.b.st_comp_by + so, P.snap.st_comp_by + ss, M, lane);
+    const size_t ss = (size_t)si * 4 * M;
+    for (int i = lane; i < 4 * M; i += WAVE) {
+      P.b.live[so + i] = P.snap.live[ss + i];
+      P.b.stash[so + i] = P.snap.stash[ss + i];
+    }
     for (int w = lane; w < P.t.EW; w += WAVE) P.b.blocked[(size_t)env * P.t.EW + w] = P.snap.blocked[(size_t)si * P.t.EW + w];
     if (lane < CG_LOG_RING)
       ((uint32_t*)(P.b.ring + (size_t)env * CG_LOG_RING * 2))[lane] = ((const uint32_t*)(P.snap.ring + (size_t)si * CG_LOG_RING * 2))[lane];
@@ -1164,11 +1166,13 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
     return;
   }
 
-  // ---- write back ----
-  plane_store(P.b.flags + so, e.flags, M, lane);
-  plane_store(P.b.busy + so, e.busy, M, lane);
-  plane_store(P.b.wl + so, e.wl, M, lane);
-  if (e.cby_dirty) plane_store(P.b.comp_by + so, e.cby, M, lane);
+  STAMP(6);
+  // ---- write back: the whole [4][M] live block with 16-byte stores ----
+  if (vec) {
+    for (int i = lane; i < items; i += WAVE) ((uint4*)(P.b.live + so))[i] = ((const uint4*)e.flags)[i];
+  } else {
+    for (int i = lane; i < 4 * M; i += WAVE) P.b.live[so + i] = e.flags[i];
+  }
   if (e.blk_dirty) for (int w = lane; w < P.t.EW; w += WAVE) P.b.blocked[(size_t)env * P.t.EW + w] = e.blk[w];
   if (e.ring_dirty && lane < CG_LOG_RING)
     ((uint32_t*)(P.b.ring + (size_t)env * CG_LOG_RING * 2))[lane] = ((const uint32_t*)e.ring)[lane];
@@ -1180,6 +1184,10 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
 #pragma unroll
     for (int i = 0; i < CG_D_COUNT; ++i) gf[i] = fe[i];
   }
+  STAMP(7);
+#ifdef CG_STAMPS
+  if (P.dbg && lane == 0) { P.dbg[(size_t)env * 16 + 8] = (unsigned long long)last_atype; P.dbg[(size_t)env * 16 + 9] = (unsigned long long)mode; }
+#endif
 }
 
 // ---------------- reset / randomize / observe / action script ----------------
@@ -1190,16 +1198,12 @@ __global__ void reset_kernel(KParams P, const int32_t* env_ids, int n) {
   if (env < 0 || env >= P.n_envs) return;
   const int M = P.t.M;
   const int si = P.snap.n_envs == 1 ? 0 : env;
-  const size_t so = (size_t)env * M, ss = (size_t)si * M;
+  const size_t so = (size_t)env * 4 * M, ss = (size_t)si * 4 * M;
   int32_t tick = P.b.ienv[(size_t)env * CG_I_COUNT + CG_I_RNG_TICK];
-  plane_store(P.b.flags + so, P.snap.flags + ss, M, lane);
-  plane_store(P.b.busy + so, P.snap.busy + ss, M, lane);
-  plane_store(P.b.wl + so, P.snap.wl + ss, M, lane);
-  plane_store(P.b.comp_by + so, P.snap.comp_by + ss, M, lane);
-  plane_store(P.b.st_flags + so, P.snap.st_flags + ss, M, lane);
-  plane_store(P.b.st_busy + so, P.snap.st_busy + ss, M, lane);
-  plane_store(P.b.st_wl + so, P.snap.st_wl + ss, M, lane);
-  plane_store(P.b.st_comp_by + so, P.snap.st_comp_by + ss, M, lane);
+  for (int i = lane; i < 4 * M; i += WAVE) {
+    P.b.live[so + i] = P.snap.live[ss + i];
+    P.b.stash[so + i] = P.snap.stash[ss + i];
+  }
   for (int w = lane; w < P.t.EW; w += WAVE) P.b.blocked[(size_t)env * P.t.EW + w] = P.snap.blocked[(size_t)si * P.t.EW + w];
   if (lane < CG_LOG_RING)
     ((uint32_t*)(P.b.ring + (size_t)env * CG_LOG_RING * 2))[lane] = ((const uint32_t*)(P.snap.ring + (size_t)si * CG_LOG_RING * 2))[lane];
@@ -1218,7 +1222,7 @@ __global__ void randomize_kernel(KParams P, const int32_t* env_ids, int n, uint3
   const int env = env_ids ? env_ids[wave] : wave;
   if (env < 0 || env >= P.n_envs) return;
   const int M = P.t.M, MC = P.t.MC;
-  uint8_t* flags = P.b.flags + (size_t)env * M;
+  uint8_t* flags = P.b.live + (size_t)env * 4 * M;
   int32_t* ie = P.b.ienv + (size_t)env * CG_I_COUNT;
   const uint32_t tick = (uint32_t)ie[CG_I_RNG_TICK];
   const uint32_t env_id = (uint32_t)(P.c.env_id_base + env);
@@ -1263,7 +1267,7 @@ __global__ void observe_kernel(KParams P, int role, float* out) {
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (wave >= P.n_envs) return;
   const int env = wave, M = P.t.M;
-  const uint8_t* flags = P.b.flags + (size_t)env * M;
+  const uint8_t* flags = P.b.live + (size_t)env * 4 * M;
   if (role == 0 || role == 1) {
     float* o = out + (size_t)env * 6 * M;
     for (int i = lane; i < 6 * M; i += WAVE) {
@@ -1342,9 +1346,10 @@ struct cygym_handle {
   bool bound, has_snap;
   void* dev_blob;       // one allocation holding the topology copies
   uint32_t* keybuf;     // randomize scratch [n_envs][Mp]
-  int wpb;
+  int wpb, max_devs;
   int wave_lds, shared_lds;
   hipEvent_t ev0, ev1;
+  unsigned long long* dbg;
   char err[256];
 };
 
@@ -1369,19 +1374,41 @@ const char* cygym_last_error(const cygym_handle* h) { return h ? h->err : g_err;
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-static int choose_launch(cygym_handle* h) {
-  const int M = h->t.M, Mp = h->t.Mp, E = h->t.E, EW = h->t.EW;
-  size_t shared = align_up((size_t)((M + 2) & ~1) * 2 + (size_t)E * 2, 16) + (size_t)Mp * 4 * 3 + (size_t)Mp * 2;
-  shared = align_up(shared, 16);
-  size_t wave = (size_t)Mp * 4 + (size_t)Mp * 8 + (size_t)((EW + 3) & ~3) * 4 + CG_LOG_RING * 4 +
-                (size_t)((Mp / 32 + 2) & ~1) * 4 + (size_t)h->t.MC * 8;
-  wave = align_up(wave, 16);
+// LDS budget: shared blob prefix + WPB per-wave regions.  Prefers staging the in-CSR too.
+static size_t wave_lds_bytes(const DevTopo& t, int max_devs) {
+  size_t w = align_up((size_t)4 * t.M, 16) + (size_t)t.Mp * 8 + (size_t)((t.EW + 3) & ~3) * 4 + CG_LOG_RING * 4 +
+             (size_t)((t.Mp / 32 + 2) & ~1) * 4 + (size_t)t.MC * 8 + align_up((size_t)max_devs * 2, 16);
+  return align_up(w, 16);
+}
+static int choose_launch(cygym_handle* h, int max_devs) {
+  DevTopo& t = h->t;
   const size_t lds_cap = 160 * 1024;
-  int wpb = 8;
-  while (wpb > 1 && shared + wave * wpb > lds_cap) wpb >>= 1;
-  if (shared + wave * wpb > lds_cap) return -1;
-  h->wpb = wpb; h->wave_lds = (int)wave; h->shared_lds = (int)shared;
-  return 0;
+  const size_t wave = wave_lds_bytes(t, max_devs);
+  for (int pass = 0; pass < 2; ++pass) {
+    const size_t shared = pass == 0 ? (size_t)t.blob_bytes : (size_t)t.o_iptr;
+    for (int wpb = 16; wpb >= 1; wpb >>= 1) {
+      // keep >= 2 workgroups per CU where that is possible without dropping below 4 waves
+      if (shared + wave * wpb <= lds_cap && (wpb <= 4 || 2 * (shared + wave * wpb) <= lds_cap || wpb == 16)) {
+        if (wpb == 16 && 2 * (shared + wave * wpb) > lds_cap) continue;
+        h->wpb = wpb; h->wave_lds = (int)wave; h->shared_lds = (int)shared;
+        t.lds_bytes = (int)shared; t.in_lds = pass == 0;
+        h->max_devs = max_devs;
+        return 0;
+      }
+    }
+  }
+  return -1;
+}
+
+static hipError_t set_lds_attr(cygym_handle* h) {
+  const int lds = h->shared_lds + h->wave_lds * h->wpb;
+  switch (h->wpb) {
+    case 16: return hipFuncSetAttribute((const void*)step_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    case 8: return hipFuncSetAttribute((const void*)step_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    case 4: return hipFuncSetAttribute((const void*)step_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    case 2: return hipFuncSetAttribute((const void*)step_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    default: return hipFuncSetAttribute((const void*)step_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  }
 }
 
 int cygym_create(const cygym_topology* topo, const cygym_config* cfg, int32_t n_envs, int32_t device_id,
@@ -1415,24 +1442,25 @@ int cygym_create(const cygym_topology* topo, const cygym_config* cfg, int32_t n_
   DevTopo& t = h->t;
   t.M = M; t.X = X; t.E = E; t.EW = (E + 31) / 32 > 0 ? (E + 31) / 32 : 1;
   t.MC = (M + WAVE - 1) / WAVE; t.Mp = t.MC * WAVE;
-  if (choose_launch(h) != 0) { delete h; return fail(nullptr, CYGYM_EUNSUPPORTED, "topology does not fit in LDS%s", ""); }
-  // one blob: u8 x3 [M], f32 x3 [M], u16 out_ptr[M+1], out_col[E], in_ptr[M+1], in_col[E], in_eid[E]
+  // one blob, laid out exactly as the LDS-shared section (see DevTopo)
   size_t off = 0;
-  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 16); return o; };
-  size_t o_dst = take(M), o_vul = take(M), o_nap = take(M);
-  size_t o_os = take((size_t)M * 4), o_ver = take((size_t)M * 4), o_ano = take((size_t)M * 4);
-  size_t o_op = take((size_t)(M + 1) * 2), o_oc = take((size_t)(E > 0 ? E : 1) * 2);
-  size_t o_ip = take((size_t)(M + 1) * 2), o_ic = take((size_t)(E > 0 ? E : 1) * 2), o_ie = take((size_t)(E > 0 ? E : 1) * 2);
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 16); return (int)o; };
+  t.o_optr = take((size_t)(M + 1) * 2); t.o_ocol = take((size_t)(E > 0 ? E : 1) * 2);
+  t.o_os = take((size_t)M * 4); t.o_ver = take((size_t)M * 4); t.o_ano = take((size_t)M * 4);
+  t.o_dst = take(M); t.o_vul = take(M); t.o_nap = take(M);
+  t.o_iptr = take((size_t)(M + 1) * 2); t.o_icol = take((size_t)(E > 0 ? E : 1) * 2); t.o_ieid = take((size_t)(E > 0 ? E : 1) * 2);
+  t.blob_bytes = (int)off;
+  if (choose_launch(h, M > 8 ? M / 8 : 1) != 0) { delete h; return fail(nullptr, CYGYM_EUNSUPPORTED, "topology does not fit in LDS%s", ""); }
   uint8_t* host = (uint8_t*)calloc(1, off);
   if (!host) { delete h; return fail(nullptr, CYGYM_EINVAL, "out of host memory%s", ""); }
-  memcpy(host + o_dst, topo->dstatic, M); memcpy(host + o_vul, topo->vuln, M); memcpy(host + o_nap, topo->napps, M);
-  memcpy(host + o_os, topo->os_val, (size_t)M * 4); memcpy(host + o_ver, topo->version, (size_t)M * 4);
-  memcpy(host + o_ano, topo->anomaly, (size_t)M * 4);
-  for (int i = 0; i <= M; ++i) { ((uint16_t*)(host + o_op))[i] = (uint16_t)topo->out_ptr[i]; ((uint16_t*)(host + o_ip))[i] = (uint16_t)topo->in_ptr[i]; }
+  memcpy(host + t.o_dst, topo->dstatic, M); memcpy(host + t.o_vul, topo->vuln, M); memcpy(host + t.o_nap, topo->napps, M);
+  memcpy(host + t.o_os, topo->os_val, (size_t)M * 4); memcpy(host + t.o_ver, topo->version, (size_t)M * 4);
+  memcpy(host + t.o_ano, topo->anomaly, (size_t)M * 4);
+  for (int i = 0; i <= M; ++i) { ((uint16_t*)(host + t.o_optr))[i] = (uint16_t)topo->out_ptr[i]; ((uint16_t*)(host + t.o_iptr))[i] = (uint16_t)topo->in_ptr[i]; }
   for (int k = 0; k < E; ++k) {
-    ((uint16_t*)(host + o_oc))[k] = (uint16_t)topo->out_col[k];
-    ((uint16_t*)(host + o_ic))[k] = (uint16_t)topo->in_col[k];
-    ((uint16_t*)(host + o_ie))[k] = (uint16_t)topo->in_eid[k];
+    ((uint16_t*)(host + t.o_ocol))[k] = (uint16_t)topo->out_col[k];
+    ((uint16_t*)(host + t.o_icol))[k] = (uint16_t)topo->in_col[k];
+    ((uint16_t*)(host + t.o_ieid))[k] = (uint16_t)topo->in_eid[k];
   }
   hipError_t e1 = hipMalloc(&h->dev_blob, off);
   if (e1 == hipSuccess) e1 = hipMemcpy(h->dev_blob, host, off, hipMemcpyHostToDevice);
@@ -1442,17 +1470,13 @@ int cygym_create(const cygym_topology* topo, const cygym_config* cfg, int32_t n_
   if (e1 == hipSuccess) e1 = hipEventCreate(&h->ev1);
   if (e1 != hipSuccess) { fail(nullptr, CYGYM_EHIP, "cygym_create: %s", hipGetErrorString(e1)); cygym_destroy(h); return CYGYM_EHIP; }
   uint8_t* d = (uint8_t*)h->dev_blob;
-  t.dstatic = d + o_dst; t.vuln = d + o_vul; t.napps = d + o_nap;
-  t.os_val = (const float*)(d + o_os); t.version = (const float*)(d + o_ver); t.anomaly = (const float*)(d + o_ano);
-  t.out_ptr = (const uint16_t*)(d + o_op); t.out_col = (const uint16_t*)(d + o_oc);
-  t.in_ptr = (const uint16_t*)(d + o_ip); t.in_col = (const uint16_t*)(d + o_ic); t.in_eid = (const uint16_t*)(d + o_ie);
+  t.blob = d;
+  t.dstatic = d + t.o_dst; t.vuln = d + t.o_vul; t.napps = d + t.o_nap;
+  t.os_val = (const float*)(d + t.o_os); t.version = (const float*)(d + t.o_ver); t.anomaly = (const float*)(d + t.o_ano);
+  t.out_ptr = (const uint16_t*)(d + t.o_optr); t.out_col = (const uint16_t*)(d + t.o_ocol);
+  t.in_ptr = (const uint16_t*)(d + t.o_iptr); t.in_col = (const uint16_t*)(d + t.o_icol); t.in_eid = (const uint16_t*)(d + t.o_ieid);
   // opt in to large dynamic LDS for every instantiation we may launch
-  const int lds = h->shared_lds + h->wave_lds * h->wpb;
-  hipError_t e2 = hipSuccess;
-  if (h->wpb == 8) e2 = hipFuncSetAttribute((const void*)step_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  else if (h->wpb == 4) e2 = hipFuncSetAttribute((const void*)step_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  else if (h->wpb == 2) e2 = hipFuncSetAttribute((const void*)step_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  else e2 = hipFuncSetAttribute((const void*)step_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipError_t e2 = set_lds_attr(h);
   if (e2 != hipSuccess) { fail(nullptr, CYGYM_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString(e2)); cygym_destroy(h); return CYGYM_EHIP; }
   *out = h;
   return CYGYM_OK;
@@ -1475,8 +1499,7 @@ int cygym_set_config(cygym_handle* h, const cygym_config* cfg) {
 }
 
 static int check_buffers(cygym_handle* h, const cygym_buffers* b, bool snapshot) {
-  if (!b || !b->flags || !b->busy || !b->wl || !b->comp_by || !b->st_flags || !b->st_busy || !b->st_wl ||
-      !b->st_comp_by || !b->blocked || !b->ring || !b->ienv || !b->fenv)
+  if (!b || !b->live || !b->stash || !b->blocked || !b->ring || !b->ienv || !b->fenv)
     return fail(h, CYGYM_EINVAL, "buffer struct has a null plane%s", "");
   if (snapshot ? (b->n_envs != 1 && b->n_envs != h->n_envs) : (b->n_envs != h->n_envs))
     return fail(h, CYGYM_EINVAL, "buffer struct has the wrong leading dimension%s", "");
@@ -1497,6 +1520,7 @@ static KParams make_params(cygym_handle* h) {
   memset(&P, 0, sizeof(P));
   P.t = h->t; P.c = h->c; P.b = h->b; P.n_envs = h->n_envs;
   P.wave_lds = h->wave_lds; P.shared_lds = h->shared_lds;
+  P.dbg = h->dbg;
   return P;
 }
 
@@ -1550,6 +1574,11 @@ int cygym_step(cygym_handle* h, const cygym_actions* a, const cygym_outputs* o, 
       !a->dev_cnt || !a->dev_idx || !o->obs || !o->raw || !o->shaped || !o->done)
     return fail(h, CYGYM_EINVAL, "cygym_step: null action / output pointer%s", "");
   if (a->max_groups < 1 || a->max_devs < 1) return fail(h, CYGYM_EINVAL, "cygym_step: max_groups / max_devs must be >= 1%s", "");
+  if (a->max_devs > 32767) return fail(h, CYGYM_EINVAL, "cygym_step: max_devs too large%s", "");
+  if (a->max_devs > h->max_devs) {   // the device list lives in LDS: re-plan the launch for a longer list
+    if (choose_launch(h, a->max_devs) != 0) return fail(h, CYGYM_EUNSUPPORTED, "device list does not fit in LDS%s", "");
+    HIPCHK(h, set_lds_attr(h));
+  }
   if (h->c.auto_reset && !h->has_snap) return fail(h, CYGYM_EINVAL, "auto_reset needs cygym_set_snapshot first%s", "");
   HIPCHK(h, hipSetDevice(h->device_id));
   KParams P = make_params(h);
@@ -1559,6 +1588,7 @@ int cygym_step(cygym_handle* h, const cygym_actions* a, const cygym_outputs* o, 
   const dim3 grid((h->n_envs + h->wpb - 1) / h->wpb), block(h->wpb * WAVE);
   hipStream_t s = (hipStream_t)stream;
   switch (h->wpb) {
+    case 16: hipLaunchKernelGGL(step_kernel<16>, grid, block, lds, s, P); break;
     case 8: hipLaunchKernelGGL(step_kernel<8>, grid, block, lds, s, P); break;
     case 4: hipLaunchKernelGGL(step_kernel<4>, grid, block, lds, s, P); break;
     case 2: hipLaunchKernelGGL(step_kernel<2>, grid, block, lds, s, P); break;
@@ -1591,6 +1621,13 @@ int cygym_gen_actions(cygym_handle* h, int32_t tick, int32_t* mode, int32_t* n_g
   hipLaunchKernelGGL(gen_actions_kernel, dim3((h->n_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, tick,
                      mode, n_groups, atype, n_exploit, exploit, app, dev_cnt, dev_idx, max_devs);
   HIPCHK(h, hipGetLastError());
+  return CYGYM_OK;
+}
+
+/* diagnostic builds only (-DCG_STAMPS): per-env phase stamps, [N][16] uint64 device buffer (NULL to disable) */
+int cygym_set_debug(cygym_handle* h, void* buf) {
+  if (!h) return fail(h, CYGYM_EINVAL, "null handle%s", "");
+  h->dbg = (unsigned long long*)buf;
   return CYGYM_OK;
 }
 

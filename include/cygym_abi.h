@@ -91,16 +91,23 @@ typedef struct cygym_config {
   uint64_t tri_thr[CG_TRI_TABLE];         /* ceil(triangular(0,2,5)) CDSimulator.py:308 */
 } cygym_config;
 
-/* Per-env mutable state, struct-of-arrays, DEVICE pointers (caller-owned). */
+/* Per-env mutable state, struct-of-arrays, DEVICE pointers (caller-owned).
+ * The four live byte planes of one env are contiguous ([N][4][M]) so that a wave
+ * stages a whole env with 16-byte-per-lane loads; plane order:
+ *   0 flags   CG_F_*                                   (CDSimulatorComponents.py:217-243)
+ *   1 busy    Device.busy_time (saturates at 255)
+ *   2 wl      Workload.processing_time, 0 = no workload (CDSimulatorComponents.py:18-26)
+ *   3 comp_by bitmask over exploit index               (Device.compromised_by)
+ * `stash` has the same shape: the per-device in-memory checkpoint of actions 11/12
+ * (volt_typhoon_env.py:419-453), plane 0 = CG_S_VALID | kept flag bits. */
+#define CG_P_FLAGS 0
+#define CG_P_BUSY 1
+#define CG_P_WL 2
+#define CG_P_COMPBY 3
+#define CG_PLANES 4
 typedef struct cygym_buffers {
-  uint8_t*  flags;      /* [N][M] CG_F_*                                        */
-  uint8_t*  busy;       /* [N][M] Device.busy_time (saturates at 255)           */
-  uint8_t*  wl;         /* [N][M] Workload.processing_time, 0 = no workload     */
-  uint8_t*  comp_by;    /* [N][M] bitmask over exploit index                    */
-  uint8_t*  st_flags;   /* [N][M] stash (actions 11/12) volt_typhoon_env.py:419 */
-  uint8_t*  st_busy;    /* [N][M]                                               */
-  uint8_t*  st_wl;      /* [N][M]                                               */
-  uint8_t*  st_comp_by; /* [N][M]                                               */
+  uint8_t*  live;       /* [N][4][M]                                            */
+  uint8_t*  stash;      /* [N][4][M]                                            */
   uint32_t* blocked;    /* [N][EW] bit per out-CSR slot, EW = ceil(E/32)        */
   uint16_t* ring;       /* [N][CG_LOG_RING][2] last comm-log (from,to) pairs    */
   int32_t*  ienv;       /* [N][CG_I_COUNT]                                      */

@@ -619,10 +619,10 @@ static void step_one(env_t* e, const cygym_actions* a, const cygym_outputs* o, i
 
 static void bind_env(env_t* e, const cygym_topology* t, const cygym_config* c, const cygym_buffers* b, int idx) {
   e->t = t; e->c = c;
-  e->M = t->n_devices; e->X = t->n_exploits; e->E = t->n_edges; e->EW = (t->n_edges + 31) / 32;
-  size_t o = (size_t)idx * e->M;
-  e->flags = b->flags + o; e->busy = b->busy + o; e->wl = b->wl + o; e->comp_by = b->comp_by + o;
-  e->st_flags = b->st_flags + o; e->st_busy = b->st_busy + o; e->st_wl = b->st_wl + o; e->st_comp_by = b->st_comp_by + o;
+  e->M = t->n_devices; e->X = t->n_exploits; e->E = t->n_edges; e->EW = (t->n_edges + 31) / 32 > 0 ? (t->n_edges + 31) / 32 : 1;
+  size_t o = (size_t)idx * e->M * CG_PLANES;
+  e->flags = b->live + o; e->busy = e->flags + e->M; e->wl = e->busy + e->M; e->comp_by = e->wl + e->M;
+  e->st_flags = b->stash + o; e->st_busy = e->st_flags + e->M; e->st_wl = e->st_busy + e->M; e->st_comp_by = e->st_wl + e->M;
   e->blocked = b->blocked + (size_t)idx * e->EW;
   e->ring = b->ring + (size_t)idx * CG_LOG_RING * 2;
   e->ienv = b->ienv + (size_t)idx * CG_I_COUNT;
@@ -632,12 +632,10 @@ static void bind_env(env_t* e, const cygym_topology* t, const cygym_config* c, c
 
 static void snapshot_restore(env_t* e, const cygym_buffers* s, int idx) {
   int si = s->n_envs == 1 ? 0 : idx;
-  size_t o = (size_t)si * e->M;
+  size_t o = (size_t)si * e->M * CG_PLANES;
   int32_t tick = e->ienv[CG_I_RNG_TICK];
-  memcpy(e->flags, s->flags + o, e->M); memcpy(e->busy, s->busy + o, e->M);
-  memcpy(e->wl, s->wl + o, e->M); memcpy(e->comp_by, s->comp_by + o, e->M);
-  memcpy(e->st_flags, s->st_flags + o, e->M); memcpy(e->st_busy, s->st_busy + o, e->M);
-  memcpy(e->st_wl, s->st_wl + o, e->M); memcpy(e->st_comp_by, s->st_comp_by + o, e->M);
+  memcpy(e->flags, s->live + o, (size_t)e->M * CG_PLANES);
+  memcpy(e->st_flags, s->stash + o, (size_t)e->M * CG_PLANES);
   memcpy(e->blocked, s->blocked + (size_t)si * e->EW, (size_t)e->EW * 4);
   memcpy(e->ring, s->ring + (size_t)si * CG_LOG_RING * 2, CG_LOG_RING * 2 * 2);
   memcpy(e->ienv, s->ienv + (size_t)si * CG_I_COUNT, CG_I_COUNT * 4);

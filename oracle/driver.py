@@ -50,28 +50,42 @@ def lib():
     return _lib
 
 
-STATE_SHAPES = {
-    "flags": ("M", np.uint8), "busy": ("M", np.uint8), "wl": ("M", np.uint8), "comp_by": ("M", np.uint8),
-    "st_flags": ("M", np.uint8), "st_busy": ("M", np.uint8), "st_wl": ("M", np.uint8), "st_comp_by": ("M", np.uint8),
-    "blocked": ("EW", np.uint32), "ring": ("R", np.uint16), "ienv": ("I", np.int32), "fenv": ("D", np.float64),
-}
+OTHER_SHAPES = {"blocked": ("EW", np.uint32), "ring": ("R", np.uint16), "ienv": ("I", np.int32), "fenv": ("D", np.float64)}
+STATE_KEYS = abi.STATE_PLANES + tuple(OTHER_SHAPES)
 
 
 def alloc_state(n, M, EW):
-    dims = {"M": (M,), "EW": (EW,), "R": (S.LOG_RING, 2), "I": (S.I_COUNT,), "D": (S.D_COUNT,)}
-    st = {k: np.zeros((n,) + dims[d], dt) for k, (d, dt) in STATE_SHAPES.items()}
+    """Struct-of-arrays state.  `live` / `stash` are the [N][4][M] buffers of the ABI; the
+    per-plane entries (flags, busy, ..., st_comp_by) are numpy VIEWS into them."""
+    dims = {"EW": (EW,), "R": (S.LOG_RING, 2), "I": (S.I_COUNT,), "D": (S.D_COUNT,)}
+    st = {"live": np.zeros((n, 4, M), np.uint8), "stash": np.zeros((n, 4, M), np.uint8)}
+    for i, k in enumerate(abi.LIVE_PLANES):
+        st[k] = st["live"][:, i]
+    for i, k in enumerate(abi.STASH_PLANES):
+        st[k] = st["stash"][:, i]
+    for k, (d, dt) in OTHER_SHAPES.items():
+        st[k] = np.zeros((n,) + dims[d], dt)
     st["ring"][:] = 0xFFFF
     return st
 
 
 def state_struct(st) -> abi.Buffers:
     b = abi.Buffers()
-    for k in STATE_SHAPES:
+    for k in abi.BUFFER_FIELDS:
         a = st[k]
-        assert a.flags["C_CONTIGUOUS"] and a.dtype == STATE_SHAPES[k][1], k
+        assert a.flags["C_CONTIGUOUS"], k
         setattr(b, k, a.ctypes.data)
-    b.n_envs = st["flags"].shape[0]
+    b.n_envs = st["live"].shape[0]
     return b
+
+
+def copy_state(st):
+    out = {k: st[k].copy() for k in abi.BUFFER_FIELDS}
+    for i, k in enumerate(abi.LIVE_PLANES):
+        out[k] = out["live"][:, i]
+    for i, k in enumerate(abi.STASH_PLANES):
+        out[k] = out["stash"][:, i]
+    return out
 
 
 def alloc_actions(n, G, L):
@@ -110,14 +124,15 @@ class OracleBatch:
 
     def load_state(self, init: dict, broadcast=True):
         """init: dict of arrays with leading dim 1 or N (planes may be wider ints)."""
-        for k, (_, dt) in STATE_SHAPES.items():
+        for k in STATE_KEYS:
             src = np.asarray(init[k])
-            if k == "blocked" and src.shape[-1] != self.topo.EW:
+            dt = self.state[k].dtype
+            if k == "blocked" and (src.shape[-1] != self.topo.EW or src.dtype not in (np.uint32, np.int32)):
                 src = abi.pack_blocked(src, self.topo.EW)
             if k == "ring":
-                src = np.where(src < 0, 0xFFFF, src)
+                src = np.where(src.astype(np.int64) < 0, 0xFFFF, src)
             self.state[k][...] = src.astype(dt) if src.shape[0] == self.N else np.broadcast_to(src.astype(dt), self.state[k].shape)
-        self.snapshot = {k: v.copy() for k, v in self.state.items()}
+        self.snapshot = copy_state(self.state)
 
     def step(self, act: dict, begin=0, end=None):
         c = self.cfg.to_c()

@@ -1,0 +1,39 @@
+"""Diagnostic: per-phase cycle shares of the tick kernel (build with -DCG_STAMPS).
+Usage on the GPU box: python tools_stamps.py [envs] [M]"""
+import ctypes as C, os, subprocess, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.abspath(__file__)); sys.path.insert(0, ROOT)
+from cygym_amd import abi, build as B
+so = os.path.join(ROOT, "cygym_amd", "libcygym_hip_stamps.so")
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DCG_STAMPS",
+                       "-I" + B.INC, "-o", so, B.SRC])
+from cygym_amd import _lib
+_lib.SO = so
+from cygym_amd.batched_env import BatchedCyberDefenseEnv
+from cygym_amd.topology import make_topology
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+M = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+topo, init, ck = make_topology(M, 1 if M <= 256 else 32, seed=0)
+cfg = abi.EnvConfig(seed=0, auto_reset=1, lambda_events=0.0, **ck)
+env = BatchedCyberDefenseEnv(topo, cfg, N, init, device="cuda:0", max_groups=1, max_devs=max(1, M // 8))
+env.lib.cygym_set_debug.argtypes = [C.c_void_p, C.c_void_p]
+dbg = torch.zeros((N, 16), dtype=torch.int64, device="cuda:0")
+env.lib.cygym_set_debug(env._h, C.c_void_p(dbg.data_ptr()))
+names = ["stage", "action", "work+arrivals", "counts", "obs", "evolve+busyc", "writeback"]
+for t in range(40):
+    env.gen_actions(t)
+    env.step()
+    if t < 30:
+        continue
+    torch.cuda.synchronize()
+    d = dbg.cpu().numpy()
+    st = d[:, :8]
+    seg = np.diff(st, axis=1)
+    tot = st[:, 7] - st[:, 0]
+    at = d[:, 8]
+    print(f"tick {t} mode {int(d[0, 9])}: wave lifetime cycles mean {tot.mean():.0f} p50 {np.median(tot):.0f} p99 {np.percentile(tot, 99):.0f} max {tot.max()}  "
+          f"span(first start..last end) {st[:, 7].max() - st[:, 0].min()}")
+    print("   mean per phase:", {n: int(seg[:, i].mean()) for i, n in enumerate(names)})
+    for a in sorted(set(at.tolist())):
+        m = at == a
+        print(f"   atype {int(a):3d}: n={int(m.sum()):5d} total mean {tot[m].mean():8.0f} max {tot[m].max():8d}  action-phase mean {seg[m, 1].mean():8.0f} max {seg[m, 1].max():8d}")
