@@ -45,7 +45,7 @@ struct DevTopo {
   int M, X, E, EW, MC, Mp;
   const uint8_t* blob;
   int o_optr, o_ocol, o_os, o_ver, o_ano, o_dst, o_vul, o_nap, o_iptr, o_icol, o_ieid;
-  int blob_bytes, lds_bytes, in_lds;
+  int blob_bytes, lds_bytes, in_lds, multi;
   // global views (host-side convenience; kernels outside the tick use them)
   const uint8_t *dstatic, *vuln, *napps;
   const float *os_val, *version, *anomaly;
@@ -83,14 +83,20 @@ __device__ __forceinline__ int below(uint64_t m) {  // set bits of m below this 
   return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
 __device__ __forceinline__ int wave_or(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o);
+  return v;
+}
+// sum of a small per-lane count (< 2^bits) with `bits` ballots (SALU popcounts; no LDS permutes)
+__device__ __forceinline__ int wave_sum_bits(int v, int bits) {
+  int t = 0;
+  for (int b = 0; b < bits; ++b) t += __popcll(ballot((v >> b) & 1)) << b;
+  return t;
+}
+__device__ __forceinline__ int wave_sum(int v) {   // general (permute-based); rare paths only
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
@@ -105,15 +111,27 @@ __device__ __forceinline__ int nth_bit(uint64_t m, int r) {  // position of the 
   for (int i = 0; i < r; ++i) m &= m - 1;
   return __builtin_ctzll(m);
 }
+__device__ __forceinline__ int nth_bit32(uint32_t m, int r) {
+  for (int i = 0; i < r; ++i) m &= m - 1;
+  return __builtin_ctz(m);
+}
+
+// ---- SWAR on 4 device bytes per 32-bit word ----
+#define ONES 0x01010101u
+__device__ __forceinline__ uint32_t nz01(uint32_t b) {   // 0x01 in every byte of b that is non-zero
+  return ((b | ((b & 0x7f7f7f7fu) + 0x7f7f7f7fu)) >> 7) & ONES;
+}
 
 // ---------------- per-wave environment view ----------------
 struct Env {
-  // LDS
-  uint8_t *flags, *busy, *wl, *cby;   // contiguous [4][M]
+  // LDS, planes at stride MS = round_up(M, 4); padding bytes of `flags` hold CG_F_NYA
+  uint8_t *flags, *busy, *wl, *cby;
   uint32_t* scr;     // [2*Mp] scratch (8 bytes per device)
   uint32_t* blk;     // [EWp]
   uint16_t* ring;    // [2*CG_LOG_RING]
-  uint32_t* marks;   // [Mp/32 + 1]
+  uint32_t* marks;   // [Mp/32 + 2]
+  uint16_t* lsrc;    // [Mp] long-row sources of the spread
+  uint8_t* el;       // [Mp] spread eligibility bytes
   int16_t* devl;     // [L] this tick's device lists (all groups, concatenated)
   // shared LDS (topology)
   const uint16_t *optr, *ocol;
@@ -123,11 +141,13 @@ struct Env {
   const uint16_t *iptr, *icol, *ieid;
   uint8_t* stash;    // global [4][M] of this env
   // misc
-  int M, MC, lane, env;
+  int M, MC, MS, lane, env;
+  int cbits;         // bits needed for a per-lane device count
   uint32_t env_id, tick;
   uint64_t seed;
-  int eflags;        // CG_I_FLAGS (uniform)
-  bool blk_dirty, ring_dirty, cby_dirty;
+  int eflags;        // CG_I_FLAGS (uniform except BUSY_SAT, OR-reduced at write-back)
+  bool blk_dirty, ring_dirty;
+  bool multi;        // topology has duplicate (u,v) out-entries
   int log_total;
 
   __device__ __forceinline__ uint32_t draw(uint32_t site, uint32_t a, uint32_t b) const {
@@ -135,7 +155,7 @@ struct Env {
   }
   __device__ __forceinline__ bool blocked(int slot) const { return (blk[slot >> 5] >> (slot & 31)) & 1u; }
   __device__ __forceinline__ void set_busy(int d, int v) {
-    if (v > 255) { v = 255; eflags |= CG_E_BUSY_SAT; }   // per-lane; OR-reduced at write-back
+    if (v > 255) { v = 255; eflags |= CG_E_BUSY_SAT; }
     busy[d] = (uint8_t)v;
   }
 };
@@ -144,9 +164,35 @@ __device__ __forceinline__ void byte_or(uint8_t* base, int d, uint32_t bits) {
   atomicOr((unsigned int*)(base + (d & ~3)), bits << ((d & 3) * 8));
 }
 
+// number of set bits of blk in slot range [a, b)  (uniform; broadcast LDS reads)
+__device__ __forceinline__ int range_popc(const uint32_t* blk, int a, int b) {
+  if (a >= b) return 0;
+  const int w0 = a >> 5, w1 = (b - 1) >> 5;
+  int n = 0;
+  for (int w = w0; w <= w1; ++w) {
+    uint32_t x = blk[w];
+    if (w == w0) x &= 0xFFFFFFFFu << (a & 31);
+    if (w == w1 && ((b & 31) != 0)) x &= 0xFFFFFFFFu >> (32 - (b & 31));
+    n += __popc(x);
+  }
+  return n;
+}
+// slot of the r-th entry in [a, b) whose blocked bit == want (uniform); r must be in range
+__device__ __forceinline__ int range_select(const uint32_t* blk, int a, int b, bool want, int r) {
+  const int w0 = a >> 5, w1 = (b - 1) >> 5;
+  for (int w = w0; w <= w1; ++w) {
+    uint32_t x = want ? blk[w] : ~blk[w];
+    if (w == w0) x &= 0xFFFFFFFFu << (a & 31);
+    if (w == w1 && ((b & 31) != 0)) x &= 0xFFFFFFFFu >> (32 - (b & 31));
+    int c = __popc(x);
+    if (r < c) return (w << 5) + nth_bit32(x, r);
+    r -= c;
+  }
+  return -1;
+}
+
 // multiplicity of every device in a list -> bytes in scr (as uint8 [Mp]); ids >= M ignored.
-// returns (uniform) true when some device occurs more than 255 times (caller treats as unsupported)
-__device__ void list_counts(Env& e, const int16_t* dev, int L) {
+__device__ __forceinline__ void list_counts(Env& e, const int16_t* dev, int L) {
   uint32_t* w = e.scr;
   for (int i = e.lane; i < (e.MC * WAVE) / 4; i += WAVE) w[i] = 0;
   wsync();
@@ -157,9 +203,35 @@ __device__ void list_counts(Env& e, const int16_t* dev, int L) {
   wsync();
 }
 
+// true when the list fits one wave pass and holds no device twice (uniform)
+__device__ __forceinline__ bool list_is_simple(Env& e, const int16_t* dev, int L) {
+  if (L > WAVE) return false;
+  uint8_t* own = (uint8_t*)e.scr;
+  int d = -1;
+  if (e.lane < L) { d = dev[e.lane]; if (d < 0 || d >= e.M) d = -1; }
+  if (d >= 0) own[d] = (uint8_t)e.lane;
+  wsync();
+  bool clash = d >= 0 && own[d] != (uint8_t)e.lane;
+  bool r = !__any(clash);
+  wsync();
+  return r;
+}
+
+// busy += 1 on every busy device (actions 2 / 10), saturating at 255
+__device__ __forceinline__ void bump_busy(Env& e) {
+  uint32_t* B = (uint32_t*)e.busy;
+  for (int w = e.lane; w < (e.MS >> 2); w += WAVE) {
+    uint32_t b = B[w];
+    uint32_t full = ~nz01(~b) & ONES;          // bytes equal to 255
+    uint32_t inc = nz01(b) & ~full;
+    if (nz01(b) & full) e.eflags |= CG_E_BUSY_SAT;
+    B[w] = b + inc;
+  }
+}
+
 // ---------------- defender ----------------
-__device__ void def_global(Env& e, const KParams& P, int at, const int16_t* dev, int L, double& cost,
-                           bool& dirty, bool grouped, int32_t* ie, double* fe) {
+__device__ __forceinline__ void def_global(Env& e, const KParams& P, int at, const int16_t* dev, int L, double& cost,
+                                           bool& dirty, bool grouped, int32_t* ie, double* fe) {
   const double ds = P.c.def_scale;
   const int M = e.M;
   if (at == 2) {  // :918-926
@@ -167,7 +239,7 @@ __device__ void def_global(Env& e, const KParams& P, int at, const int16_t* dev,
     e.eflags |= CG_E_HAS_CKPT;
     cost += -0.5 * L * ds;
     fe[CG_D_DEF_COST] += 0.5 * L * ds;
-    for (int d = e.lane; d < M; d += WAVE) if (e.busy[d] > 0) e.set_busy(d, e.busy[d] + 1);
+    bump_busy(e);
   } else if (at == 3) {  // :928-943
     ie[CG_I_REVERT_CNT] += 1;
     if (e.eflags & CG_E_HAS_CKPT) {
@@ -185,7 +257,7 @@ __device__ void def_global(Env& e, const KParams& P, int at, const int16_t* dev,
         int d = dev[0];
         if (d >= 0 && d < M && e.lane == 0) e.set_busy(d, e.busy[d] + 1);
       } else {
-        for (int d = e.lane; d < M; d += WAVE) if (e.busy[d] > 0) e.set_busy(d, e.busy[d] + 1);
+        bump_busy(e);
       }
     }
     cost += -1.0 * ds;
@@ -203,134 +275,151 @@ __device__ void def_global(Env& e, const KParams& P, int at, const int16_t* dev,
     ie[CG_I_CKPT_CNT] += 1;
     cost += -0.1 * ds;
     fe[CG_D_DEF_COST] += 0.1 * ds;
+  } else {
+    return;
   }
   wsync();
 }
 
 // action 1 over one device list; `occ` (u8 [Mp], LDS) carries stall occurrence numbers across
 // the groups of one step_grouped tick (nullptr for single-action steps).
-__device__ void def_clean(Env& e, const KParams& P, const int16_t* dev, int L, double& cost, int32_t* ie,
-                          double* fe, uint8_t* occ) {
-  list_counts(e, dev, L);
-  const uint8_t* cnt = (const uint8_t*)e.scr;
-  int n_first_comp = 0, n_first_clean = 0, n_rest = 0;
-  int disc = 0;
-  for (int c = 0; c < e.MC; ++c) {
-    int d = c * WAVE + e.lane;
-    bool hit = false;
-    int k = 0;
-    uint8_t f = 0;
-    if (d < e.M) {
-      k = cnt[d];
-      f = e.flags[d];
-      hit = k > 0 && !(f & CG_F_NYA) && !(f & CG_F_OWNED);
-    }
+__device__ __forceinline__ void def_clean(Env& e, const KParams& P, const int16_t* dev, int L, double& cost,
+                                          int32_t* ie, double* fe, uint8_t* occ) {
+  const double ds = P.c.def_scale;
+  int a, b, disc;
+  if (list_is_simple(e, dev, L)) {   // list-major: one lane per list entry, one draw per lane
+    int d = -1;
+    if (e.lane < L) { d = dev[e.lane]; if (d < 0 || d >= e.M) d = -1; }
+    uint8_t f = d >= 0 ? e.flags[d] : (uint8_t)CG_F_NYA;
+    bool hit = !(f & CG_F_NYA) && !(f & CG_F_OWNED);
+    a = __popcll(ballot(hit && (f & CG_F_COMP)));
+    b = __popcll(ballot(hit && !(f & CG_F_COMP)));
+    int dl = 0;
     if (hit) {
-      if (f & CG_F_COMP) ++n_first_comp; else ++n_first_clean;
-      n_rest += k - 1;
-      disc |= e.cby[d];
+      dl = e.cby[d];
       e.cby[d] = 0;
       e.flags[d] = (uint8_t)(f & ~(CG_F_COMP | CG_F_WLADV));
-      int b0 = occ ? occ[d] : 0;
-      if (occ) occ[d] = (uint8_t)(b0 + k);
-      e.busy[d] = (uint8_t)cg_randint(e.draw(CG_SITE_STALL_CLEAN, d, b0 + k - 1), 0, P.c.default_high);
+      int b0 = 0;
+      if (occ) { b0 = occ[d]; occ[d] = (uint8_t)(b0 + 1); }
+      e.busy[d] = (uint8_t)cg_randint(e.draw(CG_SITE_STALL_CLEAN, d, b0), 0, P.c.default_high);
       e.wl[d] = 0;
     }
+    disc = 0;
+    for (int bit = 0; bit < CG_MAX_EXPLOITS; ++bit) disc |= (ballot((dl >> bit) & 1) != 0ull) << bit;
+  } else {   // device-major with multiplicities: duplicates / long lists give the sequential result
+    list_counts(e, dev, L);
+    const uint8_t* cnt = (const uint8_t*)e.scr;
+    int n_first_comp = 0, n_first_clean = 0, n_rest = 0;
+    disc = 0;
+    for (int c = 0; c < e.MC; ++c) {
+      int d = c * WAVE + e.lane;
+      bool hit = false;
+      int k = 0;
+      uint8_t f = 0;
+      if (d < e.M) {
+        k = cnt[d];
+        f = e.flags[d];
+        hit = k > 0 && !(f & CG_F_NYA) && !(f & CG_F_OWNED);
+      }
+      if (hit) {
+        if (f & CG_F_COMP) ++n_first_comp; else ++n_first_clean;
+        n_rest += k - 1;
+        disc |= e.cby[d];
+        e.cby[d] = 0;
+        e.flags[d] = (uint8_t)(f & ~(CG_F_COMP | CG_F_WLADV));
+        int b0 = occ ? occ[d] : 0;
+        if (occ) occ[d] = (uint8_t)(b0 + k);
+        e.busy[d] = (uint8_t)cg_randint(e.draw(CG_SITE_STALL_CLEAN, d, b0 + k - 1), 0, P.c.default_high);
+        e.wl[d] = 0;
+      }
+    }
+    a = wave_sum(n_first_comp);
+    b = wave_sum(n_first_clean) + wave_sum(n_rest);
+    disc = wave_or(disc);
   }
-  int a = wave_sum(n_first_comp), b = wave_sum(n_first_clean) + wave_sum(n_rest);
-  disc = wave_or(disc);
-  const double ds = P.c.def_scale;
   cost += (0.3 * a - 0.01 * b) * ds;
   fe[CG_D_CLEAN_COST] += (0.3 * a + 0.01 * b) * ds;
   fe[CG_D_DEF_COST] += (0.3 * a + 0.01 * b) * ds;
   ie[CG_I_DISCOVERED] |= disc;
-  if (a + b > 0) e.cby_dirty = true;
   wsync();
 }
 
-// Pool pick for actions 6 / 9 (volt_typhoon_env.py:501-511): r-th edge with the wanted
-// blocked state among out-entries (row order) then in-entries (in-row order) of device d.
-__device__ bool pick_incident(Env& e, const KParams& P, int d, bool want, uint32_t site, int occ_b,
-                              int& su, int& sv) {
+// Actions 6 / 9 (volt_typhoon_env.py:501-511, 1071-1100): pick the r-th incident edge with the
+// wanted blocked state among out-entries (row order) then in-entries (in-row order) of device d,
+// and flip it.  Out-row blocked bits are a contiguous bit range of `blk`, so counting and selecting
+// there are word operations; the in-row is gathered through in_eid with ballots.
+__device__ __forceinline__ bool flip_incident(Env& e, int d, bool want, uint32_t site, int occ_b) {
   const int o0 = e.optr[d], o1 = e.optr[d + 1];
   const int i0 = e.iptr[d], i1 = e.iptr[d + 1];
-  int n = 0;
-  for (int k0 = o0; k0 < o1; k0 += WAVE) {
-    int k = k0 + e.lane;
-    bool p = (k < o1) && (e.blocked(k) == want);
-    n += __popcll(ballot(p));
-  }
-  int n_out = n;
+  const int nb = range_popc(e.blk, o0, o1);
+  const int n_out = want ? nb : (o1 - o0) - nb;
+  int n_in = 0;
   for (int k0 = i0; k0 < i1; k0 += WAVE) {
     int k = k0 + e.lane;
-    bool p = (k < i1) && (e.blocked(e.ieid[k]) == want);
-    n += __popcll(ballot(p));
+    n_in += __popcll(ballot((k < i1) && (e.blocked(e.ieid[k]) == want)));
   }
+  const int n = n_out + n_in;
   if (n == 0) return false;
   int r = (int)cg_index(e.draw(site, d, occ_b), (uint32_t)n);
+  int su, sv, slot;
   if (r < n_out) {
-    int seen = 0;
-    for (int k0 = o0; k0 < o1; k0 += WAVE) {
-      int k = k0 + e.lane;
-      bool p = (k < o1) && (e.blocked(k) == want);
-      uint64_t m = ballot(p);
-      int c = __popcll(m);
-      if (r < seen + c) { int pos = nth_bit(m, r - seen); su = d; sv = e.ocol[k0 + pos]; return true; }
-      seen += c;
-    }
+    slot = range_select(e.blk, o0, o1, want, r);
+    su = d; sv = e.ocol[slot];
   } else {
     r -= n_out;
-    int seen = 0;
+    slot = -1; su = sv = 0;
     for (int k0 = i0; k0 < i1; k0 += WAVE) {
       int k = k0 + e.lane;
-      bool p = (k < i1) && (e.blocked(e.ieid[k]) == want);
-      uint64_t m = ballot(p);
+      uint64_t m = ballot((k < i1) && (e.blocked(e.ieid[k]) == want));
       int c = __popcll(m);
-      if (r < seen + c) { int pos = nth_bit(m, r - seen); su = e.icol[k0 + pos]; sv = d; return true; }
-      seen += c;
+      if (r < c) { int kk = k0 + nth_bit(m, r); slot = e.ieid[kk]; su = e.icol[kk]; sv = d; break; }
+      r -= c;
     }
   }
-  return false;
-}
-
-__device__ void set_blocked_pair(Env& e, int u, int v, bool val) {
-  const int o0 = e.optr[u], o1 = e.optr[u + 1];
-  for (int k = o0 + e.lane; k < o1; k += WAVE) {
-    if (e.ocol[k] == v) {
-      if (val) atomicOr(&e.blk[k >> 5], 1u << (k & 31));
-      else atomicAnd(&e.blk[k >> 5], ~(1u << (k & 31)));
+  wsync();
+  if (!e.multi) {   // (u,v) occurs once: flip exactly that slot
+    if (e.lane == 0) {
+      if (!want) e.blk[slot >> 5] |= 1u << (slot & 31); else e.blk[slot >> 5] &= ~(1u << (slot & 31));
+    }
+  } else {          // every duplicate (u,v) out-entry shares the state (env._blocked holds pairs)
+    const int p0 = e.optr[su], p1 = e.optr[su + 1];
+    for (int k = p0 + e.lane; k < p1; k += WAVE) {
+      if (e.ocol[k] == sv) {
+        if (!want) atomicOr(&e.blk[k >> 5], 1u << (k & 31)); else atomicAnd(&e.blk[k >> 5], ~(1u << (k & 31)));
+      }
     }
   }
   e.blk_dirty = true;
   wsync();
+  return true;
 }
 
-__device__ void def_per_device(Env& e, const KParams& P, int at, const int16_t* dev, int L, int app,
-                               double& cost, bool& dirty, int32_t* ie, double* fe) {
+__device__ __forceinline__ void def_per_device(Env& e, const KParams& P, int at, const int16_t* dev, int L, int app,
+                                               double& cost, bool& dirty, int32_t* ie, double* fe) {
   const double ds = P.c.def_scale;
   const int M = e.M;
   if (at == 1) { def_clean(e, P, dev, L, cost, ie, fe, nullptr); return; }
-  if (at == 6 || at == 9) {  // sequential over the list, wave-parallel inside (:1071-1100)
-    // occurrence numbers: kept in scr as bytes
+  if (at == 6 || at == 9) {  // sequential over the list: each pick changes the next pool
     for (int i = e.lane; i < (e.MC * WAVE) / 4; i += WAVE) e.scr[i] = 0;
     wsync();
     uint8_t* occ = (uint8_t*)e.scr;
+    int n_act = 0, n_hit = 0;
     for (int p = 0; p < L; ++p) {
       int d = dev[p];
       if (d < 0 || d >= M) continue;
       if (e.flags[d] & CG_F_NYA) continue;
-      cost += -0.5 * ds;
-      fe[CG_D_DEF_COST] += 0.5 * ds;
-      int su = 0, sv = 0;
+      ++n_act;
       int b = occ[d];
-      if (pick_incident(e, P, d, at == 9, at == 6 ? CG_SITE_PICK_BLOCK : CG_SITE_PICK_UNBLOCK, b, su, sv)) {
-        wsync();
+      if (flip_incident(e, d, at == 9, at == 6 ? CG_SITE_PICK_BLOCK : CG_SITE_PICK_UNBLOCK, b)) {
         if (e.lane == 0) occ[d] = (uint8_t)(b + 1);
-        set_blocked_pair(e, su, sv, at == 6);
-        if (at == 6) ie[CG_I_EDGES_BLOCKED] += 1; else ie[CG_I_EDGES_ADDED] += 1;
-        dirty = true;
+        ++n_hit;
+        wsync();
       }
     }
+    cost += -0.5 * n_act * ds;
+    fe[CG_D_DEF_COST] += 0.5 * n_act * ds;
+    if (at == 6) ie[CG_I_EDGES_BLOCKED] += n_hit; else ie[CG_I_EDGES_ADDED] += n_hit;
+    if (n_hit) dirty = true;
     return;
   }
   if (at == 12) {  // :1102-1109: the reference restores device_indices[0] once per listed active device
@@ -346,47 +435,65 @@ __device__ void def_per_device(Env& e, const KParams& P, int at, const int16_t* 
       if (d < 0 || d >= M) continue;
       if (e.flags[d] & CG_F_NYA) continue;
       ++n_iter;
-      if (e.lane == 0) {
-        e.flags[d0] = (uint8_t)((e.flags[d0] & ~CG_S_KEEP) | (sf & CG_S_KEEP));
-        e.busy[d0] = sb; e.wl[d0] = sw; e.cby[d0] = sc;
+      if (n_iter == 1) {
+        if (e.lane == 0) {
+          e.flags[d0] = (uint8_t)((e.flags[d0] & ~CG_S_KEEP) | (sf & CG_S_KEEP));
+          e.busy[d0] = sb; e.wl[d0] = sw; e.cby[d0] = sc;
+        }
+        wsync();
       }
-      wsync();
     }
-    if (n_iter > 0) e.cby_dirty = true;
     cost += -1.0 * n_iter * ds;
     fe[CG_D_DEF_COST] += 1.0 * n_iter * ds;
     return;
   }
-  // count-based actions: multiplicities over the list
-  list_counts(e, dev, L);
-  const uint8_t* cnt = (const uint8_t*)e.scr;
+  // count-based actions.  n_mult = list entries (with multiplicity) on active devices.
+  const bool simple = (at == 4 || at == 7) ? list_is_simple(e, dev, L) : true;
   int n_mult = 0, n_dist = 0;
-  for (int c = 0; c < e.MC; ++c) {
-    int d = c * WAVE + e.lane;
-    if (d < M) {
-      int k = cnt[d];
-      uint8_t f = e.flags[d];
-      if (k > 0 && !(f & CG_F_NYA)) {
-        n_mult += k; n_dist += 1;
-        if (at == 4) {  // :1013-1018
-          if (app >= 0 && app < e.nap[d])
-            e.busy[d] = (uint8_t)cg_randint(e.draw(CG_SITE_STALL_PATCH, d, k - 1), 0, P.c.default_high);
-        } else if (at == 7) {  // :1082-1089
-          e.flags[d] = (uint8_t)((f | CG_F_NYA) & ~(CG_F_COMP | CG_F_WLADV));
-          e.cby[d] = 0;
-          e.wl[d] = 0;
+  if (simple && L <= WAVE) {   // list-major
+    int d = -1;
+    if (e.lane < L) { d = dev[e.lane]; if (d < 0 || d >= M) d = -1; }
+    uint8_t f = d >= 0 ? e.flags[d] : (uint8_t)CG_F_NYA;
+    bool hit = !(f & CG_F_NYA);
+    n_mult = n_dist = __popcll(ballot(hit));
+    if (hit && at == 4) {  // :1013-1018
+      if (app >= 0 && app < e.nap[d])
+        e.busy[d] = (uint8_t)cg_randint(e.draw(CG_SITE_STALL_PATCH, d, 0), 0, P.c.default_high);
+    } else if (hit && at == 7) {  // :1082-1089
+      e.flags[d] = (uint8_t)((f | CG_F_NYA) & ~(CG_F_COMP | CG_F_WLADV));
+      e.cby[d] = 0;
+      e.wl[d] = 0;
+    }
+  } else {   // device-major with multiplicities
+    list_counts(e, dev, L);
+    const uint8_t* cnt = (const uint8_t*)e.scr;
+    for (int c = 0; c < e.MC; ++c) {
+      int d = c * WAVE + e.lane;
+      if (d < M) {
+        int k = cnt[d];
+        uint8_t f = e.flags[d];
+        if (k > 0 && !(f & CG_F_NYA)) {
+          n_mult += k; n_dist += 1;
+          if (at == 4) {
+            if (app >= 0 && app < e.nap[d])
+              e.busy[d] = (uint8_t)cg_randint(e.draw(CG_SITE_STALL_PATCH, d, k - 1), 0, P.c.default_high);
+          } else if (at == 7) {
+            e.flags[d] = (uint8_t)((f | CG_F_NYA) & ~(CG_F_COMP | CG_F_WLADV));
+            e.cby[d] = 0;
+            e.wl[d] = 0;
+          }
         }
       }
     }
+    n_mult = wave_sum(n_mult);
+    n_dist = wave_sum(n_dist);
   }
-  n_mult = wave_sum(n_mult);
-  n_dist = wave_sum(n_dist);
   wsync();
   if (at == 4) {
     cost += -1.0 * n_mult * ds;
   } else if (at == 7) {
     cost += -0.5 * n_dist * ds;   // a repeated entry finds the device already removed (:992)
-    if (n_dist > 0) { dirty = true; e.cby_dirty = true; }
+    if (n_dist > 0) dirty = true;
   } else if (at == 5) {  // fast scan :1020-1069
     ie[CG_I_SCAN_CNT] += n_mult;
     int w = e.log_total < CG_SCAN_WINDOW ? e.log_total : CG_SCAN_WINDOW;
@@ -418,7 +525,6 @@ __device__ void def_per_device(Env& e, const KParams& P, int at, const int16_t* 
       e.wl[d0] = 0;
       e.busy[d0] = (uint8_t)cg_randint(e.draw(CG_SITE_STALL_ISOLATE, d0, n_mult - 1), 3, P.c.default_high + 3);
     }
-    if (n_mult > 0) e.cby_dirty = true;
     cost += -3.0 * n_mult * ds;
     fe[CG_D_CLEAN_COST] += 3.0 * n_mult * ds;
     fe[CG_D_DEF_COST] += 3.0 * n_mult * ds;
@@ -427,48 +533,53 @@ __device__ void def_per_device(Env& e, const KParams& P, int at, const int16_t* 
 }
 
 // ---------------- attacker ----------------
-// One source's pick: first unblocked out-entry that (DC source) exists, or whose target is
-// reachable, or is known+vulnerable and not compromised before this source's turn.
-// Returns the CSR slot or -1.  `coop`: the whole wave scans one row (uniform s); otherwise each
-// lane walks its own (short) row.
 #define T_INF 0xFFFFFFFFu
+constexpr int LONG_ROW = 8;
 
-__device__ __forceinline__ bool spread_eligible(const Env& e, const uint32_t* T, int v, int s, uint8_t ebit) {
-  uint8_t f = e.flags[v];
-  if (f & CG_F_REACH) return true;
-  return (f & CG_F_KNOWN) && (e.vul[v] & ebit) && (T[v] >= (uint32_t)(s + 1));
+// eligibility byte per device, rebuilt per exploit pass: bit0 reachable, bit1 known & vulnerable
+__device__ __forceinline__ bool spread_ok(const uint8_t* el, const uint32_t* T, int v, int s) {
+  uint8_t x = el[v];
+  return (x & 1) || ((x & 2) && (T[v] >= (uint32_t)(s + 1)));
 }
-
-__device__ int spread_pick_lane(const Env& e, const uint32_t* T, int s, uint8_t ebit) {
-  const bool dc = e.dst[s] & CG_D_DC;
-  for (int k = e.optr[s]; k < e.optr[s + 1]; ++k) {
+// first slot k in [from, o1) that source s can take, or o1
+__device__ __forceinline__ int spread_scan_lane(const Env& e, const uint8_t* el, const uint32_t* T, int s, bool dc,
+                                                int from, int o1) {
+  for (int k = from; k < o1; ++k) {
     if (e.blocked(k)) continue;
-    if (dc) return k;
-    if (spread_eligible(e, T, e.ocol[k], s, ebit)) return k;
+    if (dc || spread_ok(el, T, e.ocol[k], s)) return k;
   }
-  return -1;
+  return o1;
 }
-__device__ int spread_pick_coop(const Env& e, const uint32_t* T, int s, uint8_t ebit) {
-  const bool dc = e.dst[s] & CG_D_DC;
-  const int o0 = e.optr[s], o1 = e.optr[s + 1];
-  for (int k0 = o0; k0 < o1; k0 += WAVE) {
+__device__ __forceinline__ int spread_scan_coop(const Env& e, const uint8_t* el, const uint32_t* T, int s, bool dc,
+                                                int from, int o1) {
+  for (int k0 = from; k0 < o1; k0 += WAVE) {
     int k = k0 + e.lane;
     bool p = false;
-    if (k < o1 && !e.blocked(k)) p = dc || spread_eligible(e, T, e.ocol[k], s, ebit);
+    if (k < o1 && !e.blocked(k)) p = dc || spread_ok(el, T, e.ocol[k], s);
     uint64_t m = ballot(p);
     if (m) return k0 + __builtin_ctzll(m);
   }
-  return -1;
+  return o1;
 }
 
-constexpr int LONG_ROW = 8;
-
-__device__ void attacker_spread(Env& e, const KParams& P, const int32_t* expl, int n_expl, uint64_t* srcb,
-                                int32_t* ie) {
-  const int M = e.M, MC = e.MC;
+__device__ __forceinline__ void attacker_spread(Env& e, const KParams& P, const int32_t* expl, int n_expl,
+                                                uint64_t* srcb) {
+  const int M = e.M, MC = e.MC, Mp = MC * WAVE;
   uint32_t* T = e.scr;                          // [Mp] first-compromise time (source id + 1)
-  uint16_t* pick = (uint16_t*)(e.scr + MC * WAVE);  // [Mp] chosen CSR slot (0xFFFF none)
-  uint16_t* cntv = pick + MC * WAVE;            // [Mp] log entries of each source
+  uint16_t* cur = (uint16_t*)(e.scr + Mp);      // [Mp] current pick (slot) of each source, row end = none
+  uint16_t* cntv = cur + Mp;                    // [Mp] log entries of each source
+  uint8_t* el = e.el;                           // [Mp] eligibility byte per device (this exploit)
+  // long-row sources (uniform list), built once: the source set is a snapshot (:1127)
+  int n_long = 0;
+  for (int c = 0; c < MC; ++c) {
+    int s = c * WAVE + e.lane;
+    bool is_src = (srcb[c] >> e.lane) & 1ull;
+    bool lg = is_src && (e.optr[s + 1] - e.optr[s]) > LONG_ROW;
+    uint64_t lm = ballot(lg);
+    if (lg) e.lsrc[n_long + below(lm)] = (uint16_t)s;
+    n_long += __popcll(lm);
+  }
+  wsync();
   int zocc = 0;
   for (int j = 0; j < n_expl; ++j) {
     int raw = expl[j];
@@ -479,20 +590,19 @@ __device__ void attacker_spread(Env& e, const KParams& P, const int32_t* expl, i
         int cnt = __popc(mask);
         if (cnt == 0) continue;
         int r = (int)cg_index(e.draw(CG_SITE_ZERODAY, zocc++, 0), (uint32_t)cnt);
-        uint32_t m = mask;
-        for (int i = 0; i < r; ++i) m &= m - 1;
-        raw = __builtin_ctz(m);
+        raw = nth_bit32(mask, r);
       }
     }
     if (raw < 0 || raw >= P.t.X) continue;
     const uint8_t ebit = (uint8_t)(1u << raw);
-    // init T from the live compromise bits
-    for (int d = e.lane; d < MC * WAVE; d += WAVE) {
-      T[d] = (d < M && (e.flags[d] & CG_F_COMP)) ? 0u : T_INF;
-      pick[d] = 0xFFFF;
+    for (int d = e.lane; d < Mp; d += WAVE) {
+      uint8_t f = d < M ? e.flags[d] : 0;
+      T[d] = (f & CG_F_COMP) ? 0u : T_INF;
+      el[d] = (uint8_t)(((f & CG_F_REACH) ? 1 : 0) | (((f & CG_F_KNOWN) && d < M && (e.vul[d] & ebit)) ? 2 : 0));
+      cur[d] = d < M ? e.optr[d] : 0;
     }
     wsync();
-    // fix-point rounds
+    // fix-point rounds: a source re-examines its pick and, if an earlier source took it, resumes the scan
     for (int round = 0; round <= M + 1; ++round) {
       bool changed = false;
       for (int c = 0; c < MC; ++c) {
@@ -500,26 +610,38 @@ __device__ void attacker_spread(Env& e, const KParams& P, const int32_t* expl, i
         if (!sm) continue;
         int s = c * WAVE + e.lane;
         bool is_src = (sm >> e.lane) & 1ull;
-        int len = is_src ? (e.optr[s + 1] - e.optr[s]) : 0;
-        if (is_src && len <= LONG_ROW) {
-          int k = spread_pick_lane(e, T, s, ebit);
-          uint16_t nk = k < 0 ? 0xFFFF : (uint16_t)k;
-          if (nk != pick[s]) { pick[s] = nk; changed = true; }
-          if (k >= 0) atomicMin(&T[e.ocol[k]], (uint32_t)(s + 1));
-        }
-        uint64_t lm = ballot(is_src && len > LONG_ROW);
-        while (lm) {
-          int ls = c * WAVE + __builtin_ctzll(lm);
-          lm &= lm - 1;
-          int k = spread_pick_coop(e, T, ls, ebit);
-          uint16_t nk = k < 0 ? 0xFFFF : (uint16_t)k;
-          if (nk != pick[ls]) changed = true;   // uniform
-          wsync();
-          if (e.lane == 0) {
-            pick[ls] = nk;
-            if (k >= 0) atomicMin(&T[e.ocol[k]], (uint32_t)(ls + 1));
+        if (is_src) {
+          int o1 = e.optr[s + 1];
+          if (o1 - e.optr[s] <= LONG_ROW) {
+            int k0 = cur[s];
+            int k = spread_scan_lane(e, el, T, s, e.dst[s] & CG_D_DC, k0, o1);
+            if (k != k0) { cur[s] = (uint16_t)k; changed = true; }
+            if (round == 0) changed = true;
+            if (k < o1 && (round == 0 || k != k0)) atomicMin(&T[e.ocol[k]], (uint32_t)(s + 1));
           }
-          wsync();
+        }
+      }
+      // long rows: validity of the current pick checked lane-parallel, rescans wave-cooperative
+      for (int b0 = 0; b0 < n_long; b0 += WAVE) {
+        int i = b0 + e.lane;
+        bool need = false;
+        if (i < n_long) {
+          int s = e.lsrc[i];
+          int k = cur[s], o1 = e.optr[s + 1];
+          if (round == 0) need = true;
+          else if (k < o1) need = !((e.dst[s] & CG_D_DC) || spread_ok(el, T, e.ocol[k], s));
+        }
+        uint64_t nm = ballot(need);
+        while (nm) {
+          int ls = e.lsrc[b0 + __builtin_ctzll(nm)];
+          nm &= nm - 1;
+          int k0 = cur[ls], o1 = e.optr[ls + 1];
+          int k = spread_scan_coop(e, el, T, ls, e.dst[ls] & CG_D_DC, round == 0 ? k0 : k0 + 1, o1);
+          changed = changed || (k != k0) || round == 0;
+          if (e.lane == 0) {
+            cur[ls] = (uint16_t)k;
+            if (k < o1) atomicMin(&T[e.ocol[k]], (uint32_t)(ls + 1));
+          }
         }
       }
       wsync();
@@ -530,31 +652,14 @@ __device__ void attacker_spread(Env& e, const KParams& P, const int32_t* expl, i
     for (int c = 0; c < MC; ++c) {
       const uint64_t sm = srcb[c];
       int s = c * WAVE + e.lane;
-      bool is_src = (sm >> e.lane) & 1ull;
       int n = 0;
-      if (is_src) {
+      if ((sm >> e.lane) & 1ull) {
         int o0 = e.optr[s], o1 = e.optr[s + 1];
-        int last = pick[s] == 0xFFFF ? o1 - 1 : (int)pick[s];
-        if (o1 - o0 <= LONG_ROW) {
-          for (int k = o0; k <= last; ++k) n += !e.blocked(k);
-        }
+        int end = cur[s] < o1 ? cur[s] + 1 : o1;
+        n = (end - o0) - range_popc(e.blk, o0, end);
       }
-      uint64_t lm = ballot(is_src && (e.optr[s + 1] - e.optr[s]) > LONG_ROW);
-      while (lm) {
-        int ll = __builtin_ctzll(lm);
-        lm &= lm - 1;
-        int ls = c * WAVE + ll;
-        int o0 = e.optr[ls], o1 = e.optr[ls + 1];
-        int last = pick[ls] == 0xFFFF ? o1 - 1 : (int)pick[ls];
-        int acc = 0;
-        for (int k0 = o0; k0 <= last; k0 += WAVE) {
-          int k = k0 + e.lane;
-          acc += __popcll(ballot(k <= last && !e.blocked(k)));
-        }
-        if (e.lane == ll) n = acc;
-      }
-      if (s < MC * WAVE) cntv[s] = (uint16_t)n;
-      total_new += wave_sum(n);
+      cntv[s] = (uint16_t)n;
+      if (sm) total_new += wave_sum(n);
     }
     wsync();
     // ring: only the last CG_LOG_RING entries (global order: source id, then row order) matter
@@ -562,18 +667,22 @@ __device__ void attacker_spread(Env& e, const KParams& P, const int32_t* expl, i
       const uint32_t base = (uint32_t)e.log_total;
       const uint32_t end = base + (uint32_t)total_new;
       const uint32_t lo = end > CG_LOG_RING ? end - CG_LOG_RING : 0;
-      uint32_t run = base;
-      for (int c = 0; c < MC; ++c) {
+      // walk chunks from the top: only the tail sources write
+      uint32_t after = end;   // global index just past the current chunk
+      for (int c = MC - 1; c >= 0 && after > lo; --c) {
+        if (!srcb[c]) continue;
         int s = c * WAVE + e.lane;
         int n = cntv[s];
         int incl = wave_incl_scan(n, e.lane);
-        uint32_t off = run + (uint32_t)(incl - n);
         int chunk_total = __shfl(incl, 63);
+        uint32_t cbase = after - (uint32_t)chunk_total;
+        uint32_t off = cbase + (uint32_t)(incl - n);
         bool mine = n > 0 && off + (uint32_t)n > lo;
         bool is_long = mine && (e.optr[s + 1] - e.optr[s]) > LONG_ROW;
         if (mine && !is_long) {
           uint32_t idx = off;
-          int last = pick[s] == 0xFFFF ? e.optr[s + 1] - 1 : (int)pick[s];
+          int o1 = e.optr[s + 1];
+          int last = cur[s] < o1 ? (int)cur[s] : o1 - 1;
           for (int k = e.optr[s]; k <= last; ++k) {
             if (e.blocked(k)) continue;
             if (idx >= lo) { e.ring[2 * (idx % CG_LOG_RING)] = (uint16_t)s; e.ring[2 * (idx % CG_LOG_RING) + 1] = e.ocol[k]; }
@@ -587,7 +696,7 @@ __device__ void attacker_spread(Env& e, const KParams& P, const int32_t* expl, i
           int ls = c * WAVE + ll;
           uint32_t idx0 = __shfl(off, ll);
           int o0 = e.optr[ls], o1 = e.optr[ls + 1];
-          int last = pick[ls] == 0xFFFF ? o1 - 1 : (int)pick[ls];
+          int last = cur[ls] < o1 ? (int)cur[ls] : o1 - 1;
           for (int k0 = o0; k0 <= last; k0 += WAVE) {
             int k = k0 + e.lane;
             bool p = k <= last && !e.blocked(k);
@@ -597,32 +706,26 @@ __device__ void attacker_spread(Env& e, const KParams& P, const int32_t* expl, i
             idx0 += (uint32_t)__popcll(m);
           }
         }
-        run += (uint32_t)chunk_total;
+        after = cbase;
       }
       e.log_total = (int)end;
       e.ring_dirty = true;
     }
     wsync();
     // apply: compromise flags + DC attribution (:1163-1185)
-    for (int c = 0; c < MC; ++c) {
-      int d = c * WAVE + e.lane;
-      if (d < M && T[d] != T_INF && T[d] != 0u) e.flags[d] |= CG_F_COMP;
-    }
+    for (int d = e.lane; d < M; d += WAVE)
+      if (T[d] != T_INF && T[d] != 0u) e.flags[d] |= CG_F_COMP;
     wsync();
     for (int c = 0; c < MC; ++c) {
       const uint64_t sm = srcb[c];
       int s = c * WAVE + e.lane;
-      if (((sm >> e.lane) & 1ull) && (e.dst[s] & CG_D_DC) && pick[s] != 0xFFFF) {
-        byte_or(e.cby, e.ocol[pick[s]], ebit);
-        e.cby_dirty = true;
-      }
+      if (((sm >> e.lane) & 1ull) && (e.dst[s] & CG_D_DC) && cur[s] < e.optr[s + 1]) byte_or(e.cby, e.ocol[cur[s]], ebit);
     }
-    e.cby_dirty = __any(e.cby_dirty);
     wsync();
   }
 }
 
-__device__ void attacker_probe(Env& e, const KParams& P, const uint64_t* srcb, double& cost) {
+__device__ __forceinline__ void attacker_probe(Env& e, const uint64_t* srcb, double& cost) {
   int n_src = 0;
   for (int c = 0; c < e.MC; ++c) n_src += __popcll(srcb[c]);
   if (n_src == 0) return;
@@ -640,6 +743,7 @@ __device__ void attacker_probe(Env& e, const KParams& P, const uint64_t* srcb, d
     uint64_t m = ballot(p);
     if (m) {
       int v = e.ocol[k0 + __builtin_ctzll(m)];
+      wsync();
       if (e.lane == 0) e.flags[v] |= CG_F_KNOWN;
       cost += 0.1;   // :1199 (not scaled)
       break;
@@ -649,13 +753,8 @@ __device__ void attacker_probe(Env& e, const KParams& P, const uint64_t* srcb, d
 }
 
 // ---------------- arrivals: CDSimulator.generate_workloads :244-348 ----------------
-__device__ void gen_workloads(Env& e, const KParams& P, int num, bool server) {
+__device__ __forceinline__ void gen_workloads(Env& e, const KParams& P, int num, bool server, int n_active) {
   const int M = e.M, MC = e.MC;
-  int n_active = 0;
-  for (int c = 0; c < MC; ++c) {
-    int d = c * WAVE + e.lane;
-    n_active += __popcll(ballot(d < M && !(e.flags[d] & CG_F_NYA)));
-  }
   if (n_active <= 0) return;
   if (P.c.workload_cap >= 0 && num > P.c.workload_cap) num = P.c.workload_cap;
   if (num > n_active) num = n_active;
@@ -732,21 +831,8 @@ __device__ void gen_workloads(Env& e, const KParams& P, int num, bool server) {
   wsync();
 }
 
-__device__ void arrivals(Env& e, const KParams& P, int step_num) {  // volt_typhoon_env.py:575-596
-  const int M = e.M;
-  int n_active = 0, idle = 0, free_s = 0;
-  for (int c = 0; c < e.MC; ++c) {
-    int d = c * WAVE + e.lane;
-    bool act = false, idl = false, srv = false;
-    if (d < M) {
-      act = !(e.flags[d] & CG_F_NYA);
-      idl = act && e.busy[d] == 0 && e.wl[d] == 0;
-      srv = e.dst[d] & CG_D_SERVER;
-    }
-    n_active += __popcll(ballot(act));
-    idle += __popcll(ballot(idl));
-    free_s += __popcll(ballot(idl && srv));
-  }
+// volt_typhoon_env.py:575-596; the three counts come from the fused pass of the tick
+__device__ __forceinline__ void arrivals(Env& e, const KParams& P, int step_num, int n_active, int idle, int free_s) {
   int free_c = idle - free_s;
   int n1 = n_active > 1 ? n_active : 1;
   int half = 0;
@@ -775,12 +861,12 @@ __device__ void arrivals(Env& e, const KParams& P, int step_num) {  // volt_typh
       nS = (int)(nS * ratio); if (nS < 0) nS = 0;
     }
   }
-  gen_workloads(e, P, nC, false);
-  gen_workloads(e, P, nS, true);
+  gen_workloads(e, P, nC, false, n_active);
+  gen_workloads(e, P, nS, true, n_active);
 }
 
 // ---------------- evolve_network: CyberDefenseEnv.py:583-875 ----------------
-__device__ int rank_select(const Env& e, uint8_t mask, uint8_t want, int r) {
+__device__ __forceinline__ int rank_select(const Env& e, uint8_t mask, uint8_t want, int r) {
   for (int c = 0; c < e.MC; ++c) {
     int d = c * WAVE + e.lane;
     uint64_t m = ballot(d < e.M && (e.flags[d] & mask) == want);
@@ -790,7 +876,7 @@ __device__ int rank_select(const Env& e, uint8_t mask, uint8_t want, int r) {
   }
   return -1;
 }
-__device__ bool has_edge(const Env& e, int u, int v) {
+__device__ __forceinline__ bool has_edge(const Env& e, int u, int v) {
   const int o0 = e.optr[u], o1 = e.optr[u + 1];
   for (int k0 = o0; k0 < o1; k0 += WAVE) {
     int k = k0 + e.lane;
@@ -799,21 +885,24 @@ __device__ bool has_edge(const Env& e, int u, int v) {
   return false;
 }
 
-__device__ void evolve(Env& e, const KParams& P) {
+__device__ __forceinline__ void evolve(Env& e, const KParams& P) {
   const int M = e.M, MC = e.MC;
   if (!(e.eflags & CG_E_EVO_INIT)) {   // :654-659
-    for (int d = e.lane; d < M; d += WAVE) {
-      uint8_t f = e.flags[d];
-      e.flags[d] = (f & CG_F_NYA) ? (uint8_t)(f & ~CG_F_EVOACT) : (uint8_t)(f | CG_F_EVOACT);
+    uint32_t* F = (uint32_t*)e.flags;
+    for (int w = e.lane; w < (e.MS >> 2); w += WAVE) {
+      uint32_t f = F[w];
+      F[w] = (f & ~(ONES * CG_F_EVOACT)) | ((~(f >> 4) & ONES) << 5);
     }
     e.eflags |= CG_E_EVO_INIT;
     wsync();
   }
-  uint32_t* newly = e.marks;   // bit per device
-  for (int i = e.lane; i <= (MC * WAVE) / 32; i += WAVE) newly[i] = 0;
-  wsync();
-  bool any_new = false;
   int n_ev = cg_cdf_lookup(e.draw(CG_SITE_EVO_POISSON, 0, 0), P.c.poisson_thr, CG_POISSON_TABLE);
+  bool any_new = false;
+  uint32_t* newly = e.marks;   // bit per device
+  if (n_ev > 0) {
+    for (int i = e.lane; i <= (MC * WAVE) / 32; i += WAVE) newly[i] = 0;
+    wsync();
+  }
   const int floor_n = P.c.num_of_device > P.c.min_network_size ? P.c.num_of_device : P.c.min_network_size;
   for (int ev = 0; ev < n_ev; ++ev) {
     if (cg_bernoulli(e.draw(CG_SITE_EVO_COIN, ev, 0), P.c.p_add_thr)) {
@@ -890,31 +979,27 @@ __device__ void evolve(Env& e, const KParams& P) {
 }
 
 // ---------------- the tick ----------------
-// 16-byte copy helper: n16 uint4 items, strided by `stride` threads
-__device__ __forceinline__ void copy16(uint4* dst, const uint4* src, int n16, int tid, int stride) {
-  for (int i = tid; i < n16; i += stride) dst[i] = src[i];
-}
-
 template <int WPB>
 __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
   extern __shared__ __align__(16) uint8_t smem[];
-  const int M = P.t.M, MC = P.t.MC, Mp = MC * WAVE;
+  const int M = P.t.M, MC = P.t.MC, Mp = MC * WAVE, MS = (M + 3) & ~3;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int env = uni(blockIdx.x * WPB + wave);
   const bool live = env < P.n_envs;
   const int G = P.a.max_groups, L = P.a.max_devs;
 
-  // ---- per-wave LDS carve ----
+  // ---- per-wave LDS carve (must match wave_lds_bytes on the host) ----
   uint8_t* wb = smem + P.shared_lds + (size_t)wave * P.wave_lds;
-  const int live_bytes = (4 * M + 15) & ~15;
   Env e;
-  e.flags = wb; e.busy = wb + M; e.wl = wb + 2 * M; e.cby = wb + 3 * M;
-  e.scr = (uint32_t*)(wb + live_bytes);
+  e.flags = wb; e.busy = wb + MS; e.wl = wb + 2 * MS; e.cby = wb + 3 * MS;
+  e.scr = (uint32_t*)(wb + ((4 * MS + 15) & ~15));
   e.blk = e.scr + 2 * Mp;
   e.ring = (uint16_t*)(e.blk + ((P.t.EW + 3) & ~3));
   e.marks = (uint32_t*)(e.ring + 2 * CG_LOG_RING);
   uint64_t* srcb = (uint64_t*)(e.marks + ((Mp / 32 + 2) & ~1));
-  e.devl = (int16_t*)(srcb + MC);
+  e.lsrc = (uint16_t*)(srcb + MC);
+  e.el = (uint8_t*)(e.lsrc + Mp);
+  e.devl = (int16_t*)(e.el + Mp);
   e.optr = (const uint16_t*)(smem + P.t.o_optr); e.ocol = (const uint16_t*)(smem + P.t.o_ocol);
   e.osv = (const float*)(smem + P.t.o_os); e.ver = (const float*)(smem + P.t.o_ver); e.ano = (const float*)(smem + P.t.o_ano);
   e.dst = smem + P.t.o_dst; e.vul = smem + P.t.o_vul; e.nap = smem + P.t.o_nap;
@@ -922,10 +1007,12 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
     const uint8_t* ib = P.t.in_lds ? (const uint8_t*)smem : P.t.blob;
     e.iptr = (const uint16_t*)(ib + P.t.o_iptr); e.icol = (const uint16_t*)(ib + P.t.o_icol); e.ieid = (const uint16_t*)(ib + P.t.o_ieid);
   }
-  e.M = M; e.MC = MC; e.lane = lane; e.env = env;
+  e.M = M; e.MC = MC; e.MS = MS; e.lane = lane; e.env = env;
+  e.cbits = 32 - __builtin_clz((unsigned)(4 * ((MS / 4 + WAVE - 1) / WAVE)));
   e.env_id = (uint32_t)(P.c.env_id_base + env);
   e.seed = P.c.seed;
-  e.blk_dirty = e.ring_dirty = e.cby_dirty = false;
+  e.blk_dirty = e.ring_dirty = false;
+  e.multi = P.t.multi != 0;
 
   STAMP(0);
   // ---- issue every global load of this tick up front (one memory latency, not a chain) ----
@@ -955,14 +1042,25 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
     if (vec && lane < items) r0 = ((const uint4*)g_live)[lane];
     if (lane < CG_LOG_RING) ringw = ((const uint32_t*)(P.b.ring + (size_t)env * CG_LOG_RING * 2))[lane];
   }
-  // ---- workgroup-shared topology blob -> LDS (16-byte copies) ----
-  copy16((uint4*)smem, (const uint4*)P.t.blob, P.t.lds_bytes >> 4, threadIdx.x, WPB * WAVE);
+  // ---- workgroup-shared topology blob -> LDS (16-byte copies, two in flight per thread) ----
+  {
+    const uint4* src = (const uint4*)P.t.blob;
+    uint4* dstp = (uint4*)smem;
+    const int n16 = P.t.lds_bytes >> 4, stride = WPB * WAVE;
+    int i = threadIdx.x;
+    for (; i + stride < n16; i += 2 * stride) {
+      uint4 a = src[i], b = src[i + stride];
+      dstp[i] = a; dstp[i + stride] = b;
+    }
+    if (i < n16) dstp[i] = src[i];
+  }
   if (live) {
     if (vec) {
       if (lane < items) ((uint4*)e.flags)[lane] = r0;
       for (int i = lane + WAVE; i < items; i += WAVE) ((uint4*)e.flags)[i] = ((const uint4*)g_live)[i];
     } else {
-      for (int i = lane; i < 4 * M; i += WAVE) e.flags[i] = g_live[i];
+      for (int pl = 0; pl < 4; ++pl)
+        for (int i = lane; i < MS; i += WAVE) e.flags[pl * MS + i] = i < M ? g_live[pl * M + i] : (pl == 0 ? (uint8_t)CG_F_NYA : (uint8_t)0);
     }
     if (lane < CG_LOG_RING) ((uint32_t*)e.ring)[lane] = ringw;
     const uint32_t* gb = P.b.blocked + (size_t)env * P.t.EW;
@@ -978,6 +1076,11 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
   e.eflags = ie[CG_I_FLAGS];
   e.log_total = ie[CG_I_LOG_TOTAL];
   const int16_t* devs = e.devl;
+  uint32_t* const F = (uint32_t*)e.flags;
+  uint32_t* const Bz = (uint32_t*)e.busy;
+  uint32_t* const Wl = (uint32_t*)e.wl;
+  const uint32_t* const Ds = (const uint32_t*)e.dst;
+  const int NW = MS >> 2;
   double cost = 0.0;
   bool dirty = false;
   int last_atype = -1;
@@ -989,8 +1092,10 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
     if (Ld < 0) Ld = 0;
     if (mode == CG_MODE_DEFENDER) { if (!(at >= 0 && at < P.c.n_def_actions)) at = 8; }
     else                          { if (!(at >= 0 && at < P.c.n_att_actions)) at = 3; }
-    for (int d = lane; d < M; d += WAVE)   // :904-908 decay of the cached busy set
-      if ((e.flags[d] & CG_F_BUSYC) && e.busy[d] > 0) e.busy[d]--;
+    for (int w = lane; w < NW; w += WAVE) {   // :904-908 decay of the cached busy set
+      uint32_t b = Bz[w];
+      Bz[w] = b - (((F[w] >> 6) & ONES) & nz01(b));
+    }
     wsync();
     if (mode == CG_MODE_DEFENDER) {
       if (P.c.baseline != 0) at = 8;   // :913-914
@@ -1004,12 +1109,12 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
         if (lane == 0) srcb[c] = m;
       }
       wsync();
-        if (at == 1) {
+      if (at == 1) {
         int ne = nexp0;
         if (ne > CG_MAX_EXPLOITS) ne = CG_MAX_EXPLOITS;
-        attacker_spread(e, P, P.a.exploit + (size_t)env * G * CG_MAX_EXPLOITS, ne, srcb, ie);
+        attacker_spread(e, P, P.a.exploit + (size_t)env * G * CG_MAX_EXPLOITS, ne, srcb);
       } else {
-        attacker_probe(e, P, srcb, cost);
+        attacker_probe(e, srcb, cost);
       }
     }
     last_atype = at;
@@ -1033,43 +1138,44 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
       }
       dp += Ld; used += Ld;
     }
-    for (int d = lane; d < M; d += WAVE) if (e.busy[d] > 0) e.busy[d]--;   // _tick_busy_time_once :607
+    for (int w = lane; w < NW; w += WAVE) { uint32_t b = Bz[w]; Bz[w] = b - nz01(b); }   // _tick_busy_time_once :607
     wsync();
   }
 
   STAMP(2);
-  // ---- workload advance (:1242-1261 / :705-725) ----
-  int current_work = 0;
-  for (int c = 0; c < MC; ++c) {
-    int d = c * WAVE + lane;
-    bool fin = false;
-    if (d < M && e.busy[d] == 0 && !(e.flags[d] & CG_F_NYA) && e.wl[d] > 0) {
-      uint8_t w = (uint8_t)(e.wl[d] - 1);
-      e.wl[d] = w;
-      if (w == 0) {
-        if (e.flags[d] & CG_F_WLADV) e.flags[d] &= (uint8_t)~CG_F_WLADV; else fin = true;
-      }
-    }
-    current_work += __popcll(ballot(fin));
+  // ---- fused word pass: workload advance (:1242-1261 / :705-725) + every per-tick count ----
+  int c_fin = 0, c_act = 0, c_idle = 0, c_fsrv = 0, c_comp = 0, c_cdc = 0;
+  for (int w = lane; w < NW; w += WAVE) {
+    uint32_t f = F[w], b = Bz[w], l = Wl[w], st = Ds[w];
+    const uint32_t nya = (f >> 4) & ONES;
+    const uint32_t step = ~nz01(b) & ~nya & nz01(l) & ONES;   // idle-of-stall, active, has a job
+    l -= step;
+    const uint32_t fin = step & ~nz01(l);
+    const uint32_t adv = (f >> 7) & ONES;
+    f &= ~((fin & adv) << 7);
+    Wl[w] = l; F[w] = f;
+    const uint32_t act = ~nya & ONES;
+    const uint32_t idl = act & ~nz01(b) & ~nz01(l);
+    const uint32_t cmp = f & ~nya & ~(f >> 1) & ONES;          // compromised, active, not attacker-owned
+    c_fin += __popc(fin & ~adv);
+    c_act += __popc(act);
+    c_idle += __popc(idl);
+    c_fsrv += __popc(idl & (st >> 1));
+    c_comp += __popc(cmp);
+    c_cdc += __popc(cmp & st);
   }
+  const int current_work = wave_sum_bits(c_fin, e.cbits);
+  const int n_active = wave_sum_bits(c_act, e.cbits);
+  const int n_idle = wave_sum_bits(c_idle, e.cbits);
+  const int n_fsrv = wave_sum_bits(c_fsrv, e.cbits);
+  const int n_comp = wave_sum_bits(c_comp, e.cbits);
+  const int n_comp_dc = wave_sum_bits(c_cdc, e.cbits);
   ie[CG_I_WORK_DONE] += current_work;
   wsync();
-  arrivals(e, P, ie[CG_I_STEP_NUM]);
+  arrivals(e, P, ie[CG_I_STEP_NUM], n_active, n_idle, n_fsrv);   // changes wl only: the counts above stand
 
   STAMP(3);
-  // ---- counts + rewards (:1267-1304 / :732-748) ----
-  int n_comp = 0, n_comp_dc = 0;
-  for (int c = 0; c < MC; ++c) {
-    int d = c * WAVE + lane;
-    bool p = false, q = false;
-    if (d < M) {
-      uint8_t f = e.flags[d];
-      p = (f & CG_F_COMP) && !(f & CG_F_NYA) && !(f & CG_F_OWNED);
-      q = p && (e.dst[d] & CG_D_DC);
-    }
-    n_comp += __popcll(ballot(p));
-    n_comp_dc += __popcll(ballot(q));
-  }
+  // ---- rewards (:1267-1304 / :732-748) ----
   if (ng == 0) ie[CG_I_COMP_CNT] += n_comp;
   ie[CG_I_LAST_NCOMP] = n_comp;
   double raw, shaped;
@@ -1091,36 +1197,29 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
   }
 
   STAMP(4);
-  // ---- observation (_get_state CyberDefenseEnv.py:146-191), before evolve; 16-B coalesced stores ----
-  {
-    float* out = P.o.obs + (size_t)env * M * 6;
-    const int n4 = (M * 6) >> 2;   // M*6 is a multiple of 4 when M is even; tail handled below
-    for (int i4 = lane; i4 < n4; i4 += WAVE) {
-      float v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int i = i4 * 4 + j;
-        int d = i / 6, col = i - d * 6;
-        uint8_t f = e.flags[d];
-        float x;
-        switch (col) {
-          case 0: x = e.osv[d]; break;
-          case 1: x = e.ver[d]; break;
-          case 2: x = (f & CG_F_COMP) ? 1.f : 0.f; break;
-          case 3: x = e.ano[d]; break;
-          case 4: x = (f & CG_F_KNOWN) ? 1.f : 0.f; break;
-          default: x = (f & CG_F_NYA) ? 1.f : 0.f; break;
-        }
-        v[j] = x;
-      }
-      *(float4*)(out + i4 * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  // ---- observation (_get_state CyberDefenseEnv.py:146-191), before evolve.
+  // One lane per device PAIR: 12 floats = three 16-byte stores; static columns read as float2.
+  if (!(M & 1)) {
+    float4* out4 = (float4*)(P.o.obs + (size_t)env * M * 6);
+    const int npairs = M >> 1;
+    const uint16_t* F2 = (const uint16_t*)e.flags;
+    const float2* os2 = (const float2*)e.osv;
+    const float2* ve2 = (const float2*)e.ver;
+    const float2* an2 = (const float2*)e.ano;
+    for (int p = lane; p < npairs; p += WAVE) {
+      const uint32_t f2 = F2[p];
+      const float2 o = os2[p], v = ve2[p], a = an2[p];
+      const uint32_t fa = f2 & 0xFFu, fb = f2 >> 8;
+      out4[3 * p + 0] = make_float4(o.x, v.x, (float)(fa & 1u), a.x);
+      out4[3 * p + 1] = make_float4((float)((fa >> 2) & 1u), (float)((fa >> 4) & 1u), o.y, v.y);
+      out4[3 * p + 2] = make_float4((float)(fb & 1u), a.y, (float)((fb >> 2) & 1u), (float)((fb >> 4) & 1u));
     }
-    for (int i = n4 * 4 + lane; i < M * 6; i += WAVE) {
-      int d = i / 6, col = i - d * 6;
-      uint8_t f = e.flags[d];
-      float x = col == 0 ? e.osv[d] : col == 1 ? e.ver[d] : col == 2 ? ((f & CG_F_COMP) ? 1.f : 0.f)
-              : col == 3 ? e.ano[d] : col == 4 ? ((f & CG_F_KNOWN) ? 1.f : 0.f) : ((f & CG_F_NYA) ? 1.f : 0.f);
-      out[i] = x;
+  } else {   // odd M: rows are not 16-byte aligned across envs
+    float* o = P.o.obs + (size_t)env * M * 6;
+    for (int d = lane; d < M; d += WAVE) {
+      const uint32_t f = e.flags[d];
+      o[6 * d + 0] = e.osv[d]; o[6 * d + 1] = e.ver[d]; o[6 * d + 2] = (float)(f & 1u); o[6 * d + 3] = e.ano[d];
+      o[6 * d + 4] = (float)((f >> 2) & 1u); o[6 * d + 5] = (float)((f >> 4) & 1u);
     }
   }
 
@@ -1130,16 +1229,13 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
   const bool done = ie[CG_I_STEP_NUM] > P.c.episode_limit;
   if (dirty || (ie[CG_I_STEP_NUM] % P.c.evolve_period) == 0) evolve(e, P);
   if (ng == 0) {   // :1330 rebuild of the cached busy set
-    for (int d = lane; d < M; d += WAVE) {
-      uint8_t f = e.flags[d];
-      e.flags[d] = e.busy[d] > 0 ? (uint8_t)(f | CG_F_BUSYC) : (uint8_t)(f & ~CG_F_BUSYC);
-    }
+    for (int w = lane; w < NW; w += WAVE) F[w] = (F[w] & ~(ONES * CG_F_BUSYC)) | (nz01(Bz[w]) << 6);
   }
   wsync();
   ie[CG_I_RNG_TICK] += 1;
   ie[CG_I_LAST_ATYPE] = last_atype;
   ie[CG_I_LOG_TOTAL] = e.log_total;
-  ie[CG_I_FLAGS] = wave_or(e.eflags);
+  ie[CG_I_FLAGS] = e.eflags | (__any(e.eflags & CG_E_BUSY_SAT) ? CG_E_BUSY_SAT : 0);
 
   if (lane == 0) {
     P.o.raw[env] = raw;
@@ -1171,7 +1267,8 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
   if (vec) {
     for (int i = lane; i < items; i += WAVE) ((uint4*)(P.b.live + so))[i] = ((const uint4*)e.flags)[i];
   } else {
-    for (int i = lane; i < 4 * M; i += WAVE) P.b.live[so + i] = e.flags[i];
+    for (int pl = 0; pl < 4; ++pl)
+      for (int i = lane; i < M; i += WAVE) P.b.live[so + pl * M + i] = e.flags[pl * MS + i];
   }
   if (e.blk_dirty) for (int w = lane; w < P.t.EW; w += WAVE) P.b.blocked[(size_t)env * P.t.EW + w] = e.blk[w];
   if (e.ring_dirty && lane < CG_LOG_RING)
@@ -1376,8 +1473,9 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // LDS budget: shared blob prefix + WPB per-wave regions.  Prefers staging the in-CSR too.
 static size_t wave_lds_bytes(const DevTopo& t, int max_devs) {
-  size_t w = align_up((size_t)4 * t.M, 16) + (size_t)t.Mp * 8 + (size_t)((t.EW + 3) & ~3) * 4 + CG_LOG_RING * 4 +
-             (size_t)((t.Mp / 32 + 2) & ~1) * 4 + (size_t)t.MC * 8 + align_up((size_t)max_devs * 2, 16);
+  size_t w = align_up((size_t)4 * ((t.M + 3) & ~3), 16) + (size_t)t.Mp * 8 + (size_t)((t.EW + 3) & ~3) * 4 + CG_LOG_RING * 4 +
+             (size_t)((t.Mp / 32 + 2) & ~1) * 4 + (size_t)t.MC * 8 + (size_t)t.Mp * 2 + (size_t)t.Mp +
+             align_up((size_t)max_devs * 2, 16);
   return align_up(w, 16);
 }
 static int choose_launch(cygym_handle* h, int max_devs) {
@@ -1450,6 +1548,11 @@ int cygym_create(const cygym_topology* topo, const cygym_config* cfg, int32_t n_
   t.o_dst = take(M); t.o_vul = take(M); t.o_nap = take(M);
   t.o_iptr = take((size_t)(M + 1) * 2); t.o_icol = take((size_t)(E > 0 ? E : 1) * 2); t.o_ieid = take((size_t)(E > 0 ? E : 1) * 2);
   t.blob_bytes = (int)off;
+  t.multi = 0;   // duplicate (u,v) out-entries? (env._blocked holds pairs, so duplicates share their state)
+  for (int u = 0; u < M && !t.multi; ++u)
+    for (int k = topo->out_ptr[u]; k < topo->out_ptr[u + 1] && !t.multi; ++k)
+      for (int k2 = k + 1; k2 < topo->out_ptr[u + 1]; ++k2)
+        if (topo->out_col[k2] == topo->out_col[k]) { t.multi = 1; break; }
   if (choose_launch(h, M > 8 ? M / 8 : 1) != 0) { delete h; return fail(nullptr, CYGYM_EUNSUPPORTED, "topology does not fit in LDS%s", ""); }
   uint8_t* host = (uint8_t*)calloc(1, off);
   if (!host) { delete h; return fail(nullptr, CYGYM_EINVAL, "out of host memory%s", ""); }
