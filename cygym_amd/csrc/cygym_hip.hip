@@ -67,9 +67,13 @@ struct KParams {
 };
 
 #ifdef CG_STAMPS
+#define SUBSTAMP(k) do { if (P.dbg && e.lane == 0) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); P.dbg[(size_t)e.env * 16 + (k)] = _t; } } while (0)
+#define SUBVAL(k, v) do { if (P.dbg && e.lane == 0) P.dbg[(size_t)e.env * 16 + (k)] = (unsigned long long)(v); } while (0)
 #define STAMP(k) do { if (P.dbg && lane == 0) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); P.dbg[(size_t)env * 16 + (k)] = _t; } } while (0)
 #else
 #define STAMP(k) do {} while (0)
+#define SUBSTAMP(k) do {} while (0)
+#define SUBVAL(k, v) do {} while (0)
 #endif
 
 // ---------------- wave-level helpers ----------------
@@ -137,8 +141,10 @@ struct Env {
   const uint16_t *optr, *ocol;
   const uint8_t *dst, *vul, *nap;
   const float *osv, *ver, *ano;
-  // in-CSR: LDS when it fits, else the global blob (generic pointers)
-  const uint16_t *iptr, *icol, *ieid;
+  // in-CSR: LDS when it fits (in_lds), else the global blob -- two typed pointer sets, no flat loads
+  const uint16_t *iptr_l, *icol_l, *ieid_l;
+  const uint16_t *iptr_g, *icol_g, *ieid_g;
+  bool in_lds;
   uint8_t* stash;    // global [4][M] of this env
   // misc
   int M, MC, MS, lane, env;
@@ -154,6 +160,9 @@ struct Env {
     return cg_draw(seed, env_id, tick, site, a, b);
   }
   __device__ __forceinline__ bool blocked(int slot) const { return (blk[slot >> 5] >> (slot & 31)) & 1u; }
+  __device__ __forceinline__ int iptr(int d) const { return in_lds ? iptr_l[d] : iptr_g[d]; }
+  __device__ __forceinline__ int icol(int k) const { return in_lds ? icol_l[k] : icol_g[k]; }
+  __device__ __forceinline__ int ieid(int k) const { return in_lds ? ieid_l[k] : ieid_g[k]; }
   __device__ __forceinline__ void set_busy(int d, int v) {
     if (v > 255) { v = 255; eflags |= CG_E_BUSY_SAT; }
     busy[d] = (uint8_t)v;
@@ -347,34 +356,43 @@ __device__ __forceinline__ void def_clean(Env& e, const KParams& P, const int16_
 // Actions 6 / 9 (volt_typhoon_env.py:501-511, 1071-1100): pick the r-th incident edge with the
 // wanted blocked state among out-entries (row order) then in-entries (in-row order) of device d,
 // and flip it.  Out-row blocked bits are a contiguous bit range of `blk`, so counting and selecting
-// there are word operations; the in-row is gathered through in_eid with ballots.
-__device__ __forceinline__ bool flip_incident(Env& e, int d, bool want, uint32_t site, int occ_b) {
-  const int o0 = e.optr[d], o1 = e.optr[d + 1];
-  const int i0 = e.iptr[d], i1 = e.iptr[d + 1];
+// there are word operations; the in-row is gathered through in_eid with ballots.  Row bounds and the
+// draw are passed in (prefetched lane-parallel by the caller).
+__device__ __forceinline__ bool flip_incident(Env& e, int d, bool want, uint32_t u, int o0, int o1, int i0, int i1) {
   const int nb = range_popc(e.blk, o0, o1);
   const int n_out = want ? nb : (o1 - o0) - nb;
   int n_in = 0;
-  for (int k0 = i0; k0 < i1; k0 += WAVE) {
+  uint64_t m0 = 0, m1 = 0;   // ballots of the first two in-row chunks are kept for the select
+  for (int k0 = i0, j = 0; k0 < i1; k0 += WAVE, ++j) {
     int k = k0 + e.lane;
-    n_in += __popcll(ballot((k < i1) && (e.blocked(e.ieid[k]) == want)));
+    uint64_t m = ballot((k < i1) && (e.blocked(e.ieid(k)) == want));
+    if (j == 0) m0 = m; else if (j == 1) m1 = m;
+    n_in += __popcll(m);
   }
   const int n = n_out + n_in;
   if (n == 0) return false;
-  int r = (int)cg_index(e.draw(site, d, occ_b), (uint32_t)n);
+  int r = (int)cg_index(u, (uint32_t)n);
   int su, sv, slot;
   if (r < n_out) {
     slot = range_select(e.blk, o0, o1, want, r);
     su = d; sv = e.ocol[slot];
   } else {
     r -= n_out;
-    slot = -1; su = sv = 0;
-    for (int k0 = i0; k0 < i1; k0 += WAVE) {
-      int k = k0 + e.lane;
-      uint64_t m = ballot((k < i1) && (e.blocked(e.ieid[k]) == want));
-      int c = __popcll(m);
-      if (r < c) { int kk = k0 + nth_bit(m, r); slot = e.ieid[kk]; su = e.icol[kk]; sv = d; break; }
-      r -= c;
+    int kk = -1;
+    const int c0 = __popcll(m0), c1 = __popcll(m1);
+    if (r < c0) kk = i0 + nth_bit(m0, r);
+    else if (r < c0 + c1) kk = i0 + WAVE + nth_bit(m1, r - c0);
+    else {
+      r -= c0 + c1;
+      for (int k0 = i0 + 2 * WAVE; k0 < i1; k0 += WAVE) {
+        int k = k0 + e.lane;
+        uint64_t m = ballot((k < i1) && (e.blocked(e.ieid(k)) == want));
+        int c = __popcll(m);
+        if (r < c) { kk = k0 + nth_bit(m, r); break; }
+        r -= c;
+      }
     }
+    slot = e.ieid(kk); su = e.icol(kk); sv = d;
   }
   wsync();
   if (!e.multi) {   // (u,v) occurs once: flip exactly that slot
@@ -400,20 +418,40 @@ __device__ __forceinline__ void def_per_device(Env& e, const KParams& P, int at,
   const int M = e.M;
   if (at == 1) { def_clean(e, P, dev, L, cost, ie, fe, nullptr); return; }
   if (at == 6 || at == 9) {  // sequential over the list: each pick changes the next pool
-    for (int i = e.lane; i < (e.MC * WAVE) / 4; i += WAVE) e.scr[i] = 0;
-    wsync();
+    const uint32_t site = at == 6 ? CG_SITE_PICK_BLOCK : CG_SITE_PICK_UNBLOCK;
+    const bool simple = list_is_simple(e, dev, L);   // no device twice => occurrence number is always 0
     uint8_t* occ = (uint8_t*)e.scr;
+    if (!simple) {
+      for (int i = e.lane; i < (e.MC * WAVE) / 4; i += WAVE) e.scr[i] = 0;
+      wsync();
+    }
     int n_act = 0, n_hit = 0;
-    for (int p = 0; p < L; ++p) {
-      int d = dev[p];
-      if (d < 0 || d >= M) continue;
-      if (e.flags[d] & CG_F_NYA) continue;
-      ++n_act;
-      int b = occ[d];
-      if (flip_incident(e, d, at == 9, at == 6 ? CG_SITE_PICK_BLOCK : CG_SITE_PICK_UNBLOCK, b)) {
-        if (e.lane == 0) occ[d] = (uint8_t)(b + 1);
-        ++n_hit;
-        wsync();
+    for (int p0 = 0; p0 < L; p0 += WAVE) {
+      // lane-parallel prefetch of this block of entries: device, row bounds, the (occurrence 0) draw
+      const int p = p0 + e.lane;
+      int d = -1, o0 = 0, o1 = 0, i0 = 0, i1 = 0;
+      uint32_t u = 0;
+      if (p < L) { d = dev[p]; if (d < 0 || d >= M || (e.flags[d] & CG_F_NYA)) d = -1; }
+      if (d >= 0) {
+        o0 = e.optr[d]; o1 = e.optr[d + 1]; i0 = e.iptr(d); i1 = e.iptr(d + 1);
+        u = e.draw(site, d, 0);
+      }
+      uint64_t am = ballot(d >= 0);
+      n_act += __popcll(am);
+      while (am) {
+        const int q = __builtin_ctzll(am);
+        am &= am - 1;
+        const int dq = __builtin_amdgcn_readlane(d, q);
+        uint32_t uq = (uint32_t)__builtin_amdgcn_readlane((int)u, q);
+        if (!simple) {
+          int b = occ[dq];
+          if (b > 0) uq = e.draw(site, dq, b);
+        }
+        if (flip_incident(e, dq, at == 9, uq, __builtin_amdgcn_readlane(o0, q), __builtin_amdgcn_readlane(o1, q),
+                          __builtin_amdgcn_readlane(i0, q), __builtin_amdgcn_readlane(i1, q))) {
+          ++n_hit;
+          if (!simple) { if (e.lane == 0) occ[dq] += 1; wsync(); }
+        }
       }
     }
     cost += -0.5 * n_act * ds;
@@ -535,6 +573,7 @@ __device__ __forceinline__ void def_per_device(Env& e, const KParams& P, int at,
 // ---------------- attacker ----------------
 #define T_INF 0xFFFFFFFFu
 constexpr int LONG_ROW = 8;
+#define CG_D_FULLROW 0x04  // library-private static bit: the out-row is "every other device, ascending"
 
 // eligibility byte per device, rebuilt per exploit pass: bit0 reachable, bit1 known & vulnerable
 __device__ __forceinline__ bool spread_ok(const uint8_t* el, const uint32_t* T, int v, int s) {
@@ -547,6 +586,26 @@ __device__ __forceinline__ int spread_scan_lane(const Env& e, const uint8_t* el,
   for (int k = from; k < o1; ++k) {
     if (e.blocked(k)) continue;
     if (dc || spread_ok(el, T, e.ocol[k], s)) return k;
+  }
+  return o1;
+}
+// same for a FULL row (slot k <-> device v = k - o0 + (k - o0 >= s)): walk the candidate-device bitmask
+// instead of the row; `cand` holds reach | (known & vulnerable & not compromised at the start)
+__device__ __forceinline__ int spread_scan_full(const Env& e, const uint8_t* el, const uint32_t* T, const uint64_t* cand,
+                                                int s, int from, int o0, int o1) {
+  if (from >= o1) return o1;
+  int v_from = from - o0; if (v_from >= s) ++v_from;
+  for (int w = v_from >> 6; w < e.MC; ++w) {
+    uint64_t m = cand[w];
+    if (w == (v_from >> 6)) m &= ~0ull << (v_from & 63);
+    while (m) {
+      int v = (w << 6) + __builtin_ctzll(m);
+      m &= m - 1;
+      if (v == s) continue;
+      int k = o0 + v - (v > s ? 1 : 0);
+      if (e.blocked(k)) continue;
+      if (spread_ok(el, T, v, s)) return k;
+    }
   }
   return o1;
 }
@@ -566,18 +625,17 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KParams& P, const 
                                                 uint64_t* srcb) {
   const int M = e.M, MC = e.MC, Mp = MC * WAVE;
   uint32_t* T = e.scr;                          // [Mp] first-compromise time (source id + 1)
-  uint16_t* cur = (uint16_t*)(e.scr + Mp);      // [Mp] current pick (slot) of each source, row end = none
-  uint16_t* cntv = cur + Mp;                    // [Mp] log entries of each source
+  uint16_t* cur = (uint16_t*)(e.scr + Mp);      // [Mp] current pick (slot) per source DEVICE, row end = none
+  uint16_t* cntv = cur + Mp;                    // [Mp] log entries per COMPACT source index
   uint8_t* el = e.el;                           // [Mp] eligibility byte per device (this exploit)
-  // long-row sources (uniform list), built once: the source set is a snapshot (:1127)
-  int n_long = 0;
-  for (int c = 0; c < MC; ++c) {
-    int s = c * WAVE + e.lane;
-    bool is_src = (srcb[c] >> e.lane) & 1ull;
-    bool lg = is_src && (e.optr[s + 1] - e.optr[s]) > LONG_ROW;
-    uint64_t lm = ballot(lg);
-    if (lg) e.lsrc[n_long + below(lm)] = (uint16_t)s;
-    n_long += __popcll(lm);
+  uint16_t* slist = e.lsrc;                     // [Mp] the sources in id order (snapshot :1127)
+  uint64_t* cand = (uint64_t*)e.marks;          // [MC] candidate-device bitmask for full rows
+  int n_src = 0;
+#pragma unroll
+  for (int c = 0; c < MC; ++c) {   // the sources in id order (compact list)
+    const uint64_t sm = srcb[c];
+    if ((sm >> e.lane) & 1ull) slist[n_src + below(sm)] = (uint16_t)(c * WAVE + e.lane);
+    n_src += __popcll(sm);
   }
   wsync();
   int zocc = 0;
@@ -595,89 +653,96 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KParams& P, const 
     }
     if (raw < 0 || raw >= P.t.X) continue;
     const uint8_t ebit = (uint8_t)(1u << raw);
-    for (int d = e.lane; d < Mp; d += WAVE) {
+#pragma unroll
+    for (int c = 0; c < MC; ++c) {
+      int d = c * WAVE + e.lane;
       uint8_t f = d < M ? e.flags[d] : 0;
+      uint8_t x = (uint8_t)(((f & CG_F_REACH) ? 1 : 0) | (((f & CG_F_KNOWN) && d < M && (e.vul[d] & ebit)) ? 2 : 0));
       T[d] = (f & CG_F_COMP) ? 0u : T_INF;
-      el[d] = (uint8_t)(((f & CG_F_REACH) ? 1 : 0) | (((f & CG_F_KNOWN) && d < M && (e.vul[d] & ebit)) ? 2 : 0));
+      el[d] = x;
       cur[d] = d < M ? e.optr[d] : 0;
+      uint64_t cm = ballot((x & 1) || ((x & 2) && !(f & CG_F_COMP)));
+      if (e.lane == 0) cand[c] = cm;
     }
     wsync();
+    SUBSTAMP(10);
+    int n_rounds = 0;
     // fix-point rounds: a source re-examines its pick and, if an earlier source took it, resumes the scan
     for (int round = 0; round <= M + 1; ++round) {
-      bool changed = false;
-      for (int c = 0; c < MC; ++c) {
-        const uint64_t sm = srcb[c];
-        if (!sm) continue;
-        int s = c * WAVE + e.lane;
-        bool is_src = (sm >> e.lane) & 1ull;
-        if (is_src) {
-          int o1 = e.optr[s + 1];
-          if (o1 - e.optr[s] <= LONG_ROW) {
-            int k0 = cur[s];
-            int k = spread_scan_lane(e, el, T, s, e.dst[s] & CG_D_DC, k0, o1);
+      ++n_rounds;
+      bool changed = round == 0;
+      for (int b0 = 0; b0 < n_src; b0 += WAVE) {
+        const int i = b0 + e.lane;
+        bool coop = false;
+        int s = 0, o0 = 0, o1 = 0, k0 = 0;
+        uint8_t st = 0;
+        if (i < n_src) {
+          s = slist[i];
+          o0 = e.optr[s]; o1 = e.optr[s + 1]; k0 = cur[s]; st = e.dst[s];
+          const bool dc = st & CG_D_DC;
+          int k = k0;
+          if (o1 - o0 <= LONG_ROW) k = spread_scan_lane(e, el, T, s, dc, k0, o1);
+          else if ((st & CG_D_FULLROW) && !dc) {
+            if (!(k0 < o1 && !e.blocked(k0) && spread_ok(el, T, e.ocol[k0], s)))
+              k = spread_scan_full(e, el, T, cand, s, round == 0 ? k0 : k0 + 1, o0, o1);
+          } else {
+            coop = round == 0 || (k0 < o1 && !(dc || spread_ok(el, T, e.ocol[k0], s)));
+          }
+          if (!coop) {
             if (k != k0) { cur[s] = (uint16_t)k; changed = true; }
-            if (round == 0) changed = true;
             if (k < o1 && (round == 0 || k != k0)) atomicMin(&T[e.ocol[k]], (uint32_t)(s + 1));
           }
         }
-      }
-      // long rows: validity of the current pick checked lane-parallel, rescans wave-cooperative
-      for (int b0 = 0; b0 < n_long; b0 += WAVE) {
-        int i = b0 + e.lane;
-        bool need = false;
-        if (i < n_long) {
-          int s = e.lsrc[i];
-          int k = cur[s], o1 = e.optr[s + 1];
-          if (round == 0) need = true;
-          else if (k < o1) need = !((e.dst[s] & CG_D_DC) || spread_ok(el, T, e.ocol[k], s));
-        }
-        uint64_t nm = ballot(need);
+        uint64_t nm = ballot(coop);   // long rows that are not "full": wave-cooperative (re)scan
         while (nm) {
-          int ls = e.lsrc[b0 + __builtin_ctzll(nm)];
+          const int src_lane = __builtin_ctzll(nm);
           nm &= nm - 1;
-          int k0 = cur[ls], o1 = e.optr[ls + 1];
-          int k = spread_scan_coop(e, el, T, ls, e.dst[ls] & CG_D_DC, round == 0 ? k0 : k0 + 1, o1);
-          changed = changed || (k != k0) || round == 0;
+          const int ls = __shfl(s, src_lane), lo1 = __shfl(o1, src_lane), lk0 = __shfl(k0, src_lane);
+          const int lst = __shfl((int)st, src_lane);
+          int k = spread_scan_coop(e, el, T, ls, lst & CG_D_DC, round == 0 ? lk0 : lk0 + 1, lo1);
+          if (k != lk0) changed = true;
           if (e.lane == 0) {
             cur[ls] = (uint16_t)k;
-            if (k < o1) atomicMin(&T[e.ocol[k]], (uint32_t)(ls + 1));
+            if (k < lo1) atomicMin(&T[e.ocol[k]], (uint32_t)(ls + 1));
           }
         }
       }
       wsync();
       if (!__any(changed)) break;
     }
+    SUBSTAMP(11);
+    SUBVAL(15, n_rounds);
     // log entries of every source: unblocked out-entries up to and including its pick
     int total_new = 0;
-    for (int c = 0; c < MC; ++c) {
-      const uint64_t sm = srcb[c];
-      int s = c * WAVE + e.lane;
+    for (int b0 = 0; b0 < n_src; b0 += WAVE) {
+      const int i = b0 + e.lane;
       int n = 0;
-      if ((sm >> e.lane) & 1ull) {
+      if (i < n_src) {
+        int s = slist[i];
         int o0 = e.optr[s], o1 = e.optr[s + 1];
         int end = cur[s] < o1 ? cur[s] + 1 : o1;
         n = (end - o0) - range_popc(e.blk, o0, end);
       }
-      cntv[s] = (uint16_t)n;
-      if (sm) total_new += wave_sum(n);
+      cntv[i < Mp ? i : 0] = (uint16_t)n;
+      total_new += wave_sum(n);
     }
     wsync();
+    SUBSTAMP(12);
     // ring: only the last CG_LOG_RING entries (global order: source id, then row order) matter
     if (total_new > 0) {
       const uint32_t base = (uint32_t)e.log_total;
       const uint32_t end = base + (uint32_t)total_new;
       const uint32_t lo = end > CG_LOG_RING ? end - CG_LOG_RING : 0;
-      // walk chunks from the top: only the tail sources write
-      uint32_t after = end;   // global index just past the current chunk
-      for (int c = MC - 1; c >= 0 && after > lo; --c) {
-        if (!srcb[c]) continue;
-        int s = c * WAVE + e.lane;
-        int n = cntv[s];
+      uint32_t after = end;   // global index just past the current block of sources
+      for (int b0 = ((n_src - 1) / WAVE) * WAVE; b0 >= 0 && after > lo; b0 -= WAVE) {
+        const int i = b0 + e.lane;
+        int n = i < n_src ? cntv[i] : 0;
         int incl = wave_incl_scan(n, e.lane);
-        int chunk_total = __shfl(incl, 63);
-        uint32_t cbase = after - (uint32_t)chunk_total;
+        int blk_total = __shfl(incl, 63);
+        uint32_t cbase = after - (uint32_t)blk_total;
         uint32_t off = cbase + (uint32_t)(incl - n);
         bool mine = n > 0 && off + (uint32_t)n > lo;
+        int s = mine ? (int)slist[i] : 0;
         bool is_long = mine && (e.optr[s + 1] - e.optr[s]) > LONG_ROW;
         if (mine && !is_long) {
           uint32_t idx = off;
@@ -693,7 +758,7 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KParams& P, const 
         while (lm) {
           int ll = __builtin_ctzll(lm);
           lm &= lm - 1;
-          int ls = c * WAVE + ll;
+          int ls = __shfl(s, ll);
           uint32_t idx0 = __shfl(off, ll);
           int o0 = e.optr[ls], o1 = e.optr[ls + 1];
           int last = cur[ls] < o1 ? (int)cur[ls] : o1 - 1;
@@ -712,16 +777,16 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KParams& P, const 
       e.ring_dirty = true;
     }
     wsync();
+    SUBSTAMP(13);
     // apply: compromise flags + DC attribution (:1163-1185)
     for (int d = e.lane; d < M; d += WAVE)
       if (T[d] != T_INF && T[d] != 0u) e.flags[d] |= CG_F_COMP;
-    wsync();
-    for (int c = 0; c < MC; ++c) {
-      const uint64_t sm = srcb[c];
-      int s = c * WAVE + e.lane;
-      if (((sm >> e.lane) & 1ull) && (e.dst[s] & CG_D_DC) && cur[s] < e.optr[s + 1]) byte_or(e.cby, e.ocol[cur[s]], ebit);
+    for (int i = e.lane; i < n_src; i += WAVE) {
+      int s = slist[i];
+      if ((e.dst[s] & CG_D_DC) && cur[s] < e.optr[s + 1]) byte_or(e.cby, e.ocol[cur[s]], ebit);
     }
     wsync();
+    SUBSTAMP(14);
   }
 }
 
@@ -896,7 +961,9 @@ __device__ __forceinline__ void evolve(Env& e, const KParams& P) {
     e.eflags |= CG_E_EVO_INIT;
     wsync();
   }
-  int n_ev = cg_cdf_lookup(e.draw(CG_SITE_EVO_POISSON, 0, 0), P.c.poisson_thr, CG_POISSON_TABLE);
+  int n_ev = 0;
+  if (P.c.poisson_thr[0] < (1ull << 32))   // lambda_events == 0: the table says "always zero events"
+    n_ev = cg_cdf_lookup(e.draw(CG_SITE_EVO_POISSON, 0, 0), P.c.poisson_thr, CG_POISSON_TABLE);
   bool any_new = false;
   uint32_t* newly = e.marks;   // bit per device
   if (n_ev > 0) {
@@ -969,7 +1036,7 @@ __device__ __forceinline__ void evolve(Env& e, const KParams& P) {
     for (int c = 0; c < MC; ++c) {
       int d = c * WAVE + e.lane;
       if (d < M && ((newly[d >> 5] >> (d & 31)) & 1u) && !(e.flags[d] & (CG_F_NYA | CG_F_OWNED))) {
-        int deg = (e.optr[d + 1] - e.optr[d]) + (e.iptr[d + 1] - e.iptr[d]);
+        int deg = (e.optr[d + 1] - e.optr[d]) + (e.iptr(d + 1) - e.iptr(d));
         if (deg < 1) iso = true;
       }
     }
@@ -979,10 +1046,12 @@ __device__ __forceinline__ void evolve(Env& e, const KParams& P) {
 }
 
 // ---------------- the tick ----------------
-template <int WPB>
+// MT: devices per env when known at compile time (64, 256: chunk loops unroll and their LDS latencies
+// overlap), 0 = any M at run time.
+template <int WPB, int MT>
 __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
   extern __shared__ __align__(16) uint8_t smem[];
-  const int M = P.t.M, MC = P.t.MC, Mp = MC * WAVE, MS = (M + 3) & ~3;
+  const int M = MT ? MT : P.t.M, MC = MT ? (MT + WAVE - 1) / WAVE : P.t.MC, Mp = MC * WAVE, MS = (M + 3) & ~3;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int env = uni(blockIdx.x * WPB + wave);
   const bool live = env < P.n_envs;
@@ -1003,10 +1072,9 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
   e.optr = (const uint16_t*)(smem + P.t.o_optr); e.ocol = (const uint16_t*)(smem + P.t.o_ocol);
   e.osv = (const float*)(smem + P.t.o_os); e.ver = (const float*)(smem + P.t.o_ver); e.ano = (const float*)(smem + P.t.o_ano);
   e.dst = smem + P.t.o_dst; e.vul = smem + P.t.o_vul; e.nap = smem + P.t.o_nap;
-  {
-    const uint8_t* ib = P.t.in_lds ? (const uint8_t*)smem : P.t.blob;
-    e.iptr = (const uint16_t*)(ib + P.t.o_iptr); e.icol = (const uint16_t*)(ib + P.t.o_icol); e.ieid = (const uint16_t*)(ib + P.t.o_ieid);
-  }
+  e.in_lds = P.t.in_lds != 0;
+  e.iptr_l = (const uint16_t*)(smem + P.t.o_iptr); e.icol_l = (const uint16_t*)(smem + P.t.o_icol); e.ieid_l = (const uint16_t*)(smem + P.t.o_ieid);
+  e.iptr_g = (const uint16_t*)(P.t.blob + P.t.o_iptr); e.icol_g = (const uint16_t*)(P.t.blob + P.t.o_icol); e.ieid_g = (const uint16_t*)(P.t.blob + P.t.o_ieid);
   e.M = M; e.MC = MC; e.MS = MS; e.lane = lane; e.env = env;
   e.cbits = 32 - __builtin_clz((unsigned)(4 * ((MS / 4 + WAVE - 1) / WAVE)));
   e.env_id = (uint32_t)(P.c.env_id_base + env);
@@ -1024,6 +1092,9 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
   int mode = 0, ng = 0, at0 = 8, cnt0 = 0, nexp0 = 0, app0 = -1;
   uint4 r0 = make_uint4(0, 0, 0, 0);
   uint32_t ringw = 0;
+  constexpr int PF_BLK = 2, PF_DEV = 1;   // words / list entries per lane prefetched into registers
+  uint32_t bw[PF_BLK];
+  int16_t dv[PF_DEV];
   const bool vec = (M & 3) == 0;
   const int items = M >> 2;   // uint4 items of the [4][M] live block when M % 4 == 0
   if (live) {
@@ -1041,6 +1112,10 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
     app0 = P.a.app[(size_t)env * G];
     if (vec && lane < items) r0 = ((const uint4*)g_live)[lane];
     if (lane < CG_LOG_RING) ringw = ((const uint32_t*)(P.b.ring + (size_t)env * CG_LOG_RING * 2))[lane];
+#pragma unroll
+    for (int j = 0; j < PF_BLK; ++j) { int w = lane + j * WAVE; bw[j] = w < P.t.EW ? P.b.blocked[(size_t)env * P.t.EW + w] : 0u; }
+#pragma unroll
+    for (int j = 0; j < PF_DEV; ++j) { int q = lane + j * WAVE; dv[j] = q < L ? P.a.dev_idx[(size_t)env * L + q] : (int16_t)0; }
   }
   // ---- workgroup-shared topology blob -> LDS (16-byte copies, two in flight per thread) ----
   {
@@ -1064,9 +1139,13 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
     }
     if (lane < CG_LOG_RING) ((uint32_t*)e.ring)[lane] = ringw;
     const uint32_t* gb = P.b.blocked + (size_t)env * P.t.EW;
-    for (int w = lane; w < P.t.EW; w += WAVE) e.blk[w] = gb[w];
+#pragma unroll
+    for (int j = 0; j < PF_BLK; ++j) { int w = lane + j * WAVE; if (w < P.t.EW) e.blk[w] = bw[j]; }
+    for (int w = lane + PF_BLK * WAVE; w < P.t.EW; w += WAVE) e.blk[w] = gb[w];
     const int16_t* gd = P.a.dev_idx + (size_t)env * L;
-    for (int p = lane; p < L; p += WAVE) e.devl[p] = gd[p];
+#pragma unroll
+    for (int j = 0; j < PF_DEV; ++j) { int q = lane + j * WAVE; if (q < L) e.devl[q] = dv[j]; }
+    for (int q = lane + PF_DEV * WAVE; q < L; q += WAVE) e.devl[q] = gd[q];
   }
   __syncthreads();   // the only workgroup barrier: waves diverge per env from here on
   if (!live) return;
@@ -1103,6 +1182,7 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
       if (at == 1 || at == 4 || at == 5 || at == 6 || at == 7 || at == 9 || at == 12 || at == 13)
         if (Ld > 0) def_per_device(e, P, at, devs, Ld, app0, cost, dirty, ie, fe);
     } else if (P.c.baseline != 3 && (at == 1 || at == 2)) {
+#pragma unroll
       for (int c = 0; c < MC; ++c) {   // :1127 snapshot of the sources
         int d = c * WAVE + lane;
         uint64_t m = ballot(d < M && (e.flags[d] & (CG_F_COMP | CG_F_OWNED)));
@@ -1464,6 +1544,26 @@ static int fail(cygym_handle* h, int code, const char* fmt, const char* detail) 
     if (_e != hipSuccess) return fail(h, CYGYM_EHIP, #call ": %s", hipGetErrorString(_e)); \
   } while (0)
 
+template <int MT>
+static const void* kernel_for(int wpb) {
+  switch (wpb) {
+    case 16: return (const void*)step_kernel<16, MT>;
+    case 8: return (const void*)step_kernel<8, MT>;
+    case 4: return (const void*)step_kernel<4, MT>;
+    case 2: return (const void*)step_kernel<2, MT>;
+    default: return (const void*)step_kernel<1, MT>;
+  }
+}
+static const void* pick_kernel(const cygym_handle* h) {
+  if (h->t.M == 256) return kernel_for<256>(h->wpb);
+  if (h->t.M == 64) return kernel_for<64>(h->wpb);
+  return kernel_for<0>(h->wpb);
+}
+static hipError_t set_lds_attr(cygym_handle* h) {
+  const int lds = h->shared_lds + h->wave_lds * h->wpb;
+  return hipFuncSetAttribute(pick_kernel(h), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+}
+
 extern "C" {
 
 int cygym_version(void) { return CYGYM_ABI_VERSION; }
@@ -1496,17 +1596,6 @@ static int choose_launch(cygym_handle* h, int max_devs) {
     }
   }
   return -1;
-}
-
-static hipError_t set_lds_attr(cygym_handle* h) {
-  const int lds = h->shared_lds + h->wave_lds * h->wpb;
-  switch (h->wpb) {
-    case 16: return hipFuncSetAttribute((const void*)step_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    case 8: return hipFuncSetAttribute((const void*)step_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    case 4: return hipFuncSetAttribute((const void*)step_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    case 2: return hipFuncSetAttribute((const void*)step_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    default: return hipFuncSetAttribute((const void*)step_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  }
 }
 
 int cygym_create(const cygym_topology* topo, const cygym_config* cfg, int32_t n_envs, int32_t device_id,
@@ -1557,6 +1646,13 @@ int cygym_create(const cygym_topology* topo, const cygym_config* cfg, int32_t n_
   uint8_t* host = (uint8_t*)calloc(1, off);
   if (!host) { delete h; return fail(nullptr, CYGYM_EINVAL, "out of host memory%s", ""); }
   memcpy(host + t.o_dst, topo->dstatic, M); memcpy(host + t.o_vul, topo->vuln, M); memcpy(host + t.o_nap, topo->napps, M);
+  for (int u = 0; u < M; ++u) {   // library-private static bit: out-row == every other device, ascending
+    host[t.o_dst + u] &= (uint8_t)(CG_D_DC | CG_D_SERVER);
+    if (topo->out_ptr[u + 1] - topo->out_ptr[u] != M - 1) continue;
+    bool full = true;
+    for (int j = 0; j < M - 1 && full; ++j) full = topo->out_col[topo->out_ptr[u] + j] == j + (j >= u ? 1 : 0);
+    if (full) host[t.o_dst + u] |= 0x04;
+  }
   memcpy(host + t.o_os, topo->os_val, (size_t)M * 4); memcpy(host + t.o_ver, topo->version, (size_t)M * 4);
   memcpy(host + t.o_ano, topo->anomaly, (size_t)M * 4);
   for (int i = 0; i <= M; ++i) { ((uint16_t*)(host + t.o_optr))[i] = (uint16_t)topo->out_ptr[i]; ((uint16_t*)(host + t.o_iptr))[i] = (uint16_t)topo->in_ptr[i]; }
@@ -1690,12 +1786,9 @@ int cygym_step(cygym_handle* h, const cygym_actions* a, const cygym_outputs* o, 
   const int lds = h->shared_lds + h->wave_lds * h->wpb;
   const dim3 grid((h->n_envs + h->wpb - 1) / h->wpb), block(h->wpb * WAVE);
   hipStream_t s = (hipStream_t)stream;
-  switch (h->wpb) {
-    case 16: hipLaunchKernelGGL(step_kernel<16>, grid, block, lds, s, P); break;
-    case 8: hipLaunchKernelGGL(step_kernel<8>, grid, block, lds, s, P); break;
-    case 4: hipLaunchKernelGGL(step_kernel<4>, grid, block, lds, s, P); break;
-    case 2: hipLaunchKernelGGL(step_kernel<2>, grid, block, lds, s, P); break;
-    default: hipLaunchKernelGGL(step_kernel<1>, grid, block, lds, s, P); break;
+  {
+    void* args[] = {(void*)&P};
+    HIPCHK(h, hipLaunchKernel(pick_kernel(h), grid, block, args, (size_t)lds, s));
   }
   HIPCHK(h, hipGetLastError());
   return CYGYM_OK;

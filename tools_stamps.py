@@ -34,6 +34,13 @@ for t in range(40):
     print(f"tick {t} mode {int(d[0, 9])}: wave lifetime cycles mean {tot.mean():.0f} p50 {np.median(tot):.0f} p99 {np.percentile(tot, 99):.0f} max {tot.max()}  "
           f"span(first start..last end) {st[:, 7].max() - st[:, 0].min()}")
     print("   mean per phase:", {n: int(seg[:, i].mean()) for i, n in enumerate(names)})
+    if int(d[0, 9]) == 1:
+        m = at == 1
+        if m.any():
+            sub = d[m]
+            print("   spread sub-phases (mean cycles): setup", int((sub[:, 10] - sub[:, 1]).mean()), "rounds", int((sub[:, 11] - sub[:, 10]).mean()),
+                  "logcnt", int((sub[:, 12] - sub[:, 11]).mean()), "ring", int((sub[:, 13] - sub[:, 12]).mean()),
+                  "apply", int((sub[:, 14] - sub[:, 13]).mean()), " n_rounds mean", sub[:, 15].mean(), "max", sub[:, 15].max())
     for a in sorted(set(at.tolist())):
         m = at == a
         print(f"   atype {int(a):3d}: n={int(m.sum()):5d} total mean {tot[m].mean():8.0f} max {tot[m].max():8d}  action-phase mean {seg[m, 1].mean():8.0f} max {seg[m, 1].max():8d}")
