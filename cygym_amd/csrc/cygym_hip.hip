@@ -1148,7 +1148,7 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
     for (int q = lane + PF_DEV * WAVE; q < L; q += WAVE) e.devl[q] = gd[q];
   }
   __syncthreads();   // the only workgroup barrier: waves diverge per env from here on
-  if (!live) return;
+  if (!live || ng < 0) return;   // n_groups < 0: this env does not tick (per-env stepping inside a batch)
   STAMP(1);
 
   e.tick = (uint32_t)ie[CG_I_RNG_TICK];

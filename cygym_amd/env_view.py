@@ -1,0 +1,271 @@
+"""CyberDefenseEnvView: the reference's per-env Gym-style surface over one slot of a
+BatchedCyberDefenseEnv, so the reference's rollout loops can drive the HIP kernels
+unchanged.
+
+Mirrors `Volt_Typhoon_CyberDefenseEnv` (volt_typhoon_env.py) / `CyberDefenseEnv`
+(CyberDefenseEnv.py): same method names, argument meaning, return shapes and error
+behaviour.  Every tick runs in the HIP kernel; this class only marshals.
+
+    env = CyberDefenseEnvView(batch, index=0)
+    env.mode = "defender"
+    state, raw, shaped, done, info, logs = env.step((1, [0], [3, 7], 0))
+
+Batch-wide vs per-env: scalar knobs (`base_line`, `comp_scale`, `work_scale`, ...) live
+in the handle's config and therefore apply to every env of the batch; counters, flags
+and `mode` are per env.
+"""
+from __future__ import annotations
+
+import dataclasses
+import random
+
+import numpy as np
+import torch
+
+from . import abi, host_logic as HL
+from . import spec as S
+
+
+class Discrete:
+    """Stand-in for gym.spaces.Discrete (n, sample, contains)."""
+
+    def __init__(self, n):
+        self.n = int(n)
+
+    def sample(self):
+        return random.randrange(self.n)
+
+    def contains(self, x):
+        return 0 <= int(x) < self.n
+
+    def __repr__(self):
+        return f"Discrete({self.n})"
+
+
+class Box:
+    def __init__(self, low, high, shape, dtype=np.float32):
+        self.low, self.high, self.shape, self.dtype = low, high, tuple(shape), dtype
+
+
+_COUNTER_COLS = {
+    "step_num": S.I_STEP_NUM, "defender_step": S.I_DEF_STEP, "attacker_step": S.I_ATT_STEP,
+    "work_done": S.I_WORK_DONE, "checkpoint_count": S.I_CKPT_CNT, "revert_count": S.I_REVERT_CNT,
+    "scan_cnt": S.I_SCAN_CNT, "compromised_devices_cnt": S.I_COMP_CNT, "edges_blocked": S.I_EDGES_BLOCKED,
+    "edges_added": S.I_EDGES_ADDED,
+}
+_FLOAT_COLS = {"defensive_cost": S.D_DEF_COST, "clearning_cost": S.D_CLEAN_COST}
+_CONFIG_ATTRS = {"comp_scale", "work_scale", "def_scale", "lambda_events", "p_add", "p_attacker",
+                 "workload_cap", "zero_day", "fast_scan", "scaling_vulnerability"}
+
+
+class CyberDefenseEnvView:
+    def __init__(self, batch, index: int = 0):
+        object.__setattr__(self, "_b", batch)
+        object.__setattr__(self, "_i", int(index))
+        if not (0 <= self._i < batch.N):
+            raise IndexError("env index out of range")
+        self.mode = None                     # CyberDefenseEnv.py:31
+        self.state = self._get_state()
+        self.debug = False
+        self.tech = "DO"
+        self.snapshot_path = None
+        self.private_exploit_id = None
+        self.prior_pi = None
+        self.time_budget_deadline = None
+        self.time_budget_exceeded = None
+        self.time_budget_seconds = 2.592e12
+
+    # ---- attribute surface -------------------------------------------------
+    def __getattr__(self, name):
+        b = object.__getattribute__(self, "_b")
+        i = object.__getattribute__(self, "_i")
+        if name in _COUNTER_COLS:
+            return int(b.state["ienv"][i, _COUNTER_COLS[name]].item())
+        if name in _FLOAT_COLS:
+            return float(b.state["fenv"][i, _FLOAT_COLS[name]].item())
+        if name == "base_line":
+            return b.cfg.baseline
+        if name in _CONFIG_ATTRS:
+            v = getattr(b.cfg, name)
+            if name == "workload_cap":
+                return None if v < 0 else v
+            return bool(v) if name in ("zero_day", "fast_scan", "scaling_vulnerability") else v
+        if name == "γ":
+            return b.cfg.gamma
+        if name == "Max_network_size":
+            return b.M
+        if name == "numOfDevice":
+            return b.cfg.num_of_device
+        if name == "Min_network_size":
+            return b.cfg.min_network_size
+        if name == "MaxExploits":
+            return b.cfg.max_exploits
+        if name == "defender_action_space":
+            return Discrete(b.cfg.n_def_actions)
+        if name == "attacker_action_space":
+            return Discrete(b.cfg.n_att_actions)
+        if name == "observation_space":
+            return Box(low=0, high=1, shape=(b.M * 6,), dtype=np.float32)
+        raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        b = object.__getattribute__(self, "_b")
+        i = object.__getattribute__(self, "_i")
+        if name in _COUNTER_COLS:
+            b.state["ienv"][i, _COUNTER_COLS[name]] = int(value)
+        elif name in _FLOAT_COLS:
+            b.state["fenv"][i, _FLOAT_COLS[name]] = float(value)
+        elif name == "base_line":
+            if value not in abi.BASELINES:
+                raise ValueError(f"unknown base_line {value!r}")
+            b.set_config(dataclasses.replace(b.cfg, baseline=value))
+        elif name in _CONFIG_ATTRS:
+            if name == "workload_cap":
+                value = -1 if value is None else int(value)
+            elif name in ("zero_day", "fast_scan", "scaling_vulnerability"):
+                value = int(bool(value))
+            b.set_config(dataclasses.replace(b.cfg, **{name: value}))
+        elif name == "γ":
+            b.set_config(dataclasses.replace(b.cfg, gamma=float(value)))
+        elif name == "numOfDevice":
+            b.set_config(dataclasses.replace(b.cfg, num_of_device=int(value)))
+        elif name in ("Max_network_size", "MaxExploits"):
+            if int(value) != getattr(self, name):
+                raise ValueError(f"{name} is fixed by the topology of the batch")
+        else:
+            object.__setattr__(self, name, value)
+
+    # ---- small helpers of the reference -----------------------------------
+    def get_num_action_types(self, mode=None):           # volt_typhoon_env.py:514-520
+        if mode == "defender":
+            return 14
+        if mode == "attacker":
+            return 3
+        raise ValueError("Invalid mode: must be either 'defender' or 'attacker'")
+
+    def get_device_indices(self):                        # :522
+        return list(range(self._b.M))
+
+    def get_num_exploit_indices(self):                   # :525
+        return self._b.topo.X
+
+    def get_num_app_indices(self):                       # :528-533 (unique app ids: every device has its own)
+        return int(self._b.topo.napps.astype(np.int64).sum())
+
+    def seed(self, seed=None):
+        return [seed]
+
+    def _flags(self) -> np.ndarray:
+        return self._b.state["flags"][self._i].cpu().numpy()
+
+    def sample_action(self):                             # CyberDefenseEnv.py:555-578
+        if self.mode == "defender":
+            at = self.defender_action_space.sample()
+        elif self.mode == "attacker":
+            at = self.attacker_action_space.sample()
+        else:
+            raise ValueError("Invalid mode")
+        devs = random.sample(list(range(self._b.M)), k=random.randint(1, max(1, self.numOfDevice)))
+        exploit_indices = np.array([random.randrange(self.MaxExploits)], dtype=int)
+        n_apps = self.get_num_app_indices()
+        app_index = random.randint(0, n_apps - 1) if n_apps > 0 else 0
+        return (at, exploit_indices, devs, app_index)
+
+    # ---- observations (CyberDefenseEnv.py:146-257) --------------------------
+    def _obs(self, role):
+        return self._b.observe(role)[self._i].cpu().numpy()
+
+    def _get_state(self):
+        return self._obs(0).astype(np.float64)
+
+    def _get_defender_state(self):
+        return self._obs(1).astype(np.float64)
+
+    def _get_attacker_state(self):
+        return self._obs(2).astype(np.float32)
+
+    def _get_ordered_devices(self):
+        raise NotImplementedError("the object facade over the SoA (SURVEY.md 8f rank 2) is not built yet")
+
+    # ---- episode control -----------------------------------------------------
+    def initialize_environment(self):
+        """The network was built when the batch was created; re-arm this env from the snapshot."""
+        return self.reset(from_init=True)
+
+    def reset(self, from_init=True, *args, **kwargs):   # volt_typhoon_env.py:1904
+        self._b.reset([self._i])
+        self.state = self._get_state()
+        return self.state
+
+    def randomize_compromise_and_ownership(self):        # :330-383
+        self._b.randomize([self._i])
+
+    # ---- the tick -------------------------------------------------------------
+    def _launch(self, groups, grouped):
+        b, i = self._b, self._i
+        act = {k: v.cpu().numpy() for k, v in b.act.items()}
+        act["n_groups"][:] = -1                          # every other env of the batch stays put
+        HL.encode_into(act, i, self.mode, groups, grouped, b.M)
+        b.set_actions_numpy(act)
+        obs, raw, shaped, done = b.step()
+        torch.cuda.synchronize(b.device)
+        self.state = obs[i].reshape(-1).cpu().numpy().astype(np.float64)
+        return float(raw[i].item()), float(shaped[i].item()), bool(done[i].item())
+
+    def _info(self, action_taken, executed=None, grouped=False):
+        ie = self._b.state["ienv"][self._i].cpu().numpy()
+        fe = self._b.state["fenv"][self._i].cpu().numpy()
+        # step() builds info before step_num += 1 (:1272 vs :1308), step_grouped after (:751 vs :759)
+        info = {
+            "mode": self.mode, "step_count": int(ie[S.I_STEP_NUM]) - (0 if grouped else 1),
+            "revert_count": int(ie[S.I_REVERT_CNT]),
+            "checkpoint_count": int(ie[S.I_CKPT_CNT]), "defensive_cost": float(fe[S.D_DEF_COST]),
+            "clearning_cost": float(fe[S.D_CLEAN_COST]), "Scan_count": int(ie[S.I_SCAN_CNT]),
+            "action_taken": action_taken, "work_done": int(ie[S.I_WORK_DONE]),
+            "Compromised_devices": int(ie[S.I_COMP_CNT]), "Edges Blocked": int(ie[S.I_EDGES_BLOCKED]),
+            "Edges Added": int(ie[S.I_EDGES_ADDED]),
+        }
+        if executed is not None:
+            info["executed_atype"] = executed
+        return info
+
+    def _logs(self):
+        ie = self._b.state["ienv"][self._i]
+        total = int(ie[S.I_LOG_TOTAL].item())
+        ring = self._b.state["ring"][self._i].cpu().numpy().view(np.uint16).reshape(S.LOG_RING, 2)
+        n = min(total, S.LOG_RING)
+        out = []
+        for j in range(total - n, total):
+            f, t = ring[j % S.LOG_RING]
+            out.append({"time_step": 0, "from_device": int(f), "to_device": int(t), "kind": "A"})
+        return out
+
+    def step(self, action, agent_cnt=None):              # volt_typhoon_env.py:818
+        if agent_cnt is not None and agent_cnt != self._b.M:
+            raise NotImplementedError("agent_cnt != number of devices (partial tick, :1207) is not built")
+        if HL.is_grouped(action):
+            return self.step_grouped(action)
+        if action is None:
+            action = HL.default_action(self.mode, self.base_line, self._flags())
+        cfg = self._b.cfg
+        norm = HL.validate_single(self.mode, cfg.baseline, action, self._b.M, cfg.n_def_actions, cfg.n_att_actions)
+        raw, shaped, done = self._launch([norm], grouped=False)
+        executed = int(self._b.state["ienv"][self._i, S.I_LAST_ATYPE].item())
+        return self.state, raw, shaped, done, self._info(action, executed), self._logs()
+
+    def step_grouped(self, groups):                      # :694-779
+        assert isinstance(groups, (list, tuple)) and len(groups) > 0
+        HL.mode_code(self.mode)
+        norm = []
+        for g in groups:
+            at, ex, dv, app = g
+            dv = HL._as_list(dv)
+            for d in dv:                                  # :670-671 indexes every listed device
+                if not (0 <= d < self._b.M):
+                    raise KeyError(d)
+            eff = 8 if (self.mode == "defender" and int(at) == 0) else int(at)
+            if self.mode == "defender" and self.base_line == "Nash" and eff == 11 and len(dv) == 0:
+                raise ValueError("Action 11 requires exactly one device index")
+            norm.append((int(at), HL._as_list(ex), dv, HL.app_index_value(app)))
+        raw, shaped, done = self._launch(norm, grouped=True)
+        return self.state, raw, shaped, done, self._info(groups, grouped=True), self._logs()

@@ -121,7 +121,8 @@ typedef struct cygym_buffers {
  * app_index) or a list of such tuples (volt_typhoon_env.py:818, 842-876). */
 typedef struct cygym_actions {
   const int32_t* mode;      /* [N] CG_MODE_*  (env.mode)                        */
-  const int32_t* n_groups;  /* [N] 0: step(action); g>0: step_grouped(g groups) */
+  const int32_t* n_groups;  /* [N] 0: step(action); g>0: step_grouped(g groups);
+                               <0: this env does not tick (its state and outputs stay) */
   const int32_t* atype;     /* [N][G]                                           */
   const int32_t* n_exploit; /* [N][G]                                           */
   const int32_t* exploit;   /* [N][G][CG_MAX_EXPLOITS]                          */

@@ -545,6 +545,7 @@ static void step_one(env_t* e, const cygym_actions* a, const cygym_outputs* o, i
   e->tick = (uint32_t)e->ienv[CG_I_RNG_TICK];
   const int mode = a->mode[idx];
   const int ng = a->n_groups[idx];
+  if (ng < 0) return; /* this env does not tick */
   const int16_t* devs = a->dev_idx + (size_t)idx * L;
   double cost = 0.0;
   int dirty = 0;

@@ -148,6 +148,23 @@ def s16_baselines():
     return res, 1
 
 
+@scenario("s16_none")
+def s16_none():
+    """action=None: the reference's baseline defaults by mode x base_line (:847-874)."""
+    M = 16
+    res = []
+    for i, bl in enumerate(["Nash", "No Defense", "No Attack", "Preset"]):
+        env0 = H.build_env(M, 12, init_seed=55, strip_vuln_frac=0.3, overrides=dict(base_line=bl))
+        base = mixed_actions(M, ALL_DEF, ALL_ATT, 4)
+
+        def fn(e, t, env, rs, base=base):
+            mode, a = base(e, t, env, rs)
+            return mode, (None if rs.rand() < 0.6 else a)
+        r = H.run_scenario(env0, 1, 80, fn, seed=24, env_id_base=10 + i)
+        res.append((bl, r))
+    return res, 1
+
+
 @scenario("s600_sparse")
 def s600_sparse():
     """len(net) > 500: sparse attacker connect (:1344) and the lazy workload path (CDSimulator.py:325)."""

@@ -631,9 +631,14 @@ def encode_actions(acts, M, max_groups=1):
     expl = np.full((T, G, S.MAX_EXPLOITS), -1, np.int32)
     app = np.full((T, G), -1, np.int32)
     dev_cnt = np.zeros((T, G), np.int32)
+    is_none = np.zeros(T, np.int32)
     dev_flat = []
     for t, (m, a) in enumerate(acts):
         mode[t] = m
+        if a is None:                     # the reference substitutes a default (:847-874); the build's
+            is_none[t] = 1                # host logic must do the same -- only the marker is stored
+            atype[t, 0] = 8
+            continue
         groups = a if (isinstance(a, (list, tuple)) and a and isinstance(a[0], (list, tuple))) else [a]
         grouped = groups is a
         ng[t] = len(groups) if grouped else 0      # 0 => single-action step()
@@ -650,7 +655,7 @@ def encode_actions(acts, M, max_groups=1):
             dev_flat.extend(dv)
             app[t, g] = int(ap) if isinstance(ap, int) and not isinstance(ap, bool) else -1
     return dict(mode=mode, n_groups=ng, atype=atype, n_exploit=nexp, exploit=expl, app=app,
-                dev_cnt=dev_cnt, dev_flat=np.asarray(dev_flat, np.int32))
+                dev_cnt=dev_cnt, is_none=is_none, dev_flat=np.asarray(dev_flat, np.int32))
 
 
 def save_fixture(path, result, max_groups=1):
@@ -673,7 +678,7 @@ def save_fixture(path, result, max_groups=1):
     for k in ["raw", "shaped", "done", "obs", "obs_def", "obs_att", "topo_same"]:
         out[f"exp_{k}"] = np.stack([np.stack([np.asarray(tk[k]) for tk in e["ticks"]]) for e in envs])
     enc = [encode_actions(e["acts"], st["M"], max_groups) for e in envs]
-    for k in ["mode", "n_groups", "atype", "n_exploit", "exploit", "app", "dev_cnt"]:
+    for k in ["mode", "n_groups", "atype", "n_exploit", "exploit", "app", "dev_cnt", "is_none"]:
         out[f"act_{k}"] = np.stack([a[k] for a in enc])
     out["act_dev_ptr"] = np.cumsum([0] + [len(a["dev_flat"]) for a in enc]).astype(np.int64)
     out["act_dev_flat"] = np.concatenate([a["dev_flat"] for a in enc]) if enc else np.zeros(0, np.int32)

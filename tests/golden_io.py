@@ -58,6 +58,8 @@ class Fixture:
         ptr = z["act_dev_ptr"]
         cnt = z["act_dev_cnt"]            # [N][T][G]
         self.L = max(1, int(cnt.sum(axis=2).max()))
+        if "act_is_none" in z.files and z["act_is_none"].any():
+            self.L = max(self.L, self.M)   # default actions may list every device (:852-870)
         self.dev = np.zeros((self.N, self.T, self.L), np.int16)
         flat = z["act_dev_flat"]
         for e in range(self.N):
@@ -67,8 +69,33 @@ class Fixture:
             for t in range(self.T):
                 self.dev[e, t, :per_t[t]] = row[off[t]:off[t + 1]]
 
-    def actions(self, t, alloc):
-        """Fill an action dict (oracle.driver.alloc_actions / torch mirror) for tick t."""
+    def is_none(self, e, t) -> bool:
+        return "act_is_none" in self.z.files and bool(self.z["act_is_none"][e, t])
+
+    def python_action(self, e, t):
+        """The reference-style action of env e at tick t: None, a 4-tuple, or a list of 4-tuples."""
+        z = self.z
+        if self.is_none(e, t):
+            return None
+        ng = int(z["act_n_groups"][e, t])
+        groups = []
+        off = 0
+        for g in range(max(1, ng)):
+            n = int(z["act_dev_cnt"][e, t, g])
+            ne = int(z["act_n_exploit"][e, t, g])
+            app = int(z["act_app"][e, t, g])
+            groups.append((int(z["act_atype"][e, t, g]), np.array(z["act_exploit"][e, t, g, :ne], dtype=int),
+                           [int(x) for x in self.dev[e, t, off:off + n]], app if app >= 0 else None))
+            off += n
+        return groups if ng > 0 else groups[0]
+
+    def mode_name(self, e, t) -> str:
+        return "defender" if int(self.z["act_mode"][e, t]) == S.MODE_DEFENDER else "attacker"
+
+    def actions(self, t, alloc, flags=None):
+        """Fill an action dict (oracle.driver.alloc_actions / torch mirror) for tick t.
+        `flags` ([N][M], state before the tick) is needed where the fixture holds action=None:
+        the default is substituted by the build's host logic (cygym_amd/host_logic.py)."""
         z = self.z
         alloc["mode"][:] = z["act_mode"][:, t]
         alloc["n_groups"][:] = z["act_n_groups"][:, t]
@@ -78,6 +105,11 @@ class Fixture:
         alloc["app"][:] = z["act_app"][:, t]
         alloc["dev_cnt"][:] = z["act_dev_cnt"][:, t]
         alloc["dev_idx"][:] = self.dev[:, t]
+        for e in range(self.N):
+            if self.is_none(e, t):
+                from cygym_amd import host_logic as HL
+                a = HL.default_action(self.mode_name(e, t), self.cfg.baseline, np.asarray(flags)[e])
+                HL.encode_into(alloc, e, self.mode_name(e, t), [a], False, self.M)
         return alloc
 
     def expected_state(self, t):

@@ -1,0 +1,94 @@
+"""The per-env view (reference method surface) over the HIP batch, driven with the
+reference-style Python actions stored in the golden fixtures -- the rollout-loop shape
+`env.mode = ...; _, r, _, done, info, _ = env.step(action)` of do_agent.py:206-272."""
+import numpy as np
+import pytest
+
+import golden_io as gio
+from cygym_amd import spec as S
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+NAMES = [n for n in gio.fixture_names()
+         if n.startswith(("s16_none", "s16_baselines", "s32_grouped", "s16_dups", "s16_mixed", "s16_zeroday"))]
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_view_matches_reference(name):
+    from cygym_amd.batched_env import BatchedCyberDefenseEnv
+    from cygym_amd.env_view import CyberDefenseEnvView
+    fx = gio.Fixture(name)
+    T = min(fx.T, 120)
+    batch = BatchedCyberDefenseEnv(fx.topo, fx.cfg, fx.N, fx.init, device="cuda:0", max_groups=fx.G, max_devs=fx.L)
+    views = [CyberDefenseEnvView(batch, e) for e in range(fx.N)]
+    alive = [True] * fx.N
+    for t in range(T):
+        for e, env in enumerate(views):     # envs tick one at a time, like separate reference objects
+            if not alive[e]:
+                continue
+            env.mode = fx.mode_name(e, t)
+            action = fx.python_action(e, t)
+            state, raw, shaped, done, info, logs = env.step(action)
+            if not fx.exp["topo_same"][e, t]:
+                alive[e] = False
+                continue
+            exp_i = fx.exp["ienv"][e, t]
+            np.testing.assert_array_equal(state, fx.exp["obs"][e, t].reshape(-1).astype(np.float64), err_msg=f"{name} e={e} t={t}")
+            assert abs(raw - fx.exp["raw"][e, t]) < 1e-9 and abs(shaped - fx.exp["shaped"][e, t]) < 1e-9
+            assert done == bool(fx.exp["done"][e, t])
+            grouped = int(fx.z["act_n_groups"][e, t]) > 0
+            assert info["step_count"] == int(exp_i[S.I_STEP_NUM]) - (0 if grouped else 1)
+            assert info["work_done"] == int(exp_i[S.I_WORK_DONE])
+            assert info["Compromised_devices"] == int(exp_i[S.I_COMP_CNT])
+            assert info["Scan_count"] == int(exp_i[S.I_SCAN_CNT])
+            assert info["Edges Blocked"] == int(exp_i[S.I_EDGES_BLOCKED]) and info["Edges Added"] == int(exp_i[S.I_EDGES_ADDED])
+            assert abs(info["defensive_cost"] - fx.exp["fenv"][e, t][S.D_DEF_COST]) < 1e-9
+            if not grouped:
+                assert info["executed_atype"] == int(exp_i[S.I_LAST_ATYPE])
+            assert len(logs) == min(int(exp_i[S.I_LOG_TOTAL]), S.LOG_RING)
+        # the other envs really stayed put while one ticked
+        got = batch.state_numpy()
+        for e in range(fx.N):
+            if alive[e]:
+                np.testing.assert_array_equal(got["flags"][e], fx.exp["flags"][e, t].astype(np.uint8))
+    # role views and attribute surface
+    env = views[0]
+    assert env._get_defender_state().shape == (6 * fx.M,) and env._get_attacker_state().shape == (4 * fx.M + 6,)
+    assert env.step_num == int(batch.state["ienv"][0, S.I_STEP_NUM].item())
+    env.work_done = 0
+    assert env.work_done == 0
+    batch.close()
+
+
+def test_view_errors_and_reset():
+    from cygym_amd.batched_env import BatchedCyberDefenseEnv
+    from cygym_amd.env_view import CyberDefenseEnvView
+    fx = gio.Fixture("s16_mixed")
+    batch = BatchedCyberDefenseEnv(fx.topo, fx.cfg, 2, {k: v[:2] for k, v in fx.init.items()}, device="cuda:0",
+                                   max_groups=2, max_devs=16)
+    env = CyberDefenseEnvView(batch, 1)
+    with pytest.raises(ValueError):
+        env.step((1, [0], [1], 0))                       # mode not set
+    env.mode = "defender"
+    with pytest.raises(ValueError):
+        env.step((11, [0], [], 0))                       # volt_typhoon_env.py:966
+    with pytest.raises(KeyError):
+        env.step((1, [0], [99], 0))                      # unknown device id
+    with pytest.raises(NotImplementedError):
+        env.step((8, [0], [], 0), agent_cnt=3)
+    before = batch.state_numpy()["flags"].copy()
+    s0 = env.reset()
+    env.step((7, [0], [2, 3], 0))
+    assert env.step_num == 1
+    s1 = env.reset(from_init=True)
+    np.testing.assert_array_equal(s0, s1)
+    np.testing.assert_array_equal(batch.state_numpy()["flags"][0], before[0])   # env 0 untouched throughout
+    env.base_line = "No Defense"
+    assert env.base_line == "No Defense"
+    st, r, _, _, info, _ = env.step(None)
+    assert info["executed_atype"] == 8
+    assert env.get_num_action_types("defender") == 14 and env.get_num_action_types("attacker") == 3
+    a = env.sample_action()
+    assert len(a) == 4
+    batch.close()

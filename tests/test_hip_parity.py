@@ -32,7 +32,7 @@ def test_hip_matches_reference_fixture(name):
     alive = np.ones(fx.N, bool)
     checked = 0
     for t in range(fx.T):
-        fx.actions(t, act)
+        fx.actions(t, act, flags=env.state["flags"].cpu().numpy())
         env.set_actions_numpy(act)
         obs, raw, shaped, done = env.step()
         got = env.state_numpy()

@@ -1,0 +1,130 @@
+"""CPU-side checks: spec mirror vs header, ABI struct sizes, library exports, host logic."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from cygym_amd import abi, host_logic as HL
+from cygym_amd import spec as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_constants():
+    txt = open(os.path.join(ROOT, "include", "cygym_spec.h")).read()
+    vals = {}
+    for m in re.finditer(r"#define\s+(CG_\w+)\s+(0x[0-9A-Fa-f]+u?|\d+)\b", txt):
+        vals[m.group(1)] = int(m.group(2).rstrip("u"), 0)
+    for body in re.findall(r"enum\s*\{(.*?)\};", txt, re.S):
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        nxt = 0
+        for item in body.split(","):
+            item = item.strip()
+            if not item:
+                continue
+            if "=" in item:
+                k, v = [x.strip() for x in item.split("=")]
+                nxt = int(v, 0)
+            else:
+                k = item
+            vals[k] = nxt
+            nxt += 1
+    return vals
+
+
+def test_spec_mirror_matches_header():
+    h = _header_constants()
+    pairs = {"CG_F_COMP": S.F_COMP, "CG_F_OWNED": S.F_OWNED, "CG_F_KNOWN": S.F_KNOWN, "CG_F_REACH": S.F_REACH,
+             "CG_F_NYA": S.F_NYA, "CG_F_EVOACT": S.F_EVOACT, "CG_F_BUSYC": S.F_BUSYC, "CG_F_WLADV": S.F_WLADV,
+             "CG_S_VALID": S.S_VALID, "CG_D_DC": S.D_DC, "CG_D_SERVER": S.D_SERVER,
+             "CG_E_HAS_CKPT": S.E_HAS_CKPT, "CG_E_EVO_INIT": S.E_EVO_INIT, "CG_E_DET_TRAIN": S.E_DET_TRAIN,
+             "CG_E_DET_RANDOM": S.E_DET_RANDOM, "CG_E_PREV_SET": S.E_PREV_SET, "CG_E_TOPO_OVF": S.E_TOPO_OVF,
+             "CG_E_BUSY_SAT": S.E_BUSY_SAT, "CG_I_COUNT": S.I_COUNT, "CG_I_RNG_TICK": S.I_RNG_TICK,
+             "CG_I_LOG_TOTAL": S.I_LOG_TOTAL, "CG_I_LAST_ATYPE": S.I_LAST_ATYPE, "CG_I_FLAGS": S.I_FLAGS,
+             "CG_D_COUNT": S.D_COUNT, "CG_D_PREV_ATT_POT": S.D_PREV_ATT_POT, "CG_LOG_RING": S.LOG_RING,
+             "CG_SCAN_WINDOW": S.SCAN_WINDOW, "CG_SITE_STALL_REVERT": S.SITE_STALL_REVERT,
+             "CG_SITE_ARR_TIME": S.SITE_ARR_TIME, "CG_SITE_EVO_PA": S.SITE_EVO_PA, "CG_SITE_LAZY": S.SITE_LAZY,
+             "CG_SITE_ACTGEN": S.SITE_ACTGEN, "CG_POISSON_TABLE": S.POISSON_TABLE, "CG_TRI_TABLE": S.TRI_TABLE,
+             "CG_MAX_EXPLOITS": S.MAX_EXPLOITS}
+    for k, v in pairs.items():
+        assert h[k] == v, (k, h[k], v)
+
+
+def test_library_loads_and_exports_every_symbol():
+    """No compute without a GPU: the .so must load on a CPU-only host and export the whole ABI."""
+    from cygym_amd import _lib
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "cygym_abi.h")).read()
+    declared = set(re.findall(r"\b(cygym_[a-z_]+)\s*\(", hdr)) - {"cygym_handle"}
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/cygym_abi.h but not exported"
+    assert lib.cygym_version() == abi.ABI_VERSION
+    # bad arguments come back as error codes with a message, never a crash
+    h = C.c_void_p()
+    assert lib.cygym_create(None, None, 0, 0, C.byref(h)) < 0
+    assert b"bad argument" in lib.cygym_last_error(None)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from cygym_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "SO", "/nonexistent/libcygym_hip.so")
+    with pytest.raises(_lib.CygymError):
+        _lib.load()
+
+
+def test_batched_env_refuses_cpu_device():
+    from cygym_amd.batched_env import BatchedCyberDefenseEnv
+    from cygym_amd.topology import make_topology
+    topo, init, ck = make_topology(16, 2, seed=0)
+    with pytest.raises(Exception):
+        BatchedCyberDefenseEnv(topo, abi.EnvConfig(**ck), 2, init, device="cpu")
+
+
+def test_default_actions_and_validation():
+    f = np.zeros(6, np.uint8)
+    f[1] = S.F_OWNED
+    f[2] = S.F_NYA
+    f[3] = S.F_KNOWN
+    f[4] = S.F_KNOWN | S.F_NYA
+    assert HL.default_action("defender", "No Defense", f) == (8, [0], [0, 3, 5], 0)   # not owned, not NYA
+    assert HL.default_action("defender", "Preset", f) == (7, [0], [], 0)
+    assert HL.default_action("defender", "Nash", f) == (7, [0], [], 0)
+    assert HL.default_action("attacker", "No Attack", f) == (3, [0], [3], 0)
+    assert HL.default_action("attacker", "Nash", f) == (2, [0], [], 0)
+    assert HL.is_grouped([(1, [0], [1], 0)]) and not HL.is_grouped((1, [0], [1], 0)) and not HL.is_grouped([])
+    assert HL.app_index_value(3) == 3 and HL.app_index_value(np.int64(3)) == -1 and HL.app_index_value(None) == -1
+    with pytest.raises(ValueError):
+        HL.validate_single("defender", "Nash", (11, [0], [], 0), 8, 14, 5)
+    HL.validate_single("defender", "No Defense", (11, [0], [], 0), 8, 14, 5)   # forced to no-op first (:913)
+    with pytest.raises(KeyError):
+        HL.validate_single("defender", "Nash", (4, [0], [1, 8], 0), 8, 14, 5)
+    HL.validate_single("defender", "Nash", (2, [0], [99], 0), 8, 14, 5)       # action 2 never indexes devices
+    HL.validate_single("attacker", "Nash", (1, [0], [99], 0), 8, 14, 5)
+
+
+def test_topology_validation_and_blocked_packing():
+    from cygym_amd.topology import make_topology
+    topo, init, _ = make_topology(64, 4, seed=2)
+    topo.validate()
+    bad = abi.TopologyArrays(**{**{k: getattr(topo, k) for k in ("M", "X", "dstatic", "vuln", "napps", "os_val", "version",
+                                                                "anomaly", "out_ptr", "out_col", "in_ptr", "in_col")},
+                                "in_eid": np.roll(topo.in_eid, 1)})
+    with pytest.raises(ValueError):
+        bad.validate()
+    bits = (np.random.RandomState(0).rand(3, topo.E) < 0.3).astype(np.uint8)
+    np.testing.assert_array_equal(abi.unpack_blocked(abi.pack_blocked(bits, topo.EW), topo.E), bits)
+
+
+def test_philox_known_answers():
+    from cygym_amd import rng as R
+    assert R.philox4x32_10(0, 0, 0, 0, 0, 0) == (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)
+    assert R.philox4x32_10(*([0xffffffff] * 6)) == (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)
+    assert R.philox4x32_10(0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, 0xa4093822, 0x299f31d0) == \
+        (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)
+    v = R.draw_np(7, np.arange(5), 3, S.SITE_ARR_TIME, np.arange(5), 0)
+    assert [int(x) for x in v] == [R.draw(7, e, 3, S.SITE_ARR_TIME, e, 0) for e in range(5)]
+    assert R.poisson_table(0.0)[0] == 1 << 32 and R.bernoulli_threshold(0.0) == 0 and R.bernoulli_threshold(1.0) == 1 << 32

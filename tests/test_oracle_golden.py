@@ -23,7 +23,7 @@ def test_oracle_matches_reference(name):
     alive = np.ones(fx.N, bool)   # parity is defined while the topology is unchanged
     checked = 0
     for t in range(fx.T):
-        fx.actions(t, act)
+        fx.actions(t, act, flags=ob.state["flags"])
         obs, raw, shaped, done = ob.step(act)
         same = fx.exp["topo_same"][:, t].astype(bool)
         # where the reference ADDED edges (evolve star / PA), the build must have flagged it
