@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "libcygym_hip.so")
 
 EXPORTS = [
-    "cygym_version", "cygym_last_error", "cygym_create", "cygym_destroy", "cygym_set_config", "cygym_bind",
+    "cygym_version", "cygym_last_error", "cygym_create", "cygym_destroy", "cygym_set_config", "cygym_bind", "cygym_derive",
     "cygym_set_snapshot", "cygym_reset", "cygym_randomize", "cygym_step", "cygym_observe", "cygym_gen_actions",
     "cygym_timer_start", "cygym_timer_stop",
 ]
@@ -47,6 +47,7 @@ def load():
     L.cygym_set_config.argtypes = [H, C.POINTER(abi.Config)]
     L.cygym_bind.argtypes = [H, C.POINTER(abi.Buffers)]
     L.cygym_set_snapshot.argtypes = [H, C.POINTER(abi.Buffers)]
+    L.cygym_derive.argtypes = [H, C.POINTER(abi.Buffers), C.c_void_p]
     L.cygym_reset.argtypes = [H, C.POINTER(abi.Buffers), C.c_void_p, C.c_int32, C.c_void_p]
     L.cygym_randomize.argtypes = [H, C.c_void_p, C.c_int32, C.c_void_p]
     L.cygym_step.argtypes = [H, C.POINTER(abi.Actions), C.POINTER(abi.Outputs), C.c_void_p]

@@ -17,7 +17,8 @@ import torch
 from . import _lib, abi
 from . import spec as S
 
-_BUF_DTYPES = {"live": torch.uint8, "stash": torch.uint8, "blocked": torch.int32, "ring": torch.int16,
+_BUF_DTYPES = {"live": torch.uint8, "stash": torch.uint8, "blocked": torch.int32, "blocked_in": torch.int32,
+               "ring": torch.int16,
                "ienv": torch.int32, "fenv": torch.float64}
 _STATE_KEYS = abi.STATE_PLANES + ("blocked", "ring", "ienv", "fenv")
 _NP_VIEW = {"blocked": np.uint32, "ring": np.uint16}
@@ -25,7 +26,7 @@ _NP_VIEW = {"blocked": np.uint32, "ring": np.uint16}
 
 def _alloc_state(n, M, EW, device):
     """`live` / `stash` are the [N][4][M] buffers of the ABI; flags/busy/... are VIEWS into them."""
-    dims = {"live": (4, M), "stash": (4, M), "blocked": (EW,), "ring": (S.LOG_RING, 2),
+    dims = {"live": (4, M), "stash": (4, M), "blocked": (EW,), "blocked_in": (EW,), "ring": (S.LOG_RING, 2),
             "ienv": (S.I_COUNT,), "fenv": (S.D_COUNT,)}
     st = {k: torch.zeros((n,) + dims[k], dtype=dt, device=device) for k, dt in _BUF_DTYPES.items()}
     for i, k in enumerate(abi.LIVE_PLANES):
@@ -100,6 +101,7 @@ class BatchedCyberDefenseEnv:
         self._load(self.snapshot, init_state)
         _lib.check(self.lib.cygym_bind(self._h, C.byref(_buffers_struct(self.state))), self._h, "cygym_bind")
         self._snap_struct = _buffers_struct(self.snapshot)
+        self._derive(self.snapshot)
         _lib.check(self.lib.cygym_set_snapshot(self._h, C.byref(self._snap_struct)), self._h, "cygym_set_snapshot")
         dev = self.device
         self.act = dict(
@@ -143,6 +145,10 @@ class BatchedCyberDefenseEnv:
                 a = a.astype(np.uint8)
             dst[k].copy_(torch.from_numpy(np.ascontiguousarray(a)).reshape(dst[k].shape))
 
+    def _derive(self, st):
+        """Fill the library-maintained derived buffers (blocked_in) of a state dict."""
+        _lib.check(self.lib.cygym_derive(self._h, C.byref(_buffers_struct(st)), self._stream()), self._h, "cygym_derive")
+
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
@@ -169,9 +175,11 @@ class BatchedCyberDefenseEnv:
         lead = int(np.asarray(state["flags"]).shape[0])
         if lead == self.N:
             self._load(self.state, state)
+            self._derive(self.state)
         else:
             tmp = _alloc_state(1, self.M, self.EW, self.device)
             self._load(tmp, state)
+            self._derive(tmp)
             for k in abi.BUFFER_FIELDS:
                 self.state[k].copy_(tmp[k].expand_as(self.state[k]))
 

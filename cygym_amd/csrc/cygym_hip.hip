@@ -28,6 +28,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <new>
 #include "cygym_abi.h"
 
@@ -39,12 +40,13 @@ constexpr int WAVE = 64;
 
 // The shared topology lives in ONE packed device blob whose layout is also the layout of the
 // workgroup-shared LDS section (copied with 16-byte loads): byte offsets o_* into the blob.
-//   [optr u16 M+1][ocol u16 E][os f32 M][ver f32 M][ano f32 M][dst u8 M][vul u8 M][nap u8 M] | [iptr u16 M+1][icol u16 E][ieid u16 E]
+//   [optr u16 M+1][ocol u16 E][os f32 M][ver f32 M][ano f32 M][dst u8 M][vul u8 M][nap u8 M] | [iptr u16 M+1][icol u16 E][ieid u16 E][oeid u16 E]
+//   (ieid: out-slot of an in-entry; oeid: in-entry of an out-slot)
 // The first `lds_bytes` bytes are staged in LDS: everything when it fits (in_lds), else all but the in-CSR.
 struct DevTopo {
   int M, X, E, EW, MC, Mp;
   const uint8_t* blob;
-  int o_optr, o_ocol, o_os, o_ver, o_ano, o_dst, o_vul, o_nap, o_iptr, o_icol, o_ieid;
+  int o_optr, o_ocol, o_os, o_ver, o_ano, o_dst, o_vul, o_nap, o_iptr, o_icol, o_ieid, o_oeid;
   int blob_bytes, lds_bytes, in_lds, multi;
   // global views (host-side convenience; kernels outside the tick use them)
   const uint8_t *dstatic, *vuln, *napps;
@@ -131,7 +133,8 @@ struct Env {
   // LDS, planes at stride MS = round_up(M, 4); padding bytes of `flags` hold CG_F_NYA
   uint8_t *flags, *busy, *wl, *cby;
   uint32_t* scr;     // [2*Mp] scratch (8 bytes per device)
-  uint32_t* blk;     // [EWp]
+  uint32_t* blk;     // [EWp] blocked bit per out-slot
+  uint32_t* bin;     // [EWp] the same bits in in-CSR entry order
   uint16_t* ring;    // [2*CG_LOG_RING]
   uint32_t* marks;   // [Mp/32 + 2]
   uint16_t* lsrc;    // [Mp] long-row sources of the spread
@@ -141,10 +144,8 @@ struct Env {
   const uint16_t *optr, *ocol;
   const uint8_t *dst, *vul, *nap;
   const float *osv, *ver, *ano;
-  // in-CSR: LDS when it fits (in_lds), else the global blob -- two typed pointer sets, no flat loads
-  const uint16_t *iptr_l, *icol_l, *ieid_l;
-  const uint16_t *iptr_g, *icol_g, *ieid_g;
-  bool in_lds;
+  // in-CSR + slot<->entry maps: global memory (L2-resident blob); read by block/unblock and evolve only
+  const uint16_t *iptr_g, *icol_g, *ieid_g, *oeid_g;
   uint8_t* stash;    // global [4][M] of this env
   // misc
   int M, MC, MS, lane, env;
@@ -160,9 +161,7 @@ struct Env {
     return cg_draw(seed, env_id, tick, site, a, b);
   }
   __device__ __forceinline__ bool blocked(int slot) const { return (blk[slot >> 5] >> (slot & 31)) & 1u; }
-  __device__ __forceinline__ int iptr(int d) const { return in_lds ? iptr_l[d] : iptr_g[d]; }
-  __device__ __forceinline__ int icol(int k) const { return in_lds ? icol_l[k] : icol_g[k]; }
-  __device__ __forceinline__ int ieid(int k) const { return in_lds ? ieid_l[k] : ieid_g[k]; }
+  __device__ __forceinline__ int iptr(int d) const { return iptr_g[d]; }
   __device__ __forceinline__ void set_busy(int d, int v) {
     if (v > 255) { v = 255; eflags |= CG_E_BUSY_SAT; }
     busy[d] = (uint8_t)v;
@@ -353,63 +352,49 @@ __device__ __forceinline__ void def_clean(Env& e, const KParams& P, const int16_
   wsync();
 }
 
-// Actions 6 / 9 (volt_typhoon_env.py:501-511, 1071-1100): pick the r-th incident edge with the
-// wanted blocked state among out-entries (row order) then in-entries (in-row order) of device d,
-// and flip it.  Out-row blocked bits are a contiguous bit range of `blk`, so counting and selecting
-// there are word operations; the in-row is gathered through in_eid with ballots.  Row bounds and the
-// draw are passed in (prefetched lane-parallel by the caller).
-__device__ __forceinline__ bool flip_incident(Env& e, int d, bool want, uint32_t u, int o0, int o1, int i0, int i1) {
-  const int nb = range_popc(e.blk, o0, o1);
-  const int n_out = want ? nb : (o1 - o0) - nb;
-  int n_in = 0;
-  uint64_t m0 = 0, m1 = 0;   // ballots of the first two in-row chunks are kept for the select
-  for (int k0 = i0, j = 0; k0 < i1; k0 += WAVE, ++j) {
-    int k = k0 + e.lane;
-    uint64_t m = ballot((k < i1) && (e.blocked(e.ieid(k)) == want));
-    if (j == 0) m0 = m; else if (j == 1) m1 = m;
-    n_in += __popcll(m);
-  }
+// Actions 6 / 9 (volt_typhoon_env.py:501-511, 1071-1100): the pool of device d is its out-entries with the
+// wanted blocked state (row order) followed by its in-entries (in-row order).  With the blocked bits kept in
+// BOTH orders (blk by out-slot, bin by in-entry) the pool is two contiguous bit ranges, so counting and
+// selecting are word operations (no per-edge gathers).
+struct Pick { int slot, j, x; };   // out-slot, in-entry and the OTHER endpoint of the chosen edge; slot < 0: empty pool
+// All pointers are passed BY VALUE: selecting between addresses of Env members (which the optimiser does when
+// two branch arms load through different members) would pin the whole Env struct in scratch memory.
+struct PoolPtrs {
+  uint32_t *blk, *bin;                   // LDS
+  const uint16_t *optr, *ocol;           // LDS
+  const uint16_t *icol, *ieid, *oeid;    // global
+};
+__device__ __forceinline__ Pick pool_pick(const PoolPtrs q, bool want, uint32_t u, int o0, int o1, int i0, int i1) {
+  Pick p; p.slot = -1; p.j = -1; p.x = -1;
+  const int nbo = range_popc(q.blk, o0, o1), nbi = range_popc(q.bin, i0, i1);
+  const int n_out = want ? nbo : (o1 - o0) - nbo;
+  const int n_in = want ? nbi : (i1 - i0) - nbi;
   const int n = n_out + n_in;
-  if (n == 0) return false;
-  int r = (int)cg_index(u, (uint32_t)n);
-  int su, sv, slot;
-  if (r < n_out) {
-    slot = range_select(e.blk, o0, o1, want, r);
-    su = d; sv = e.ocol[slot];
+  if (n == 0) return p;
+  const int r = (int)cg_index(u, (uint32_t)n);
+  const bool from_out = r < n_out;
+  int slot = -1, j = -1;
+  if (from_out) slot = range_select(q.blk, o0, o1, want, r);
+  else          j = range_select(q.bin, i0, i1, want, r - n_out);
+  if (from_out) { p.slot = slot; p.j = q.oeid[slot]; p.x = q.ocol[slot]; }      // independent loads
+  else          { p.j = j; p.slot = q.ieid[j]; p.x = q.icol[j]; }
+  return p;
+}
+// toggle edge (su -> sv) given one of its slots; with duplicate (u,v) out-entries all of them share the state
+__device__ __forceinline__ void pool_flip(const PoolPtrs q, bool multi, const Pick p, int d, int o0, int o1, bool want) {
+  if (!multi) {
+    if (!want) { atomicOr(&q.blk[p.slot >> 5], 1u << (p.slot & 31)); atomicOr(&q.bin[p.j >> 5], 1u << (p.j & 31)); }
+    else       { atomicAnd(&q.blk[p.slot >> 5], ~(1u << (p.slot & 31))); atomicAnd(&q.bin[p.j >> 5], ~(1u << (p.j & 31))); }
   } else {
-    r -= n_out;
-    int kk = -1;
-    const int c0 = __popcll(m0), c1 = __popcll(m1);
-    if (r < c0) kk = i0 + nth_bit(m0, r);
-    else if (r < c0 + c1) kk = i0 + WAVE + nth_bit(m1, r - c0);
-    else {
-      r -= c0 + c1;
-      for (int k0 = i0 + 2 * WAVE; k0 < i1; k0 += WAVE) {
-        int k = k0 + e.lane;
-        uint64_t m = ballot((k < i1) && (e.blocked(e.ieid(k)) == want));
-        int c = __popcll(m);
-        if (r < c) { kk = k0 + nth_bit(m, r); break; }
-        r -= c;
+    int su = d, sv = p.x;
+    if (!(p.slot >= o0 && p.slot < o1)) { su = p.x; sv = d; }
+    for (int k = q.optr[su]; k < q.optr[su + 1]; ++k)
+      if (q.ocol[k] == sv) {
+        const int j = q.oeid[k];
+        if (!want) { atomicOr(&q.blk[k >> 5], 1u << (k & 31)); atomicOr(&q.bin[j >> 5], 1u << (j & 31)); }
+        else       { atomicAnd(&q.blk[k >> 5], ~(1u << (k & 31))); atomicAnd(&q.bin[j >> 5], ~(1u << (j & 31))); }
       }
-    }
-    slot = e.ieid(kk); su = e.icol(kk); sv = d;
   }
-  wsync();
-  if (!e.multi) {   // (u,v) occurs once: flip exactly that slot
-    if (e.lane == 0) {
-      if (!want) e.blk[slot >> 5] |= 1u << (slot & 31); else e.blk[slot >> 5] &= ~(1u << (slot & 31));
-    }
-  } else {          // every duplicate (u,v) out-entry shares the state (env._blocked holds pairs)
-    const int p0 = e.optr[su], p1 = e.optr[su + 1];
-    for (int k = p0 + e.lane; k < p1; k += WAVE) {
-      if (e.ocol[k] == sv) {
-        if (!want) atomicOr(&e.blk[k >> 5], 1u << (k & 31)); else atomicAnd(&e.blk[k >> 5], ~(1u << (k & 31)));
-      }
-    }
-  }
-  e.blk_dirty = true;
-  wsync();
-  return true;
 }
 
 __device__ __forceinline__ void def_per_device(Env& e, const KParams& P, int at, const int16_t* dev, int L, int app,
@@ -417,17 +402,22 @@ __device__ __forceinline__ void def_per_device(Env& e, const KParams& P, int at,
   const double ds = P.c.def_scale;
   const int M = e.M;
   if (at == 1) { def_clean(e, P, dev, L, cost, ie, fe, nullptr); return; }
-  if (at == 6 || at == 9) {  // sequential over the list: each pick changes the next pool
+  if (at == 6 || at == 9) {  // sequential semantics: each pick changes the pools of BOTH endpoints
     const uint32_t site = at == 6 ? CG_SITE_PICK_BLOCK : CG_SITE_PICK_UNBLOCK;
+    const bool want = (at == 9);
     const bool simple = list_is_simple(e, dev, L);   // no device twice => occurrence number is always 0
-    uint8_t* occ = (uint8_t*)e.scr;
+    uint8_t* occ = (uint8_t*)(e.scr + e.MC * WAVE);   // second scratch half (first half: first-touch table)
     if (!simple) {
-      for (int i = e.lane; i < (e.MC * WAVE) / 4; i += WAVE) e.scr[i] = 0;
+      for (int i = e.lane; i < (e.MC * WAVE) / 4; i += WAVE) ((uint32_t*)occ)[i] = 0;
       wsync();
     }
+    uint32_t* fh = e.scr;   // [Mp] first remaining entry (lane) whose flipped edge ends at this device
+    PoolPtrs q;
+    q.blk = e.blk; q.bin = e.bin; q.optr = e.optr; q.ocol = e.ocol; q.icol = e.icol_g; q.ieid = e.ieid_g; q.oeid = e.oeid_g;
+    const bool multi = e.multi;
     int n_act = 0, n_hit = 0;
     for (int p0 = 0; p0 < L; p0 += WAVE) {
-      // lane-parallel prefetch of this block of entries: device, row bounds, the (occurrence 0) draw
+      // one lane per list entry: device, row bounds and the (occurrence 0) draw
       const int p = p0 + e.lane;
       int d = -1, o0 = 0, o1 = 0, i0 = 0, i1 = 0;
       uint32_t u = 0;
@@ -438,21 +428,42 @@ __device__ __forceinline__ void def_per_device(Env& e, const KParams& P, int at,
       }
       uint64_t am = ballot(d >= 0);
       n_act += __popcll(am);
+      SUBSTAMP(10);
+      int n_pass = 0;
+      // Speculate: every remaining entry picks on the bitmasks as they stand.  An entry is exact unless an
+      // EARLIER remaining entry flips an edge ending at its device (or is the same device); apply the exact
+      // prefix in parallel and repeat from the first inexact entry (at least one entry retires per pass).
       while (am) {
-        const int q = __builtin_ctzll(am);
-        am &= am - 1;
-        const int dq = __builtin_amdgcn_readlane(d, q);
-        uint32_t uq = (uint32_t)__builtin_amdgcn_readlane((int)u, q);
-        if (!simple) {
-          int b = occ[dq];
-          if (b > 0) uq = e.draw(site, dq, b);
+        for (int i = e.lane; i < e.MC * WAVE; i += WAVE) fh[i] = 0xFFFFFFFFu;
+        wsync();
+        const bool mine = (am >> e.lane) & 1ull;
+        Pick pk; pk.slot = -1; pk.j = -1; pk.x = -1;
+        if (mine) {
+          uint32_t uu = u;
+          if (!simple) { const int b = occ[d]; if (b > 0) uu = e.draw(site, d, b); }
+          pk = pool_pick(q, want, uu, o0, o1, i0, i1);
+          if (pk.slot >= 0) atomicMin(&fh[pk.x], (uint32_t)e.lane);
+          if (!simple) atomicMin(&fh[d], (uint32_t)e.lane);   // a repeated device must wait for its first occurrence
         }
-        if (flip_incident(e, dq, at == 9, uq, __builtin_amdgcn_readlane(o0, q), __builtin_amdgcn_readlane(o1, q),
-                          __builtin_amdgcn_readlane(i0, q), __builtin_amdgcn_readlane(i1, q))) {
-          ++n_hit;
-          if (!simple) { if (e.lane == 0) occ[dq] += 1; wsync(); }
+        wsync();
+        const bool taint = mine && fh[d] < (uint32_t)e.lane;
+        const uint64_t tm = ballot(taint);
+        const int q0 = tm ? __builtin_ctzll(tm) : WAVE;
+        const bool apply = mine && pk.slot >= 0 && e.lane < q0;
+        if (apply) {
+          pool_flip(q, multi, pk, d, o0, o1, want);
+          if (!simple) occ[d] += 1;
         }
+        const uint64_t apm = ballot(apply);
+        n_hit += __popcll(apm);
+        if (apm) e.blk_dirty = true;
+        wsync();
+        am &= q0 < WAVE ? (~0ull << q0) : 0ull;
+        ++n_pass;
       }
+      SUBSTAMP(11);
+      SUBVAL(15, n_pass);
+      SUBVAL(14, n_act);
     }
     cost += -0.5 * n_act * ds;
     fe[CG_D_DEF_COST] += 0.5 * n_act * ds;
@@ -1063,7 +1074,8 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
   e.flags = wb; e.busy = wb + MS; e.wl = wb + 2 * MS; e.cby = wb + 3 * MS;
   e.scr = (uint32_t*)(wb + ((4 * MS + 15) & ~15));
   e.blk = e.scr + 2 * Mp;
-  e.ring = (uint16_t*)(e.blk + ((P.t.EW + 3) & ~3));
+  e.bin = e.blk + ((P.t.EW + 3) & ~3);
+  e.ring = (uint16_t*)(e.bin + ((P.t.EW + 3) & ~3));
   e.marks = (uint32_t*)(e.ring + 2 * CG_LOG_RING);
   uint64_t* srcb = (uint64_t*)(e.marks + ((Mp / 32 + 2) & ~1));
   e.lsrc = (uint16_t*)(srcb + MC);
@@ -1072,9 +1084,8 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
   e.optr = (const uint16_t*)(smem + P.t.o_optr); e.ocol = (const uint16_t*)(smem + P.t.o_ocol);
   e.osv = (const float*)(smem + P.t.o_os); e.ver = (const float*)(smem + P.t.o_ver); e.ano = (const float*)(smem + P.t.o_ano);
   e.dst = smem + P.t.o_dst; e.vul = smem + P.t.o_vul; e.nap = smem + P.t.o_nap;
-  e.in_lds = P.t.in_lds != 0;
-  e.iptr_l = (const uint16_t*)(smem + P.t.o_iptr); e.icol_l = (const uint16_t*)(smem + P.t.o_icol); e.ieid_l = (const uint16_t*)(smem + P.t.o_ieid);
-  e.iptr_g = (const uint16_t*)(P.t.blob + P.t.o_iptr); e.icol_g = (const uint16_t*)(P.t.blob + P.t.o_icol); e.ieid_g = (const uint16_t*)(P.t.blob + P.t.o_ieid);
+  e.iptr_g = (const uint16_t*)(P.t.blob + P.t.o_iptr); e.icol_g = (const uint16_t*)(P.t.blob + P.t.o_icol);
+  e.ieid_g = (const uint16_t*)(P.t.blob + P.t.o_ieid); e.oeid_g = (const uint16_t*)(P.t.blob + P.t.o_oeid);
   e.M = M; e.MC = MC; e.MS = MS; e.lane = lane; e.env = env;
   e.cbits = 32 - __builtin_clz((unsigned)(4 * ((MS / 4 + WAVE - 1) / WAVE)));
   e.env_id = (uint32_t)(P.c.env_id_base + env);
@@ -1093,7 +1104,7 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
   uint4 r0 = make_uint4(0, 0, 0, 0);
   uint32_t ringw = 0;
   constexpr int PF_BLK = 2, PF_DEV = 1;   // words / list entries per lane prefetched into registers
-  uint32_t bw[PF_BLK];
+  uint32_t bw[PF_BLK], bwi[PF_BLK];
   int16_t dv[PF_DEV];
   const bool vec = (M & 3) == 0;
   const int items = M >> 2;   // uint4 items of the [4][M] live block when M % 4 == 0
@@ -1113,21 +1124,26 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
     if (vec && lane < items) r0 = ((const uint4*)g_live)[lane];
     if (lane < CG_LOG_RING) ringw = ((const uint32_t*)(P.b.ring + (size_t)env * CG_LOG_RING * 2))[lane];
 #pragma unroll
-    for (int j = 0; j < PF_BLK; ++j) { int w = lane + j * WAVE; bw[j] = w < P.t.EW ? P.b.blocked[(size_t)env * P.t.EW + w] : 0u; }
+    for (int j = 0; j < PF_BLK; ++j) {
+      int w = lane + j * WAVE;
+      bw[j] = w < P.t.EW ? P.b.blocked[(size_t)env * P.t.EW + w] : 0u;
+      bwi[j] = w < P.t.EW ? P.b.blocked_in[(size_t)env * P.t.EW + w] : 0u;
+    }
 #pragma unroll
     for (int j = 0; j < PF_DEV; ++j) { int q = lane + j * WAVE; dv[j] = q < L ? P.a.dev_idx[(size_t)env * L + q] : (int16_t)0; }
   }
-  // ---- workgroup-shared topology blob -> LDS (16-byte copies, two in flight per thread) ----
+  // ---- workgroup-shared topology blob -> LDS: every 16-byte load is issued before the first store ----
   {
     const uint4* src = (const uint4*)P.t.blob;
     uint4* dstp = (uint4*)smem;
     const int n16 = P.t.lds_bytes >> 4, stride = WPB * WAVE;
-    int i = threadIdx.x;
-    for (; i + stride < n16; i += 2 * stride) {
-      uint4 a = src[i], b = src[i + stride];
-      dstp[i] = a; dstp[i + stride] = b;
-    }
-    if (i < n16) dstp[i] = src[i];
+    constexpr int PF_BLOB = 4;
+    uint4 br[PF_BLOB];
+#pragma unroll
+    for (int j = 0; j < PF_BLOB; ++j) { const int i = threadIdx.x + j * stride; br[j] = src[i < n16 ? i : n16 - 1]; }   // unconditional: stays in registers
+#pragma unroll
+    for (int j = 0; j < PF_BLOB; ++j) { const int i = threadIdx.x + j * stride; if (i < n16) dstp[i] = br[j]; }
+    for (int i = threadIdx.x + PF_BLOB * stride; i < n16; i += stride) dstp[i] = src[i];
   }
   if (live) {
     if (vec) {
@@ -1140,8 +1156,8 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
     if (lane < CG_LOG_RING) ((uint32_t*)e.ring)[lane] = ringw;
     const uint32_t* gb = P.b.blocked + (size_t)env * P.t.EW;
 #pragma unroll
-    for (int j = 0; j < PF_BLK; ++j) { int w = lane + j * WAVE; if (w < P.t.EW) e.blk[w] = bw[j]; }
-    for (int w = lane + PF_BLK * WAVE; w < P.t.EW; w += WAVE) e.blk[w] = gb[w];
+    for (int j = 0; j < PF_BLK; ++j) { int w = lane + j * WAVE; if (w < P.t.EW) { e.blk[w] = bw[j]; e.bin[w] = bwi[j]; } }
+    for (int w = lane + PF_BLK * WAVE; w < P.t.EW; w += WAVE) { e.blk[w] = gb[w]; e.bin[w] = P.b.blocked_in[(size_t)env * P.t.EW + w]; }
     const int16_t* gd = P.a.dev_idx + (size_t)env * L;
 #pragma unroll
     for (int j = 0; j < PF_DEV; ++j) { int q = lane + j * WAVE; if (q < L) e.devl[q] = dv[j]; }
@@ -1330,7 +1346,10 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
       P.b.live[so + i] = P.snap.live[ss + i];
       P.b.stash[so + i] = P.snap.stash[ss + i];
     }
-    for (int w = lane; w < P.t.EW; w += WAVE) P.b.blocked[(size_t)env * P.t.EW + w] = P.snap.blocked[(size_t)si * P.t.EW + w];
+    for (int w = lane; w < P.t.EW; w += WAVE) {
+      P.b.blocked[(size_t)env * P.t.EW + w] = P.snap.blocked[(size_t)si * P.t.EW + w];
+      P.b.blocked_in[(size_t)env * P.t.EW + w] = P.snap.blocked_in[(size_t)si * P.t.EW + w];
+    }
     if (lane < CG_LOG_RING)
       ((uint32_t*)(P.b.ring + (size_t)env * CG_LOG_RING * 2))[lane] = ((const uint32_t*)(P.snap.ring + (size_t)si * CG_LOG_RING * 2))[lane];
     if (lane < CG_I_COUNT) {
@@ -1350,7 +1369,11 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
     for (int pl = 0; pl < 4; ++pl)
       for (int i = lane; i < M; i += WAVE) P.b.live[so + pl * M + i] = e.flags[pl * MS + i];
   }
-  if (e.blk_dirty) for (int w = lane; w < P.t.EW; w += WAVE) P.b.blocked[(size_t)env * P.t.EW + w] = e.blk[w];
+  if (e.blk_dirty)
+    for (int w = lane; w < P.t.EW; w += WAVE) {
+      P.b.blocked[(size_t)env * P.t.EW + w] = e.blk[w];
+      P.b.blocked_in[(size_t)env * P.t.EW + w] = e.bin[w];
+    }
   if (e.ring_dirty && lane < CG_LOG_RING)
     ((uint32_t*)(P.b.ring + (size_t)env * CG_LOG_RING * 2))[lane] = ((const uint32_t*)e.ring)[lane];
   if (lane == 0) {
@@ -1381,7 +1404,10 @@ __global__ void reset_kernel(KParams P, const int32_t* env_ids, int n) {
     P.b.live[so + i] = P.snap.live[ss + i];
     P.b.stash[so + i] = P.snap.stash[ss + i];
   }
-  for (int w = lane; w < P.t.EW; w += WAVE) P.b.blocked[(size_t)env * P.t.EW + w] = P.snap.blocked[(size_t)si * P.t.EW + w];
+  for (int w = lane; w < P.t.EW; w += WAVE) {
+    P.b.blocked[(size_t)env * P.t.EW + w] = P.snap.blocked[(size_t)si * P.t.EW + w];
+    P.b.blocked_in[(size_t)env * P.t.EW + w] = P.snap.blocked_in[(size_t)si * P.t.EW + w];
+  }
   if (lane < CG_LOG_RING)
     ((uint32_t*)(P.b.ring + (size_t)env * CG_LOG_RING * 2))[lane] = ((const uint32_t*)(P.snap.ring + (size_t)si * CG_LOG_RING * 2))[lane];
   if (lane < CG_I_COUNT) {
@@ -1436,6 +1462,24 @@ __global__ void randomize_kernel(KParams P, const int32_t* env_ids, int n, uint3
     else if (rank < k_owned + extra) f |= (CG_F_COMP | CG_F_KNOWN);
     // flags are rewritten after every lane has read the eligibility bits (NYA/DC do not change)
     flags[d] = f;
+  }
+}
+
+// blocked_in[j] = blocked[in_eid[j]]: the derived in-order mirror of the blocked bits (wave per env)
+__global__ void derive_kernel(KParams P, cygym_buffers bufs) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= bufs.n_envs) return;
+  const uint32_t* blk = bufs.blocked + (size_t)wave * P.t.EW;
+  uint32_t* bin = bufs.blocked_in + (size_t)wave * P.t.EW;
+  for (int j0 = 0; j0 < P.t.EW * 32; j0 += WAVE) {
+    const int j = j0 + lane;
+    bool bit = false;
+    if (j < P.t.E) { const int k = P.t.in_eid[j]; bit = (blk[k >> 5] >> (k & 31)) & 1u; }
+    const uint64_t m = __ballot(bit);
+    if (lane == 0) {
+      bin[j0 >> 5] = (uint32_t)m;
+      if ((j0 >> 5) + 1 < P.t.EW) bin[(j0 >> 5) + 1] = (uint32_t)(m >> 32);
+    }
   }
 }
 
@@ -1573,29 +1617,35 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // LDS budget: shared blob prefix + WPB per-wave regions.  Prefers staging the in-CSR too.
 static size_t wave_lds_bytes(const DevTopo& t, int max_devs) {
-  size_t w = align_up((size_t)4 * ((t.M + 3) & ~3), 16) + (size_t)t.Mp * 8 + (size_t)((t.EW + 3) & ~3) * 4 + CG_LOG_RING * 4 +
+  size_t w = align_up((size_t)4 * ((t.M + 3) & ~3), 16) + (size_t)t.Mp * 8 + (size_t)((t.EW + 3) & ~3) * 4 * 2 + CG_LOG_RING * 4 +
              (size_t)((t.Mp / 32 + 2) & ~1) * 4 + (size_t)t.MC * 8 + (size_t)t.Mp * 2 + (size_t)t.Mp +
              align_up((size_t)max_devs * 2, 16);
   return align_up(w, 16);
 }
+// The in-CSR (iptr/icol/ieid/oeid, ~2/3 of the blob) is read by block/unblock only (~9 % of env-ticks):
+// it stays in global memory (L2-resident) and only the first o_iptr bytes are staged in LDS every tick.
 static int choose_launch(cygym_handle* h, int max_devs) {
   DevTopo& t = h->t;
   const size_t lds_cap = 160 * 1024;
   const size_t wave = wave_lds_bytes(t, max_devs);
-  for (int pass = 0; pass < 2; ++pass) {
-    const size_t shared = pass == 0 ? (size_t)t.blob_bytes : (size_t)t.o_iptr;
-    for (int wpb = 16; wpb >= 1; wpb >>= 1) {
-      // keep >= 2 workgroups per CU where that is possible without dropping below 4 waves
-      if (shared + wave * wpb <= lds_cap && (wpb <= 4 || 2 * (shared + wave * wpb) <= lds_cap || wpb == 16)) {
-        if (wpb == 16 && 2 * (shared + wave * wpb) > lds_cap) continue;
-        h->wpb = wpb; h->wave_lds = (int)wave; h->shared_lds = (int)shared;
-        t.lds_bytes = (int)shared; t.in_lds = pass == 0;
-        h->max_devs = max_devs;
-        return 0;
-      }
-    }
+  const size_t shared = (size_t)t.o_iptr;
+  int best = 0, best_waves = 0;
+  const char* force = getenv("CYGYM_WPB");   // tuning aid: force the waves-per-workgroup choice
+  const int forced = force ? atoi(force) : 0;
+  for (int wpb = 16; wpb >= 1; wpb >>= 1) {
+    if (forced && wpb != forced) continue;
+    const size_t per_wg = shared + wave * wpb;
+    if (per_wg > lds_cap) continue;
+    int waves = (int)(lds_cap / per_wg) * wpb;
+    if (waves > 32) waves = 32;
+    // ties: two 8-wave workgroups per CU beat one 16-wave workgroup (their phases interleave)
+    if (waves > best_waves || (waves == best_waves && wpb == 8)) { best_waves = waves; best = wpb; }
   }
-  return -1;
+  if (!best) return -1;
+  h->wpb = best; h->wave_lds = (int)wave; h->shared_lds = (int)shared;
+  t.lds_bytes = (int)shared; t.in_lds = 0;
+  h->max_devs = max_devs;
+  return 0;
 }
 
 int cygym_create(const cygym_topology* topo, const cygym_config* cfg, int32_t n_envs, int32_t device_id,
@@ -1620,6 +1670,19 @@ int cygym_create(const cygym_topology* topo, const cygym_config* cfg, int32_t n_
         topo->in_eid[k] < 0 || topo->in_eid[k] >= E)
       return fail(nullptr, CYGYM_EINVAL, "CSR column / edge id out of range%s", "");
   }
+  {   // in_eid must be a bijection in-entry -> out-slot that agrees with both CSRs
+    unsigned char* seen = (unsigned char*)calloc((size_t)(E > 0 ? E : 1), 1);
+    if (!seen) return fail(nullptr, CYGYM_EINVAL, "out of host memory%s", "");
+    bool ok = true;
+    for (int v = 0; v < M && ok; ++v)
+      for (int j = topo->in_ptr[v]; j < topo->in_ptr[v + 1] && ok; ++j) {
+        const int k = topo->in_eid[j], u = topo->in_col[j];
+        ok = !seen[k] && topo->out_col[k] == v && k >= topo->out_ptr[u] && k < topo->out_ptr[u + 1];
+        seen[k] = 1;
+      }
+    free(seen);
+    if (!ok) return fail(nullptr, CYGYM_EINVAL, "in_eid does not match the out-CSR%s", "");
+  }
   cygym_handle* h = new (std::nothrow) cygym_handle();
   if (!h) return fail(nullptr, CYGYM_EINVAL, "out of host memory%s", "");
   memset(h, 0, sizeof(*h));
@@ -1636,6 +1699,7 @@ int cygym_create(const cygym_topology* topo, const cygym_config* cfg, int32_t n_
   t.o_os = take((size_t)M * 4); t.o_ver = take((size_t)M * 4); t.o_ano = take((size_t)M * 4);
   t.o_dst = take(M); t.o_vul = take(M); t.o_nap = take(M);
   t.o_iptr = take((size_t)(M + 1) * 2); t.o_icol = take((size_t)(E > 0 ? E : 1) * 2); t.o_ieid = take((size_t)(E > 0 ? E : 1) * 2);
+  t.o_oeid = take((size_t)(E > 0 ? E : 1) * 2);
   t.blob_bytes = (int)off;
   t.multi = 0;   // duplicate (u,v) out-entries? (env._blocked holds pairs, so duplicates share their state)
   for (int u = 0; u < M && !t.multi; ++u)
@@ -1660,6 +1724,7 @@ int cygym_create(const cygym_topology* topo, const cygym_config* cfg, int32_t n_
     ((uint16_t*)(host + t.o_ocol))[k] = (uint16_t)topo->out_col[k];
     ((uint16_t*)(host + t.o_icol))[k] = (uint16_t)topo->in_col[k];
     ((uint16_t*)(host + t.o_ieid))[k] = (uint16_t)topo->in_eid[k];
+    ((uint16_t*)(host + t.o_oeid))[topo->in_eid[k]] = (uint16_t)k;   // inverse map: in-entry of every out-slot
   }
   hipError_t e1 = hipMalloc(&h->dev_blob, off);
   if (e1 == hipSuccess) e1 = hipMemcpy(h->dev_blob, host, off, hipMemcpyHostToDevice);
@@ -1698,7 +1763,7 @@ int cygym_set_config(cygym_handle* h, const cygym_config* cfg) {
 }
 
 static int check_buffers(cygym_handle* h, const cygym_buffers* b, bool snapshot) {
-  if (!b || !b->live || !b->stash || !b->blocked || !b->ring || !b->ienv || !b->fenv)
+  if (!b || !b->live || !b->stash || !b->blocked || !b->blocked_in || !b->ring || !b->ienv || !b->fenv)
     return fail(h, CYGYM_EINVAL, "buffer struct has a null plane%s", "");
   if (snapshot ? (b->n_envs != 1 && b->n_envs != h->n_envs) : (b->n_envs != h->n_envs))
     return fail(h, CYGYM_EINVAL, "buffer struct has the wrong leading dimension%s", "");
@@ -1721,6 +1786,19 @@ static KParams make_params(cygym_handle* h) {
   P.wave_lds = h->wave_lds; P.shared_lds = h->shared_lds;
   P.dbg = h->dbg;
   return P;
+}
+
+int cygym_derive(cygym_handle* h, const cygym_buffers* bufs, void* stream) {
+  if (!h) return fail(h, CYGYM_EINVAL, "cygym_derive: null handle%s", "");
+  int rc = check_buffers(h, bufs, true);
+  if (rc) return rc;
+  HIPCHK(h, hipSetDevice(h->device_id));
+  KParams P = make_params(h);
+  const int threads = 256, waves_per_block = threads / WAVE;
+  hipLaunchKernelGGL(derive_kernel, dim3((bufs->n_envs + waves_per_block - 1) / waves_per_block), dim3(threads), 0,
+                     (hipStream_t)stream, P, *bufs);
+  HIPCHK(h, hipGetLastError());
+  return CYGYM_OK;
 }
 
 int cygym_reset(cygym_handle* h, const cygym_buffers* snapshot, const int32_t* env_ids, int32_t n, void* stream) {

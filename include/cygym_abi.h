@@ -109,6 +109,9 @@ typedef struct cygym_buffers {
   uint8_t*  live;       /* [N][4][M]                                            */
   uint8_t*  stash;      /* [N][4][M]                                            */
   uint32_t* blocked;    /* [N][EW] bit per out-CSR slot, EW = ceil(E/32)        */
+  uint32_t* blocked_in; /* [N][EW] DERIVED mirror of `blocked` in in-CSR entry order (bit j = blocked[in_eid[j]]),
+                           maintained by the library so that every incident-edge pool is two contiguous bit
+                           ranges; fill it with cygym_derive() after writing `blocked` from the host */
   uint16_t* ring;       /* [N][CG_LOG_RING][2] last comm-log (from,to) pairs    */
   int32_t*  ienv;       /* [N][CG_I_COUNT]                                      */
   double*   fenv;       /* [N][CG_D_COUNT]                                      */
@@ -154,6 +157,10 @@ void cygym_destroy(cygym_handle* h);
 /* attribute writes on the env object (env.base_line = ..., env.comp_scale = ...) */
 int cygym_set_config(cygym_handle* h, const cygym_config* cfg);
 int cygym_bind(cygym_handle* h, const cygym_buffers* state);
+
+/* Recompute the derived members of `bufs` (blocked_in) from the canonical ones, for all
+ * bufs->n_envs envs.  Call after loading state / snapshots from the host. */
+int cygym_derive(cygym_handle* h, const cygym_buffers* bufs, void* stream);
 
 /* Replaces: reset(from_init=True) volt_typhoon_env.py:1904-1936 (restore the
  * pickled initial env).  `snapshot` has n_envs == 1 (broadcast) or N.

@@ -65,6 +65,7 @@ def alloc_state(n, M, EW):
         st[k] = st["stash"][:, i]
     for k, (d, dt) in OTHER_SHAPES.items():
         st[k] = np.zeros((n,) + dims[d], dt)
+    st["blocked_in"] = np.zeros((n, EW), np.uint32)   # derived, library-side only: the oracle never reads it
     st["ring"][:] = 0xFFFF
     return st
 

@@ -41,6 +41,13 @@ for t in range(40):
             print("   spread sub-phases (mean cycles): setup", int((sub[:, 10] - sub[:, 1]).mean()), "rounds", int((sub[:, 11] - sub[:, 10]).mean()),
                   "logcnt", int((sub[:, 12] - sub[:, 11]).mean()), "ring", int((sub[:, 13] - sub[:, 12]).mean()),
                   "apply", int((sub[:, 14] - sub[:, 13]).mean()), " n_rounds mean", sub[:, 15].mean(), "max", sub[:, 15].max())
+    if int(d[0, 9]) == 0:
+        for aa in (6, 9):
+            m = at == aa
+            if m.any():
+                sub = d[m]
+                print(f"   action {aa}: pre {int((sub[:, 10] - sub[:, 1]).mean())} loop {int((sub[:, 11] - sub[:, 10]).mean())} (max {int((sub[:, 11] - sub[:, 10]).max())}) rest {int((sub[:, 2] - sub[:, 11]).mean())}"
+                      f" passes mean {sub[:, 15].mean():.2f} max {sub[:, 15].max()} entries mean {sub[:, 14].mean():.1f}")
     for a in sorted(set(at.tolist())):
         m = at == a
         print(f"   atype {int(a):3d}: n={int(m.sum()):5d} total mean {tot[m].mean():8.0f} max {tot[m].max():8d}  action-phase mean {seg[m, 1].mean():8.0f} max {seg[m, 1].max():8d}")
