@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--fused", type=int, default=-1,
+                    help="also time cygym_rollout with this many ticks per launch (0 = off, -1 = all K steps in one launch)")
     args = ap.parse_args()
 
     import torch
@@ -137,6 +139,8 @@ def main():
         "check": {"last_raw_reward_sum": ret_sum},
     }
 
+    if args.fused:
+        out["fused_rollout"] = fused_leg(env, init, scripts, W, K, args.fused, world, dev, n_per_gpu, B)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(topo, init, cfg, M, L, scripts, W, args.cpu_seconds)
     if rank == 0:
@@ -144,6 +148,47 @@ def main():
     env.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def fused_leg(env, init, scripts, W, K, T, world, dev, n_per_gpu, B):
+    """cygym_rollout: the same K ticks on the same script, T ticks per launch (open-loop), every tick's
+    observation still written to HBM.  Restarts from the initial state, so its last reward sum must equal
+    the per-tick leg's (same trajectory)."""
+    import torch
+    import torch.distributed as dist
+    T = K if T < 0 else min(T, K)
+    env.load_state(init)
+    for t in range(W):
+        env.step(scripts[t])
+    n_launch = (K + T - 1) // T
+    chunks = []
+    for c in range(n_launch):
+        lo, hi = W + c * T, min(W + K, W + (c + 1) * T)
+        act = {k: torch.stack([scripts[t][k] for t in range(lo, hi)]).contiguous() for k in scripts[0]}
+        _, out = env.alloc_rollout(hi - lo)
+        chunks.append((act, out))
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    env.timer_start()
+    for act, out in chunks:
+        env.rollout(act, out)
+    ev_ms = env.timer_stop()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([wall, ev_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall, ev_ms = float(tt[0]), float(tt[1])
+    achieved = n_per_gpu * K * B / (ev_ms / 1e3) / 1e9
+    return {"what": "cygym_rollout: open-loop, actions of all ticks pre-staged, state on chip between ticks, "
+                    "every tick's obs/reward written", "ticks_per_launch": T,
+            "value": n_per_gpu * world * K / wall, "unit": "env-steps/s", "ms_per_tick": wall / K * 1e3,
+            "roofline_frac": achieved / HBM_PEAK_GBS, "roofline_achieved_GBs": achieved,
+            "last_raw_reward_sum": float(chunks[-1][1]["raw"][-1].sum())}
 
 
 def cpu_baseline(topo, init, cfg, M, L, scripts, W, budget_s):

@@ -222,6 +222,46 @@ class BatchedCyberDefenseEnv:
         _lib.check(self.lib.cygym_step(self._h, C.byref(a), C.byref(self._out), self._stream()), self._h, "cygym_step")
         return self.obs, self.raw, self.shaped, self.done
 
+    def alloc_rollout(self, n_ticks: int):
+        """Action and output tensors with a leading tick dimension for rollout()."""
+        T = int(n_ticks)
+        act = {k: torch.zeros((T,) + tuple(v.shape), dtype=v.dtype, device=self.device) for k, v in self.act.items()}
+        act["exploit"].fill_(-1)
+        act["app"].fill_(-1)
+        out = dict(obs=torch.zeros((T, self.N, self.M, 6), dtype=torch.float32, device=self.device),
+                   raw=torch.zeros((T, self.N), dtype=torch.float64, device=self.device),
+                   shaped=torch.zeros((T, self.N), dtype=torch.float64, device=self.device),
+                   done=torch.zeros((T, self.N), dtype=torch.uint8, device=self.device))
+        return act, out
+
+    def rollout(self, act: dict, out: dict):
+        """T consecutive ticks in ONE launch (cygym_rollout): `act` / `out` carry a leading tick dimension
+        (see alloc_rollout).  Open-loop: every tick's action is staged beforehand.  Same results as T step()
+        calls; an env's state stays on chip between its ticks and envs never wait for each other."""
+        T = int(act["mode"].shape[0])
+        a = abi.Actions()
+        for k in ("mode", "n_groups", "atype", "n_exploit", "exploit", "app", "dev_cnt", "dev_idx"):
+            t = act[k]
+            if not t.is_contiguous() or t.device != self.device or t.shape[0] != T or t.shape[1] != self.N:
+                raise ValueError(f"rollout tensor {k} must be contiguous [T, N, ...] on {self.device}")
+            setattr(a, k, t.data_ptr())
+        a.max_groups = int(act["atype"].shape[2])
+        a.max_devs = int(act["dev_idx"].shape[2])
+        o = abi.Outputs()
+        for k in ("obs", "raw", "shaped", "done"):
+            t = out[k]
+            if not t.is_contiguous() or t.shape[0] != T or t.shape[1] != self.N:
+                raise ValueError(f"rollout output {k} must be contiguous [T, N, ...]")
+            setattr(o, k, t.data_ptr())
+        _lib.check(self.lib.cygym_rollout(self._h, T, C.byref(a), C.byref(o), self._stream()), self._h, "cygym_rollout")
+        return out
+
+    def gen_actions_rollout(self, tick0: int, act: dict):
+        """Fill a [T, N, ...] action dict with the synthetic script for ticks tick0 .. tick0+T-1."""
+        for t in range(act["mode"].shape[0]):
+            self.gen_actions(tick0 + t, {k: v[t] for k, v in act.items()})
+        return act
+
     def set_actions_numpy(self, act_np: dict):
         for k, t in self.act.items():
             a = np.asarray(act_np[k])

@@ -56,6 +56,7 @@ struct DevTopo {
 };
 
 struct KParams {
+  const KParams* self;  // device copy of this struct (fused kernel re-reads it every tick instead of pinning SGPRs)
   DevTopo t;
   cygym_config c;
   cygym_buffers b;
@@ -63,6 +64,7 @@ struct KParams {
   cygym_actions a;
   cygym_outputs o;
   int n_envs;
+  int n_ticks;          // ticks per launch (cygym_rollout); actions / outputs are [n_ticks][N] arrays
   int wave_lds;         // bytes of LDS per wave
   int shared_lds;       // bytes of the workgroup-shared LDS section
   unsigned long long* dbg;   // diagnostic builds (-DCG_STAMPS): [N][16] s_memtime stamps per env
@@ -1059,28 +1061,23 @@ __device__ __forceinline__ void evolve(Env& e, const KParams& P) {
 // ---------------- the tick ----------------
 // MT: devices per env when known at compile time (64, 256: chunk loops unroll and their LDS latencies
 // overlap), 0 = any M at run time.
-template <int WPB, int MT>
-__global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
-  extern __shared__ __align__(16) uint8_t smem[];
-  const int M = MT ? MT : P.t.M, MC = MT ? (MT + WAVE - 1) / WAVE : P.t.MC, Mp = MC * WAVE, MS = (M + 3) & ~3;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int env = uni(blockIdx.x * WPB + wave);
-  const bool live = env < P.n_envs;
-  const int G = P.a.max_groups, L = P.a.max_devs;
-
-  // ---- per-wave LDS carve (must match wave_lds_bytes on the host) ----
+// Per-wave LDS carve + pointer table of one env (must match wave_lds_bytes on the host).
+struct WaveAux { uint64_t* srcb; int32_t* park; };
+__device__ __forceinline__ WaveAux env_setup(Env& e, uint8_t* smem, const KParams& P, int M, int MC, int Mp, int MS,
+                                             int wave, int lane, int env) {
   uint8_t* wb = smem + P.shared_lds + (size_t)wave * P.wave_lds;
-  Env e;
   e.flags = wb; e.busy = wb + MS; e.wl = wb + 2 * MS; e.cby = wb + 3 * MS;
   e.scr = (uint32_t*)(wb + ((4 * MS + 15) & ~15));
   e.blk = e.scr + 2 * Mp;
   e.bin = e.blk + ((P.t.EW + 3) & ~3);
   e.ring = (uint16_t*)(e.bin + ((P.t.EW + 3) & ~3));
   e.marks = (uint32_t*)(e.ring + 2 * CG_LOG_RING);
-  uint64_t* srcb = (uint64_t*)(e.marks + ((Mp / 32 + 2) & ~1));
-  e.lsrc = (uint16_t*)(srcb + MC);
+  WaveAux x;
+  x.srcb = (uint64_t*)(e.marks + ((Mp / 32 + 2) & ~1));
+  e.lsrc = (uint16_t*)(x.srcb + MC);
   e.el = (uint8_t*)(e.lsrc + Mp);
   e.devl = (int16_t*)(e.el + Mp);
+  x.park = (int32_t*)(wb + P.wave_lds - 128);   // [16 i32 + 3 f64] per-env scalars between fused ticks
   e.optr = (const uint16_t*)(smem + P.t.o_optr); e.ocol = (const uint16_t*)(smem + P.t.o_ocol);
   e.osv = (const float*)(smem + P.t.o_os); e.ver = (const float*)(smem + P.t.o_ver); e.ano = (const float*)(smem + P.t.o_ano);
   e.dst = smem + P.t.o_dst; e.vul = smem + P.t.o_vul; e.nap = smem + P.t.o_nap;
@@ -1090,14 +1087,38 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
   e.cbits = 32 - __builtin_clz((unsigned)(4 * ((MS / 4 + WAVE - 1) / WAVE)));
   e.env_id = (uint32_t)(P.c.env_id_base + env);
   e.seed = P.c.seed;
-  e.blk_dirty = e.ring_dirty = false;
   e.multi = P.t.multi != 0;
+  e.stash = P.b.stash + (size_t)env * 4 * M;
+  return x;
+}
+
+// FUSED: cygym_rollout (n_ticks > 1).  The per-env scalars are parked in LDS between ticks so that they are
+// not loop-carried registers; the single-tick instantiation has a compile-time trip count of 1.
+template <int WPB, int MT, bool FUSED>
+__global__ __launch_bounds__(WPB * WAVE, FUSED ? 4 : 1) void step_kernel(const KParams P0) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  // every use below goes through `P`: the kernarg copy for the single-tick kernel, the device copy for the
+  // fused one (so that it can be re-read, opaquely, at the top of every tick)
+  const KParams* pk;
+  if constexpr (FUSED) pk = P0.self; else pk = &P0;
+#define P (*pk)
+  const int M = MT ? MT : P.t.M, MC = MT ? (MT + WAVE - 1) / WAVE : P.t.MC, Mp = MC * WAVE, MS = (M + 3) & ~3;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int env = uni(blockIdx.x * WPB + wave);
+  const bool live = env < P.n_envs;
+  const int G = P.a.max_groups, L = P.a.max_devs;
+
+  Env e;
+  WaveAux aux = env_setup(e, smem, P, M, MC, Mp, MS, wave, lane, live ? env : 0);
+  uint64_t* srcb = aux.srcb;
+  int32_t* park = aux.park;
+  e.env = env;
+  e.blk_dirty = e.ring_dirty = false;
 
   STAMP(0);
   // ---- issue every global load of this tick up front (one memory latency, not a chain) ----
   const size_t so = (size_t)(live ? env : 0) * 4 * M;
   const uint8_t* g_live = P.b.live + so;
-  e.stash = P.b.stash + so;
   int32_t ie[CG_I_COUNT];
   double fe[CG_D_COUNT];
   int mode = 0, ng = 0, at0 = 8, cnt0 = 0, nexp0 = 0, app0 = -1;
@@ -1164,18 +1185,59 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
     for (int q = lane + PF_DEV * WAVE; q < L; q += WAVE) e.devl[q] = gd[q];
   }
   __syncthreads();   // the only workgroup barrier: waves diverge per env from here on
-  if (!live || ng < 0) return;   // n_groups < 0: this env does not tick (per-env stepping inside a batch)
+  if (!live) return;
   STAMP(1);
 
-  e.tick = (uint32_t)ie[CG_I_RNG_TICK];
-  e.eflags = ie[CG_I_FLAGS];
-  e.log_total = ie[CG_I_LOG_TOTAL];
+  const int NW = MS >> 2;
+
+  // ---- ticks of this launch: 1 for cygym_step, T for cygym_rollout (state stays in LDS / registers;
+  // no cross-env synchronisation between ticks) ----
+  const int n_ticks = FUSED ? P.n_ticks : 1;
+  for (int tk = 0; tk < n_ticks; ++tk) {
+  const size_t te = (size_t)tk * P.n_envs + env;   // row of this (tick, env) in the action / output arrays
+  if (FUSED && tk > 0) {   // tick 0's header and list were prefetched with the state
+    // Re-derive everything uniform from the device copy of the parameters: keeping ~200 loop-invariant
+    // scalars alive across the tick body would spill SGPRs into VGPRs and halve the occupancy.
+    {
+      const uint64_t pv = (uint64_t)P0.self;
+      uint32_t plo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pv);
+      uint32_t phi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(pv >> 32));
+      asm volatile("" : "+s"(plo), "+s"(phi));   // opaque: nothing derived from it is hoisted out of the tick loop
+      pk = (const KParams*)(((uint64_t)phi << 32) | plo);
+    }
+    aux = env_setup(e, smem, P, M, MC, Mp, MS, wave, lane, env);
+    srcb = aux.srcb; park = aux.park;
+#pragma unroll
+    for (int i = 0; i < CG_I_COUNT; ++i) ie[i] = park[i];
+#pragma unroll
+    for (int i = 0; i < CG_D_COUNT; ++i) fe[i] = ((const double*)(park + CG_I_COUNT))[i];
+    mode = P.a.mode[te];
+    ng = P.a.n_groups[te];
+    at0 = P.a.atype[te * G];
+    cnt0 = P.a.dev_cnt[te * G];
+    nexp0 = P.a.n_exploit[te * G];
+    app0 = P.a.app[te * G];
+    const int16_t* gd = P.a.dev_idx + te * L;
+    for (int q = lane; q < L; q += WAVE) e.devl[q] = gd[q];
+    wsync();
+  }
+  if (ng < 0) {   // n_groups < 0: this env does not tick (per-env stepping inside a batch)
+    if (FUSED && tk == 0 && lane == 0) {
+#pragma unroll
+      for (int i = 0; i < CG_I_COUNT; ++i) park[i] = ie[i];
+#pragma unroll
+      for (int i = 0; i < CG_D_COUNT; ++i) ((double*)(park + CG_I_COUNT))[i] = fe[i];
+    }
+    continue;
+  }
   const int16_t* devs = e.devl;
   uint32_t* const F = (uint32_t*)e.flags;
   uint32_t* const Bz = (uint32_t*)e.busy;
   uint32_t* const Wl = (uint32_t*)e.wl;
   const uint32_t* const Ds = (const uint32_t*)e.dst;
-  const int NW = MS >> 2;
+  e.tick = (uint32_t)ie[CG_I_RNG_TICK];
+  e.eflags = ie[CG_I_FLAGS];
+  e.log_total = ie[CG_I_LOG_TOTAL];
   double cost = 0.0;
   bool dirty = false;
   int last_atype = -1;
@@ -1208,7 +1270,7 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
       if (at == 1) {
         int ne = nexp0;
         if (ne > CG_MAX_EXPLOITS) ne = CG_MAX_EXPLOITS;
-        attacker_spread(e, P, P.a.exploit + (size_t)env * G * CG_MAX_EXPLOITS, ne, srcb);
+        attacker_spread(e, P, P.a.exploit + te * G * CG_MAX_EXPLOITS, ne, srcb);
       } else {
         attacker_probe(e, srcb, cost);
       }
@@ -1221,8 +1283,8 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
     const int16_t* dp = devs;
     int used = 0;
     for (int g = 0; g < ng && g < G; ++g) {
-      int at = P.a.atype[(size_t)env * G + g];
-      int Ld = P.a.dev_cnt[(size_t)env * G + g];
+      int at = P.a.atype[te * G + g];
+      int Ld = P.a.dev_cnt[te * G + g];
       if (Ld < 0) Ld = 0;
       if (used + Ld > L) Ld = L - used;
       if (mode == CG_MODE_DEFENDER && at == 0) at = 8;
@@ -1296,7 +1358,7 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
   // ---- observation (_get_state CyberDefenseEnv.py:146-191), before evolve.
   // One lane per device PAIR: 12 floats = three 16-byte stores; static columns read as float2.
   if (!(M & 1)) {
-    float4* out4 = (float4*)(P.o.obs + (size_t)env * M * 6);
+    float4* out4 = (float4*)(P.o.obs + te * M * 6);
     const int npairs = M >> 1;
     const uint16_t* F2 = (const uint16_t*)e.flags;
     const float2* os2 = (const float2*)e.osv;
@@ -1311,7 +1373,7 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
       out4[3 * p + 2] = make_float4((float)(fb & 1u), a.y, (float)((fb >> 2) & 1u), (float)((fb >> 4) & 1u));
     }
   } else {   // odd M: rows are not 16-byte aligned across envs
-    float* o = P.o.obs + (size_t)env * M * 6;
+    float* o = P.o.obs + te * M * 6;
     for (int d = lane; d < M; d += WAVE) {
       const uint32_t f = e.flags[d];
       o[6 * d + 0] = e.osv[d]; o[6 * d + 1] = e.ver[d]; o[6 * d + 2] = (float)(f & 1u); o[6 * d + 3] = e.ano[d];
@@ -1334,32 +1396,48 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
   ie[CG_I_FLAGS] = e.eflags | (__any(e.eflags & CG_E_BUSY_SAT) ? CG_E_BUSY_SAT : 0);
 
   if (lane == 0) {
-    P.o.raw[env] = raw;
-    P.o.shaped[env] = shaped;
-    P.o.done[env] = done ? 1 : 0;
+    P.o.raw[te] = raw;
+    P.o.shaped[te] = shaped;
+    P.o.done[te] = done ? 1 : 0;
   }
 
-  if (done && P.c.auto_reset && P.snap.live) {   // reload the initial snapshot; RNG tick stays monotone
+  if (done && P.c.auto_reset && P.snap.live) {   // reload the initial snapshot; the RNG tick stays monotone
     const int si = P.snap.n_envs == 1 ? 0 : env;
     const size_t ss = (size_t)si * 4 * M;
-    for (int i = lane; i < 4 * M; i += WAVE) {
-      P.b.live[so + i] = P.snap.live[ss + i];
-      P.b.stash[so + i] = P.snap.stash[ss + i];
+    wsync();
+    if (vec) {
+      for (int i = lane; i < items; i += WAVE) ((uint4*)e.flags)[i] = ((const uint4*)(P.snap.live + ss))[i];
+    } else {
+      for (int pl = 0; pl < 4; ++pl)
+        for (int i = lane; i < M; i += WAVE) e.flags[pl * MS + i] = P.snap.live[ss + pl * M + i];
     }
+    for (int i = lane; i < 4 * M; i += WAVE) P.b.stash[so + i] = P.snap.stash[ss + i];
     for (int w = lane; w < P.t.EW; w += WAVE) {
-      P.b.blocked[(size_t)env * P.t.EW + w] = P.snap.blocked[(size_t)si * P.t.EW + w];
-      P.b.blocked_in[(size_t)env * P.t.EW + w] = P.snap.blocked_in[(size_t)si * P.t.EW + w];
+      e.blk[w] = P.snap.blocked[(size_t)si * P.t.EW + w];
+      e.bin[w] = P.snap.blocked_in[(size_t)si * P.t.EW + w];
     }
-    if (lane < CG_LOG_RING)
-      ((uint32_t*)(P.b.ring + (size_t)env * CG_LOG_RING * 2))[lane] = ((const uint32_t*)(P.snap.ring + (size_t)si * CG_LOG_RING * 2))[lane];
-    if (lane < CG_I_COUNT) {
-      int32_t v = P.snap.ienv[(size_t)si * CG_I_COUNT + lane];
-      if (lane == CG_I_RNG_TICK) v = ie[CG_I_RNG_TICK];
-      P.b.ienv[(size_t)env * CG_I_COUNT + lane] = v;
-    }
-    if (lane < CG_D_COUNT) P.b.fenv[(size_t)env * CG_D_COUNT + lane] = P.snap.fenv[(size_t)si * CG_D_COUNT + lane];
-    return;
+    if (lane < CG_LOG_RING) ((uint32_t*)e.ring)[lane] = ((const uint32_t*)(P.snap.ring + (size_t)si * CG_LOG_RING * 2))[lane];
+    e.blk_dirty = e.ring_dirty = true;
+    const int32_t keep_tick = ie[CG_I_RNG_TICK];
+    const int32_t* g = P.snap.ienv + (size_t)si * CG_I_COUNT;
+#pragma unroll
+    for (int i = 0; i < CG_I_COUNT; ++i) ie[i] = g[i];
+    ie[CG_I_RNG_TICK] = keep_tick;
+    const double* gf = P.snap.fenv + (size_t)si * CG_D_COUNT;
+#pragma unroll
+    for (int i = 0; i < CG_D_COUNT; ++i) fe[i] = gf[i];
+    wsync();
   }
+  if (FUSED && tk + 1 < n_ticks) {   // park the scalars for the next tick
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < CG_I_COUNT; ++i) park[i] = ie[i];
+#pragma unroll
+      for (int i = 0; i < CG_D_COUNT; ++i) ((double*)(park + CG_I_COUNT))[i] = fe[i];
+    }
+    wsync();
+  }
+  }   // for tk
 
   STAMP(6);
   // ---- write back: the whole [4][M] live block with 16-byte stores ----
@@ -1386,8 +1464,9 @@ __global__ __launch_bounds__(WPB * WAVE) void step_kernel(const KParams P) {
   }
   STAMP(7);
 #ifdef CG_STAMPS
-  if (P.dbg && lane == 0) { P.dbg[(size_t)env * 16 + 8] = (unsigned long long)last_atype; P.dbg[(size_t)env * 16 + 9] = (unsigned long long)mode; }
+  if (P.dbg && lane == 0) { P.dbg[(size_t)env * 16 + 8] = (unsigned long long)(long long)ie[CG_I_LAST_ATYPE]; P.dbg[(size_t)env * 16 + 9] = (unsigned long long)mode; }
 #endif
+#undef P
 }
 
 // ---------------- reset / randomize / observe / action script ----------------
@@ -1570,6 +1649,7 @@ struct cygym_handle {
   int wpb, max_devs;
   int wave_lds, shared_lds;
   hipEvent_t ev0, ev1;
+  KParams* dparams;     // device copy of the launch parameters (read by the fused kernel)
   unsigned long long* dbg;
   char err[256];
 };
@@ -1588,24 +1668,26 @@ static int fail(cygym_handle* h, int code, const char* fmt, const char* detail) 
     if (_e != hipSuccess) return fail(h, CYGYM_EHIP, #call ": %s", hipGetErrorString(_e)); \
   } while (0)
 
-template <int MT>
+template <int MT, bool FUSED>
 static const void* kernel_for(int wpb) {
   switch (wpb) {
-    case 16: return (const void*)step_kernel<16, MT>;
-    case 8: return (const void*)step_kernel<8, MT>;
-    case 4: return (const void*)step_kernel<4, MT>;
-    case 2: return (const void*)step_kernel<2, MT>;
-    default: return (const void*)step_kernel<1, MT>;
+    case 16: return (const void*)step_kernel<16, MT, FUSED>;
+    case 8: return (const void*)step_kernel<8, MT, FUSED>;
+    case 4: return (const void*)step_kernel<4, MT, FUSED>;
+    case 2: return (const void*)step_kernel<2, MT, FUSED>;
+    default: return (const void*)step_kernel<1, MT, FUSED>;
   }
 }
-static const void* pick_kernel(const cygym_handle* h) {
-  if (h->t.M == 256) return kernel_for<256>(h->wpb);
-  if (h->t.M == 64) return kernel_for<64>(h->wpb);
-  return kernel_for<0>(h->wpb);
+static const void* pick_kernel(const cygym_handle* h, bool fused) {
+  if (h->t.M == 256) return fused ? kernel_for<256, true>(h->wpb) : kernel_for<256, false>(h->wpb);
+  if (h->t.M == 64) return fused ? kernel_for<64, true>(h->wpb) : kernel_for<64, false>(h->wpb);
+  return fused ? kernel_for<0, true>(h->wpb) : kernel_for<0, false>(h->wpb);
 }
 static hipError_t set_lds_attr(cygym_handle* h) {
   const int lds = h->shared_lds + h->wave_lds * h->wpb;
-  return hipFuncSetAttribute(pick_kernel(h), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipError_t e = hipFuncSetAttribute(pick_kernel(h, false), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(pick_kernel(h, true), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
 
 extern "C" {
@@ -1619,7 +1701,7 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static size_t wave_lds_bytes(const DevTopo& t, int max_devs) {
   size_t w = align_up((size_t)4 * ((t.M + 3) & ~3), 16) + (size_t)t.Mp * 8 + (size_t)((t.EW + 3) & ~3) * 4 * 2 + CG_LOG_RING * 4 +
              (size_t)((t.Mp / 32 + 2) & ~1) * 4 + (size_t)t.MC * 8 + (size_t)t.Mp * 2 + (size_t)t.Mp +
-             align_up((size_t)max_devs * 2, 16);
+             align_up((size_t)max_devs * 2, 16) + 128 /* scalar parking of the fused kernel */;
   return align_up(w, 16);
 }
 // The in-CSR (iptr/icol/ieid/oeid, ~2/3 of the blob) is read by block/unblock only (~9 % of env-ticks):
@@ -1730,6 +1812,7 @@ int cygym_create(const cygym_topology* topo, const cygym_config* cfg, int32_t n_
   if (e1 == hipSuccess) e1 = hipMemcpy(h->dev_blob, host, off, hipMemcpyHostToDevice);
   free(host);
   if (e1 == hipSuccess) e1 = hipMalloc((void**)&h->keybuf, (size_t)n_envs * t.Mp * 4);
+  if (e1 == hipSuccess) e1 = hipMalloc((void**)&h->dparams, sizeof(KParams));
   if (e1 == hipSuccess) e1 = hipEventCreate(&h->ev0);
   if (e1 == hipSuccess) e1 = hipEventCreate(&h->ev1);
   if (e1 != hipSuccess) { fail(nullptr, CYGYM_EHIP, "cygym_create: %s", hipGetErrorString(e1)); cygym_destroy(h); return CYGYM_EHIP; }
@@ -1750,6 +1833,7 @@ void cygym_destroy(cygym_handle* h) {
   if (!h) return;
   if (h->dev_blob) (void)hipFree(h->dev_blob);
   if (h->keybuf) (void)hipFree(h->keybuf);
+  if (h->dparams) (void)hipFree(h->dparams);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   delete h;
@@ -1846,7 +1930,12 @@ int cygym_set_snapshot(cygym_handle* h, const cygym_buffers* snapshot) {
 }
 
 int cygym_step(cygym_handle* h, const cygym_actions* a, const cygym_outputs* o, void* stream) {
+  return cygym_rollout(h, 1, a, o, stream);
+}
+
+int cygym_rollout(cygym_handle* h, int32_t n_ticks, const cygym_actions* a, const cygym_outputs* o, void* stream) {
   if (!h || !h->bound) return fail(h, CYGYM_ENOTBOUND, "cygym_step: handle not bound%s", "");
+  if (n_ticks < 1) return fail(h, CYGYM_EINVAL, "cygym_rollout: n_ticks must be >= 1%s", "");
   if (!a || !o || !a->mode || !a->n_groups || !a->atype || !a->n_exploit || !a->exploit || !a->app ||
       !a->dev_cnt || !a->dev_idx || !o->obs || !o->raw || !o->shaped || !o->done)
     return fail(h, CYGYM_EINVAL, "cygym_step: null action / output pointer%s", "");
@@ -1860,13 +1949,16 @@ int cygym_step(cygym_handle* h, const cygym_actions* a, const cygym_outputs* o, 
   HIPCHK(h, hipSetDevice(h->device_id));
   KParams P = make_params(h);
   P.a = *a; P.o = *o;
+  P.n_ticks = n_ticks;
   P.snap = h->snap;
+  P.self = h->dparams;
+  if (n_ticks > 1) HIPCHK(h, hipMemcpyAsync(h->dparams, &P, sizeof(KParams), hipMemcpyHostToDevice, (hipStream_t)stream));
   const int lds = h->shared_lds + h->wave_lds * h->wpb;
   const dim3 grid((h->n_envs + h->wpb - 1) / h->wpb), block(h->wpb * WAVE);
   hipStream_t s = (hipStream_t)stream;
   {
     void* args[] = {(void*)&P};
-    HIPCHK(h, hipLaunchKernel(pick_kernel(h), grid, block, args, (size_t)lds, s));
+    HIPCHK(h, hipLaunchKernel(pick_kernel(h, n_ticks > 1), grid, block, args, (size_t)lds, s));
   }
   HIPCHK(h, hipGetLastError());
   return CYGYM_OK;

@@ -180,6 +180,14 @@ int cygym_randomize(cygym_handle* h, const int32_t* env_ids, int32_t n, void* st
  * arrivals :575-596 / CDSimulator.py:244-348, logger/detector CDSimulator.py:663-742. */
 int cygym_step(cygym_handle* h, const cygym_actions* a, const cygym_outputs* o, void* stream);
 
+/* n_ticks consecutive ticks in ONE launch: every array of `a` and `o` has a leading tick
+ * dimension ([n_ticks][N]...), the actions of all ticks are staged beforehand (open-loop
+ * policies: baselines, fixed action sequences `strat.actions[t % len]` do_agent.py:2052, or
+ * any pre-computed script).  Same results as n_ticks calls of cygym_step, but an env's state
+ * stays on chip between its ticks and envs do not wait for each other between ticks. */
+int cygym_rollout(cygym_handle* h, int32_t n_ticks, const cygym_actions* a, const cygym_outputs* o,
+                  void* stream);
+
 /* Replaces: _get_state / _get_defender_state / _get_attacker_state
  * CyberDefenseEnv.py:146-257.  role 0: full [N][6M]; 1: defender [N][6M];
  * 2: attacker [N][4M + MaxExploits].  out: DEVICE float32. */

@@ -189,3 +189,33 @@ def test_full_size_properties(M, blocks, N):
     assert (full["ienv"][:, S.I_DEF_STEP] + full["ienv"][:, S.I_ATT_STEP] == ticks).all()
     assert np.isfinite(ret.cpu().numpy()).all()
     env.close(); tail.close()
+
+
+@pytest.mark.parametrize("M,blocks,N,T", [(64, 4, 96, 37), (256, 1, 128, 30), (600, 4, 24, 22)])
+def test_rollout_equals_stepwise(M, blocks, N, T):
+    """cygym_rollout (T ticks fused in one launch) == T calls of cygym_step == the oracle, including an
+    episode cap with auto-reset in the middle."""
+    topo, cfg, env, ob, L = _oracle_pair(M, blocks, N, seed=21, n_active=M - 8, env_id_base=5,
+                                         cfg_kw=dict(episode_limit=17, auto_reset=1))
+    from cygym_amd.batched_env import BatchedCyberDefenseEnv
+    topo2, init2, _ = make_topology(M, blocks, seed=21, n_active=M - 8)
+    fused = BatchedCyberDefenseEnv(topo2, cfg, N, init2, device="cuda:0", max_groups=1, max_devs=L)
+    act, out = fused.alloc_rollout(T)
+    fused.gen_actions_rollout(0, act)
+    fused.rollout(act, out)
+    for t in range(T):
+        env.gen_actions(t)
+        obs, raw, shaped, done = env.step()
+        o_obs, o_raw, o_shaped, o_done = ob.step(gen_actions_numpy(cfg.seed, cfg.env_id_base, N, M, topo.X, t, L))
+        assert torch.equal(out["obs"][t], obs), f"obs t={t}"
+        assert torch.equal(out["raw"][t], raw) and torch.equal(out["shaped"][t], shaped) and torch.equal(out["done"][t], done)
+        np.testing.assert_allclose(raw.cpu().numpy(), o_raw, rtol=0, atol=1e-9)
+        np.testing.assert_array_equal(done.cpu().numpy(), o_done)
+    a, b = fused.state_numpy(), env.state_numpy()
+    for k in ("live", "stash", "blocked", "blocked_in", "ring", "ienv", "fenv"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    b["ienv"] = b["ienv"].copy()
+    b["ienv"][:, S.I_FLAGS] &= ~0x80
+    assert not gio.compare_state(b, ob.state, "stepwise vs oracle")
+    assert out["done"].any(), "the episode cap must have been crossed"
+    env.close(); fused.close()

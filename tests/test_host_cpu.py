@@ -128,3 +128,24 @@ def test_philox_known_answers():
     v = R.draw_np(7, np.arange(5), 3, S.SITE_ARR_TIME, np.arange(5), 0)
     assert [int(x) for x in v] == [R.draw(7, e, 3, S.SITE_ARR_TIME, e, 0) for e in range(5)]
     assert R.poisson_table(0.0)[0] == 1 << 32 and R.bernoulli_threshold(0.0) == 0 and R.bernoulli_threshold(1.0) == 1 << 32
+
+
+def test_tick_kernels_do_not_spill():
+    """A select between addresses of struct members once pinned the whole per-wave state in scratch and cost
+    40 % throughput: the per-tick kernels must stay spill-free (the fused rollout kernel is register-capped
+    at 128 for 4 waves/SIMD and may spill a little)."""
+    import json
+    from cygym_amd import build as B
+    B.build()
+    if not os.path.exists(B.RESOURCES):
+        B.build(force=True)
+    res = json.load(open(B.RESOURCES))
+    ticks = {k: v for k, v in res.items() if "step_kernel" in k}
+    assert ticks, "no step_kernel instantiations found in the resource report"
+    for name, r in ticks.items():
+        fused = "ELb1E" in name
+        if fused:
+            assert r["scratch"] <= 256, (name, r)
+        else:
+            assert r["scratch"] == 0 and r.get("vgpr_spill", 0) == 0, (name, r)
+            assert r["vgprs"] <= 128, (name, r)
