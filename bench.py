@@ -72,9 +72,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal aid (one-GPU box): CYGYM_BENCH_BACKEND=gloo CYGYM_BENCH_SAME_GPU=1 runs every rank on cuda:0
+    # with CPU collectives, to exercise the multi-rank code path without a second GPU.
+    backend = os.environ.get("CYGYM_BENCH_BACKEND", "nccl")
+    if os.environ.get("CYGYM_BENCH_SAME_GPU") == "1":
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     dev = torch.device(f"cuda:{local_rank}")
@@ -115,7 +123,7 @@ def main():
     torch.cuda.synchronize(dev)
     wall = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([wall, ev_ms], dtype=torch.float64, device=dev)
+        tt = torch.tensor([wall, ev_ms], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall, ev_ms = float(tt[0]), float(tt[1])
 
@@ -139,8 +147,20 @@ def main():
         "check": {"last_raw_reward_sum": ret_sum},
     }
 
+    # HBM traffic of the dominant kernel from the committed PMC pass of this same command
+    # (profiles/: separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled per the gfx950 note)
+    pmc = os.path.join(ROOT, "profiles", "r01_v5_target_pmc_summary.json")
+    if args.workload == "target" and not args.envs and os.path.exists(pmc):
+        try:
+            c = json.load(open(pmc))["per_tick"]
+            out["roofline"]["traffic"] = (2.0 * c["FETCH_SIZE"]["mean_per_launch"] + c["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
+            out["roofline"]["traffic_unit"] = "bytes per launch"
+            out["roofline"]["traffic_source"] = "profiles/r01_v5_target_pmc_summary.json (rocprofv3 --pmc, same command)"
+            out["roofline"]["algorithmic_bytes_per_launch"] = n_per_gpu * B
+        except Exception:
+            pass
     if args.fused:
-        out["fused_rollout"] = fused_leg(env, init, scripts, W, K, args.fused, world, dev, n_per_gpu, B)
+        out["fused_rollout"] = fused_leg(env, init, scripts, W, K, args.fused, world, dev, n_per_gpu, B, backend)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(topo, init, cfg, M, L, scripts, W, args.cpu_seconds)
     if rank == 0:
@@ -150,7 +170,7 @@ def main():
         dist.destroy_process_group()
 
 
-def fused_leg(env, init, scripts, W, K, T, world, dev, n_per_gpu, B):
+def fused_leg(env, init, scripts, W, K, T, world, dev, n_per_gpu, B, backend="nccl"):
     """cygym_rollout: the same K ticks on the same script, T ticks per launch (open-loop), every tick's
     observation still written to HBM.  Restarts from the initial state, so its last reward sum must equal
     the per-tick leg's (same trajectory)."""
@@ -180,7 +200,7 @@ def fused_leg(env, init, scripts, W, K, T, world, dev, n_per_gpu, B):
         dist.barrier()
     wall = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([wall, ev_ms], dtype=torch.float64, device=dev)
+        tt = torch.tensor([wall, ev_ms], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall, ev_ms = float(tt[0]), float(tt[1])
     achieved = n_per_gpu * K * B / (ev_ms / 1e3) / 1e9

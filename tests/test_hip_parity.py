@@ -84,7 +84,8 @@ def _oracle_pair(M, blocks, N, seed, n_active=None, cfg_kw=None, env_id_base=0):
     return topo, cfg, env, ob, L
 
 
-@pytest.mark.parametrize("M,blocks,N,ticks,n_active", [(16, 2, 64, 300, 12), (64, 4, 512, 260, 56),
+@pytest.mark.parametrize("M,blocks,N,ticks,n_active", [(13, 1, 40, 200, 11), (37, 2, 33, 200, 30), (130, 3, 65, 120, 120),
+                                                       (16, 2, 64, 300, 12), (64, 4, 512, 260, 56),
                                                        (256, 1, 256, 160, 230), (600, 4, 48, 60, 560),
                                                        (2048, 32, 24, 40, 2000)])
 def test_hip_matches_oracle_synthetic(M, blocks, N, ticks, n_active):
