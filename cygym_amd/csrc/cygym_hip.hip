@@ -140,7 +140,6 @@ struct Env {
   uint16_t* ring;    // [2*CG_LOG_RING]
   uint32_t* marks;   // [Mp/32 + 2]
   uint16_t* lsrc;    // [Mp] long-row sources of the spread
-  uint8_t* el;       // [Mp] spread eligibility bytes
   int16_t* devl;     // [L] this tick's device lists (all groups, concatenated)
   // shared LDS (topology)
   const uint16_t *optr, *ocol;
@@ -405,6 +404,7 @@ __device__ __forceinline__ void def_per_device(Env& e, const KParams& P, int at,
   const int M = e.M;
   if (at == 1) { def_clean(e, P, dev, L, cost, ie, fe, nullptr); return; }
   if (at == 6 || at == 9) {  // sequential semantics: each pick changes the pools of BOTH endpoints
+    __builtin_amdgcn_s_setprio(3);   // long path: see the spread
     const uint32_t site = at == 6 ? CG_SITE_PICK_BLOCK : CG_SITE_PICK_UNBLOCK;
     const bool want = (at == 9);
     const bool simple = list_is_simple(e, dev, L);   // no device twice => occurrence number is always 0
@@ -471,6 +471,7 @@ __device__ __forceinline__ void def_per_device(Env& e, const KParams& P, int at,
     fe[CG_D_DEF_COST] += 0.5 * n_act * ds;
     if (at == 6) ie[CG_I_EDGES_BLOCKED] += n_hit; else ie[CG_I_EDGES_ADDED] += n_hit;
     if (n_hit) dirty = true;
+    __builtin_amdgcn_s_setprio(0);
     return;
   }
   if (at == 12) {  // :1102-1109: the reference restores device_indices[0] once per listed active device
@@ -588,23 +589,28 @@ __device__ __forceinline__ void def_per_device(Env& e, const KParams& P, int at,
 constexpr int LONG_ROW = 8;
 #define CG_D_FULLROW 0x04  // library-private static bit: the out-row is "every other device, ascending"
 
-// eligibility byte per device, rebuilt per exploit pass: bit0 reachable, bit1 known & vulnerable
-__device__ __forceinline__ bool spread_ok(const uint8_t* el, const uint32_t* T, int v, int s) {
-  uint8_t x = el[v];
-  return (x & 1) || ((x & 2) && (T[v] >= (uint32_t)(s + 1)));
+// T[v] = (first-compromise time << 2) | eligibility bits (bit0 reachable, bit1 known & vulnerable to this
+// exploit): one LDS word answers "can source s take v".  atomicMin keeps the (constant) low bits intact.
+#define T_TIME_INF 0x3FFFFFFFu
+__device__ __forceinline__ bool spread_ok(const uint32_t* T, int v, int s) {
+  const uint32_t t = T[v];
+  return (t & 1u) || ((t & 2u) && ((t >> 2) >= (uint32_t)(s + 1)));
+}
+__device__ __forceinline__ void spread_take(uint32_t* T, int v, int s) {
+  atomicMin(&T[v], ((uint32_t)(s + 1) << 2) | (T[v] & 3u));
 }
 // first slot k in [from, o1) that source s can take, or o1
-__device__ __forceinline__ int spread_scan_lane(const Env& e, const uint8_t* el, const uint32_t* T, int s, bool dc,
+__device__ __forceinline__ int spread_scan_lane(const Env& e, const uint32_t* T, int s, bool dc,
                                                 int from, int o1) {
   for (int k = from; k < o1; ++k) {
     if (e.blocked(k)) continue;
-    if (dc || spread_ok(el, T, e.ocol[k], s)) return k;
+    if (dc || spread_ok(T, e.ocol[k], s)) return k;
   }
   return o1;
 }
 // same for a FULL row (slot k <-> device v = k - o0 + (k - o0 >= s)): walk the candidate-device bitmask
 // instead of the row; `cand` holds reach | (known & vulnerable & not compromised at the start)
-__device__ __forceinline__ int spread_scan_full(const Env& e, const uint8_t* el, const uint32_t* T, const uint64_t* cand,
+__device__ __forceinline__ int spread_scan_full(const Env& e, const uint32_t* T, const uint64_t* cand,
                                                 int s, int from, int o0, int o1) {
   if (from >= o1) return o1;
   int v_from = from - o0; if (v_from >= s) ++v_from;
@@ -617,17 +623,17 @@ __device__ __forceinline__ int spread_scan_full(const Env& e, const uint8_t* el,
       if (v == s) continue;
       int k = o0 + v - (v > s ? 1 : 0);
       if (e.blocked(k)) continue;
-      if (spread_ok(el, T, v, s)) return k;
+      if (spread_ok(T, v, s)) return k;
     }
   }
   return o1;
 }
-__device__ __forceinline__ int spread_scan_coop(const Env& e, const uint8_t* el, const uint32_t* T, int s, bool dc,
+__device__ __forceinline__ int spread_scan_coop(const Env& e, const uint32_t* T, int s, bool dc,
                                                 int from, int o1) {
   for (int k0 = from; k0 < o1; k0 += WAVE) {
     int k = k0 + e.lane;
     bool p = false;
-    if (k < o1 && !e.blocked(k)) p = dc || spread_ok(el, T, e.ocol[k], s);
+    if (k < o1 && !e.blocked(k)) p = dc || spread_ok(T, e.ocol[k], s);
     uint64_t m = ballot(p);
     if (m) return k0 + __builtin_ctzll(m);
   }
@@ -640,7 +646,6 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KParams& P, const 
   uint32_t* T = e.scr;                          // [Mp] first-compromise time (source id + 1)
   uint16_t* cur = (uint16_t*)(e.scr + Mp);      // [Mp] current pick (slot) per source DEVICE, row end = none
   uint16_t* cntv = cur + Mp;                    // [Mp] log entries per COMPACT source index
-  uint8_t* el = e.el;                           // [Mp] eligibility byte per device (this exploit)
   uint16_t* slist = e.lsrc;                     // [Mp] the sources in id order (snapshot :1127)
   uint64_t* cand = (uint64_t*)e.marks;          // [MC] candidate-device bitmask for full rows
   int n_src = 0;
@@ -671,8 +676,7 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KParams& P, const 
       int d = c * WAVE + e.lane;
       uint8_t f = d < M ? e.flags[d] : 0;
       uint8_t x = (uint8_t)(((f & CG_F_REACH) ? 1 : 0) | (((f & CG_F_KNOWN) && d < M && (e.vul[d] & ebit)) ? 2 : 0));
-      T[d] = (f & CG_F_COMP) ? 0u : T_INF;
-      el[d] = x;
+      T[d] = (((f & CG_F_COMP) ? 0u : T_TIME_INF) << 2) | x;
       cur[d] = d < M ? e.optr[d] : 0;
       uint64_t cm = ballot((x & 1) || ((x & 2) && !(f & CG_F_COMP)));
       if (e.lane == 0) cand[c] = cm;
@@ -694,16 +698,16 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KParams& P, const 
           o0 = e.optr[s]; o1 = e.optr[s + 1]; k0 = cur[s]; st = e.dst[s];
           const bool dc = st & CG_D_DC;
           int k = k0;
-          if (o1 - o0 <= LONG_ROW) k = spread_scan_lane(e, el, T, s, dc, k0, o1);
+          if (o1 - o0 <= LONG_ROW) k = spread_scan_lane(e, T, s, dc, k0, o1);
           else if ((st & CG_D_FULLROW) && !dc) {
-            if (!(k0 < o1 && !e.blocked(k0) && spread_ok(el, T, e.ocol[k0], s)))
-              k = spread_scan_full(e, el, T, cand, s, round == 0 ? k0 : k0 + 1, o0, o1);
+            if (!(k0 < o1 && !e.blocked(k0) && spread_ok(T, e.ocol[k0], s)))
+              k = spread_scan_full(e, T, cand, s, round == 0 ? k0 : k0 + 1, o0, o1);
           } else {
-            coop = round == 0 || (k0 < o1 && !(dc || spread_ok(el, T, e.ocol[k0], s)));
+            coop = round == 0 || (k0 < o1 && !(dc || spread_ok(T, e.ocol[k0], s)));
           }
           if (!coop) {
             if (k != k0) { cur[s] = (uint16_t)k; changed = true; }
-            if (k < o1 && (round == 0 || k != k0)) atomicMin(&T[e.ocol[k]], (uint32_t)(s + 1));
+            if (k < o1 && (round == 0 || k != k0)) spread_take(T, e.ocol[k], s);
           }
         }
         uint64_t nm = ballot(coop);   // long rows that are not "full": wave-cooperative (re)scan
@@ -712,11 +716,11 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KParams& P, const 
           nm &= nm - 1;
           const int ls = __shfl(s, src_lane), lo1 = __shfl(o1, src_lane), lk0 = __shfl(k0, src_lane);
           const int lst = __shfl((int)st, src_lane);
-          int k = spread_scan_coop(e, el, T, ls, lst & CG_D_DC, round == 0 ? lk0 : lk0 + 1, lo1);
+          int k = spread_scan_coop(e, T, ls, lst & CG_D_DC, round == 0 ? lk0 : lk0 + 1, lo1);
           if (k != lk0) changed = true;
           if (e.lane == 0) {
             cur[ls] = (uint16_t)k;
-            if (k < lo1) atomicMin(&T[e.ocol[k]], (uint32_t)(ls + 1));
+            if (k < lo1) spread_take(T, e.ocol[k], ls);
           }
         }
       }
@@ -793,7 +797,7 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KParams& P, const 
     SUBSTAMP(13);
     // apply: compromise flags + DC attribution (:1163-1185)
     for (int d = e.lane; d < M; d += WAVE)
-      if (T[d] != T_INF && T[d] != 0u) e.flags[d] |= CG_F_COMP;
+      if ((T[d] >> 2) != T_TIME_INF && (T[d] >> 2) != 0u) e.flags[d] |= CG_F_COMP;
     for (int i = e.lane; i < n_src; i += WAVE) {
       int s = slist[i];
       if ((e.dst[s] & CG_D_DC) && cur[s] < e.optr[s + 1]) byte_or(e.cby, e.ocol[cur[s]], ebit);
@@ -1075,8 +1079,7 @@ __device__ __forceinline__ WaveAux env_setup(Env& e, uint8_t* smem, const KParam
   WaveAux x;
   x.srcb = (uint64_t*)(e.marks + ((Mp / 32 + 2) & ~1));
   e.lsrc = (uint16_t*)(x.srcb + MC);
-  e.el = (uint8_t*)(e.lsrc + Mp);
-  e.devl = (int16_t*)(e.el + Mp);
+  e.devl = (int16_t*)(e.lsrc + Mp);
   x.park = (int32_t*)(wb + P.wave_lds - 128);   // [16 i32 + 3 f64] per-env scalars between fused ticks
   e.optr = (const uint16_t*)(smem + P.t.o_optr); e.ocol = (const uint16_t*)(smem + P.t.o_ocol);
   e.osv = (const float*)(smem + P.t.o_os); e.ver = (const float*)(smem + P.t.o_ver); e.ano = (const float*)(smem + P.t.o_ano);
@@ -1270,7 +1273,9 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? 4 : 1) void step_kernel(const K
       if (at == 1) {
         int ne = nexp0;
         if (ne > CG_MAX_EXPLOITS) ne = CG_MAX_EXPLOITS;
+        __builtin_amdgcn_s_setprio(3);   // the spread bounds the launch: win issue arbitration over short envs
         attacker_spread(e, P, P.a.exploit + te * G * CG_MAX_EXPLOITS, ne, srcb);
+        __builtin_amdgcn_s_setprio(0);
       } else {
         attacker_probe(e, srcb, cost);
       }
@@ -1700,7 +1705,7 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // LDS budget: shared blob prefix + WPB per-wave regions.  Prefers staging the in-CSR too.
 static size_t wave_lds_bytes(const DevTopo& t, int max_devs) {
   size_t w = align_up((size_t)4 * ((t.M + 3) & ~3), 16) + (size_t)t.Mp * 8 + (size_t)((t.EW + 3) & ~3) * 4 * 2 + CG_LOG_RING * 4 +
-             (size_t)((t.Mp / 32 + 2) & ~1) * 4 + (size_t)t.MC * 8 + (size_t)t.Mp * 2 + (size_t)t.Mp +
+             (size_t)((t.Mp / 32 + 2) & ~1) * 4 + (size_t)t.MC * 8 + (size_t)t.Mp * 2 +
              align_up((size_t)max_devs * 2, 16) + 128 /* scalar parking of the fused kernel */;
   return align_up(w, 16);
 }

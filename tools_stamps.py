@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__)); sys.path.insert(0, ROOT)
 from cygym_amd import abi, build as B
 so = os.path.join(ROOT, "cygym_amd", "libcygym_hip_stamps.so")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DCG_STAMPS",
-                       "-I" + B.INC, "-o", so, B.SRC])
+                       "-I" + B.INC, "-o", so, os.environ.get("CYGYM_SRC", B.SRC)])
 from cygym_amd import _lib
 _lib.SO = so
 from cygym_amd.batched_env import BatchedCyberDefenseEnv
@@ -38,6 +38,10 @@ for t in range(40):
         m = at == 1
         if m.any():
             sub = d[m]
+            if os.environ.get("CYGYM_SRC"):
+                r2 = sub[:, 15] >= 2
+                print("   DIAG rounds: round0", int((sub[:, 12] - sub[:, 10]).mean()), "round1", int((sub[r2, 13] - sub[r2, 12]).mean()),
+                      "rest-of-rounds", int((sub[r2, 11] - sub[r2, 13]).mean()), "n>=2 frac", r2.mean())
             print("   spread sub-phases (mean cycles): setup", int((sub[:, 10] - sub[:, 1]).mean()), "rounds", int((sub[:, 11] - sub[:, 10]).mean()),
                   "logcnt", int((sub[:, 12] - sub[:, 11]).mean()), "ring", int((sub[:, 13] - sub[:, 12]).mean()),
                   "apply", int((sub[:, 14] - sub[:, 13]).mean()), " n_rounds mean", sub[:, 15].mean(), "max", sub[:, 15].max())
