@@ -184,8 +184,16 @@ class CyberDefenseEnvView:
     def _get_attacker_state(self):
         return self._obs(2).astype(np.float32)
 
-    def _get_ordered_devices(self):
-        raise NotImplementedError("the object facade over the SoA (SURVEY.md 8f rank 2) is not built yet")
+    @property
+    def simulator(self):
+        """Read-only object facade (`env.simulator.subnet.net[i].isCompromised`, `.graph`, `.exploits`,
+        `.logger.get_logs()`), rebuilt from the current state on every access."""
+        from .facade import SimulatorView
+        return SimulatorView(self)
+
+    def _get_ordered_devices(self):                      # CyberDefenseEnv.py:95-102
+        net = self.simulator.subnet.net
+        return [net[i] for i in sorted(net.keys())][: self._b.M]
 
     # ---- episode control -----------------------------------------------------
     def initialize_environment(self):

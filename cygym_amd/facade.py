@@ -1,0 +1,153 @@
+"""Read-only object facade over one env of the batch.
+
+Some reference agents walk the simulator's object graph instead of the flat
+observation: `env._get_ordered_devices()` (IPPO.py:86 build_visibility_mask),
+`env.simulator.subnet.net` (HMARL.py:126-137, 339, 470, 539), `.graph.get_edgelist()`
+(meta_hierarchical_br.py:74-96), `env.simulator.exploits`, `logger.get_logs()`.
+These classes answer those reads from the struct-of-arrays state; they hold a
+host copy of the env's planes taken when the facade object was created, and are
+read-only (the tick is the only writer).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import spec as S
+
+
+class WorkloadView:
+    __slots__ = ("processing_time", "adversarial", "wtype", "assigned")
+
+    def __init__(self, processing_time, adversarial, wtype):
+        self.processing_time = int(processing_time)
+        self.adversarial = bool(adversarial)
+        self.wtype = wtype
+        self.assigned = True
+
+
+class DeviceView:
+    """Attribute names of CDSimulatorComponents.Device (:217-243)."""
+    __slots__ = ("id", "isCompromised", "attacker_owned", "Known_to_attacker", "reachable_by_attacker",
+                 "Not_yet_added", "busy_time", "workload", "device_type", "wtype", "anomaly_score",
+                 "compromised_by", "version", "n_apps")
+
+    def getId(self):
+        return self.id
+
+    def __repr__(self):
+        return f"DeviceView(id={self.id}, comp={self.isCompromised}, owned={self.attacker_owned}, nya={self.Not_yet_added})"
+
+
+class ExploitView:
+    __slots__ = ("id", "index", "discovered")
+
+    def getId(self):
+        return self.id
+
+
+class GraphView:
+    """The cached adjacency (_outnbrs / _innbrs) with python-igraph's read accessors."""
+
+    def __init__(self, topo, blocked_bits):
+        self._t = topo
+        self._blocked = blocked_bits
+
+    def vcount(self):
+        return self._t.M
+
+    def ecount(self):
+        return self._t.E
+
+    def get_edgelist(self):
+        src = np.repeat(np.arange(self._t.M), np.diff(self._t.out_ptr))
+        return [(int(u), int(v)) for u, v in zip(src, self._t.out_col)]
+
+    def neighbors(self, v, mode="all"):
+        t = self._t
+        out = [int(x) for x in t.out_col[t.out_ptr[v]:t.out_ptr[v + 1]]]
+        inn = [int(x) for x in t.in_col[t.in_ptr[v]:t.in_ptr[v + 1]]]
+        m = str(mode).lower()
+        return out if m == "out" else inn if m == "in" else sorted(out + inn)
+
+    def get_adjlist(self, mode="out"):
+        return [self.neighbors(v, mode) for v in range(self._t.M)]
+
+    def degree(self, v=None, mode="all"):
+        if v is None:
+            return [len(self.neighbors(i, mode)) for i in range(self._t.M)]
+        if isinstance(v, (list, tuple, range)):
+            return [len(self.neighbors(i, mode)) for i in v]
+        return len(self.neighbors(v, mode))
+
+    def blocked_edges(self):
+        src = np.repeat(np.arange(self._t.M), np.diff(self._t.out_ptr))
+        return {(int(src[k]), int(self._t.out_col[k])) for k in np.nonzero(self._blocked)[0]}
+
+
+class SubnetView:
+    def __init__(self, net, graph):
+        self.net = net
+        self.graph = graph
+
+
+class LoggerView:
+    def __init__(self, logs):
+        self.logs = logs
+
+    def get_logs(self):
+        return self.logs
+
+
+class DetectorView:
+    def __init__(self, eflags):
+        self.trained = bool(eflags & S.E_DET_TRAIN)
+        self.random_detection = bool(eflags & S.E_DET_RANDOM)
+
+
+class SimulatorView:
+    """What `env.simulator` exposes to the reference's agents."""
+
+    def __init__(self, view):
+        from . import abi
+        b, i = view._b, view._i
+        st = {k: b.state[k][i].cpu().numpy() for k in ("live", "blocked", "ienv")}
+        flags, busy, wl, cby = st["live"]
+        topo = b.topo
+        net = {}
+        for d in range(topo.M):
+            dv = DeviceView()
+            f = int(flags[d])
+            dv.id = d
+            dv.isCompromised = bool(f & S.F_COMP)
+            dv.attacker_owned = bool(f & S.F_OWNED)
+            dv.Known_to_attacker = bool(f & S.F_KNOWN)
+            dv.reachable_by_attacker = bool(f & S.F_REACH)
+            dv.Not_yet_added = bool(f & S.F_NYA)
+            dv.busy_time = int(busy[d])
+            dv.device_type = "DomainController" if topo.dstatic[d] & S.D_DC else None
+            dv.wtype = "server" if topo.dstatic[d] & S.D_SERVER else "client"
+            dv.anomaly_score = float(topo.anomaly[d])
+            dv.version = float(topo.version[d])
+            dv.n_apps = int(topo.napps[d])
+            dv.workload = WorkloadView(wl[d], f & S.F_WLADV, dv.wtype) if wl[d] > 0 else None
+            dv.compromised_by = {e for e in range(topo.X) if (int(cby[d]) >> e) & 1}
+            net[d] = dv
+        bits = abi.unpack_blocked(st["blocked"].view(np.uint32)[None], topo.E)[0]
+        self.subnet = SubnetView(net, GraphView(topo, bits))
+        disc = int(st["ienv"][S.I_DISCOVERED])
+        self.exploits = []
+        for e in range(topo.X):
+            ex = ExploitView()
+            ex.id = e
+            ex.index = e
+            ex.discovered = bool((disc >> e) & 1)
+            self.exploits.append(ex)
+        self.logger = LoggerView(view._logs())
+        self.detector = DetectorView(int(st["ienv"][S.I_FLAGS]))
+        self.system_time = 0
+
+    def getExploitsSize(self):
+        return len(self.exploits)
+
+    def getSubnetSize(self):
+        return len(self.subnet.net)

@@ -92,3 +92,35 @@ def test_view_errors_and_reset():
     a = env.sample_action()
     assert len(a) == 4
     batch.close()
+
+
+def test_object_facade_reads_the_soa():
+    """The reads the reference's agents make on env internals (IPPO.py:74-96, HMARL.py:126-137)."""
+    from cygym_amd.batched_env import BatchedCyberDefenseEnv
+    from cygym_amd.env_view import CyberDefenseEnvView
+    fx = gio.Fixture("s64_mixed")
+    batch = BatchedCyberDefenseEnv(fx.topo, fx.cfg, fx.N, fx.init, device="cuda:0", max_groups=1, max_devs=fx.L)
+    env = CyberDefenseEnvView(batch, 1)
+    for t in range(40):
+        env.mode = fx.mode_name(1, t)
+        env.step(fx.python_action(1, t))
+    f = fx.exp["flags"][1, 39]
+    devs = env._get_ordered_devices()
+    assert len(devs) == fx.M
+    for d in devs:   # IPPO.build_visibility_mask's predicate, both roles
+        att = d.Known_to_attacker and d.attacker_owned and not d.Not_yet_added
+        dfn = (not d.Not_yet_added) and d.attacker_owned
+        assert att == bool((f[d.id] & S.F_KNOWN) and (f[d.id] & S.F_OWNED) and not (f[d.id] & S.F_NYA))
+        assert dfn == bool((f[d.id] & S.F_OWNED) and not (f[d.id] & S.F_NYA))
+        assert d.isCompromised == bool(f[d.id] & S.F_COMP)
+        assert d.busy_time == int(fx.exp["busy"][1, 39, d.id])
+        assert (d.workload is not None) == (fx.exp["wl"][1, 39, d.id] > 0)
+    sim = env.simulator
+    assert sim.getExploitsSize() == fx.topo.X and set(sim.subnet.net.keys()) == set(range(fx.M))
+    assert len(sim.subnet.graph.get_edgelist()) == fx.topo.E
+    n_blocked = int(fx.exp["blocked"][1, 39].sum())
+    assert len(sim.subnet.graph.blocked_edges()) <= n_blocked and (n_blocked == 0) == (len(sim.subnet.graph.blocked_edges()) == 0)
+    assert len(sim.logger.get_logs()) == min(int(fx.exp["ienv"][1, 39, S.I_LOG_TOTAL]), S.LOG_RING)
+    live_ids = [i for i, d in sim.subnet.net.items() if not d.Not_yet_added]   # HMARL.py:470
+    assert live_ids == [i for i in range(fx.M) if not (f[i] & S.F_NYA)]
+    batch.close()
