@@ -1238,6 +1238,8 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? 4 : 1) void step_kernel(const K
   uint32_t* const Bz = (uint32_t*)e.busy;
   uint32_t* const Wl = (uint32_t*)e.wl;
   const uint32_t* const Ds = (const uint32_t*)e.dst;
+  const bool partial = (mode & CG_MODE_PARTIAL) && ng == 0;   // step(action, agent_cnt != len(net)) :1207
+  mode &= 0xFF;
   e.tick = (uint32_t)ie[CG_I_RNG_TICK];
   e.eflags = ie[CG_I_FLAGS];
   e.log_total = ie[CG_I_LOG_TOTAL];
@@ -1311,7 +1313,7 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? 4 : 1) void step_kernel(const K
   for (int w = lane; w < NW; w += WAVE) {
     uint32_t f = F[w], b = Bz[w], l = Wl[w], st = Ds[w];
     const uint32_t nya = (f >> 4) & ONES;
-    const uint32_t step = ~nz01(b) & ~nya & nz01(l) & ONES;   // idle-of-stall, active, has a job
+    const uint32_t step = partial ? 0u : (~nz01(b) & ~nya & nz01(l) & ONES);   // idle-of-stall, active, has a job
     l -= step;
     const uint32_t fin = step & ~nz01(l);
     const uint32_t adv = (f >> 7) & ONES;
@@ -1335,7 +1337,7 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? 4 : 1) void step_kernel(const K
   const int n_comp_dc = wave_sum_bits(c_cdc, e.cbits);
   ie[CG_I_WORK_DONE] += current_work;
   wsync();
-  arrivals(e, P, ie[CG_I_STEP_NUM], n_active, n_idle, n_fsrv);   // changes wl only: the counts above stand
+  if (!partial) arrivals(e, P, ie[CG_I_STEP_NUM], n_active, n_idle, n_fsrv);   // changes wl only: the counts above stand
 
   STAMP(3);
   // ---- rewards (:1267-1304 / :732-748) ----
@@ -1387,8 +1389,10 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? 4 : 1) void step_kernel(const K
   }
 
   STAMP(5);
-  ie[CG_I_STEP_NUM] += 1;
-  if (mode == CG_MODE_ATTACKER) ie[CG_I_ATT_STEP] += 1; else ie[CG_I_DEF_STEP] += 1;
+  if (!partial) {   // :1307-1312
+    ie[CG_I_STEP_NUM] += 1;
+    if (mode == CG_MODE_ATTACKER) ie[CG_I_ATT_STEP] += 1; else ie[CG_I_DEF_STEP] += 1;
+  }
   const bool done = ie[CG_I_STEP_NUM] > P.c.episode_limit;
   if (dirty || (ie[CG_I_STEP_NUM] % P.c.evolve_period) == 0) evolve(e, P);
   if (ng == 0) {   // :1330 rebuild of the cached busy set

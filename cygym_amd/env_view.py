@@ -209,23 +209,25 @@ class CyberDefenseEnvView:
         self._b.randomize([self._i])
 
     # ---- the tick -------------------------------------------------------------
-    def _launch(self, groups, grouped):
+    def _launch(self, groups, grouped, partial=False):
         b, i = self._b, self._i
         act = {k: v.cpu().numpy() for k, v in b.act.items()}
         act["n_groups"][:] = -1                          # every other env of the batch stays put
         HL.encode_into(act, i, self.mode, groups, grouped, b.M)
+        if partial:
+            act["mode"][i] |= S.MODE_PARTIAL
         b.set_actions_numpy(act)
         obs, raw, shaped, done = b.step()
         torch.cuda.synchronize(b.device)
         self.state = obs[i].reshape(-1).cpu().numpy().astype(np.float64)
         return float(raw[i].item()), float(shaped[i].item()), bool(done[i].item())
 
-    def _info(self, action_taken, executed=None, grouped=False):
+    def _info(self, action_taken, executed=None, grouped=False, partial=False):
         ie = self._b.state["ienv"][self._i].cpu().numpy()
         fe = self._b.state["fenv"][self._i].cpu().numpy()
         # step() builds info before step_num += 1 (:1272 vs :1308), step_grouped after (:751 vs :759)
         info = {
-            "mode": self.mode, "step_count": int(ie[S.I_STEP_NUM]) - (0 if grouped else 1),
+            "mode": self.mode, "step_count": int(ie[S.I_STEP_NUM]) - (0 if (grouped or partial) else 1),
             "revert_count": int(ie[S.I_REVERT_CNT]),
             "checkpoint_count": int(ie[S.I_CKPT_CNT]), "defensive_cost": float(fe[S.D_DEF_COST]),
             "clearning_cost": float(fe[S.D_CLEAN_COST]), "Scan_count": int(ie[S.I_SCAN_CNT]),
@@ -249,17 +251,16 @@ class CyberDefenseEnvView:
         return out
 
     def step(self, action, agent_cnt=None):              # volt_typhoon_env.py:818
-        if agent_cnt is not None and agent_cnt != self._b.M:
-            raise NotImplementedError("agent_cnt != number of devices (partial tick, :1207) is not built")
         if HL.is_grouped(action):
-            return self.step_grouped(action)
+            return self.step_grouped(action)          # the reference ignores agent_cnt here (:842-844)
+        partial = agent_cnt is not None and agent_cnt != self._b.M   # :1207 / :1307
         if action is None:
             action = HL.default_action(self.mode, self.base_line, self._flags())
         cfg = self._b.cfg
         norm = HL.validate_single(self.mode, cfg.baseline, action, self._b.M, cfg.n_def_actions, cfg.n_att_actions)
-        raw, shaped, done = self._launch([norm], grouped=False)
+        raw, shaped, done = self._launch([norm], grouped=False, partial=partial)
         executed = int(self._b.state["ienv"][self._i, S.I_LAST_ATYPE].item())
-        return self.state, raw, shaped, done, self._info(action, executed), self._logs()
+        return self.state, raw, shaped, done, self._info(action, executed, partial=partial), self._logs()
 
     def step_grouped(self, groups):                      # :694-779
         assert isinstance(groups, (list, tuple)) and len(groups) > 0

@@ -83,6 +83,8 @@ enum {
 /* ---- actions ---- */
 #define CG_MODE_DEFENDER 0
 #define CG_MODE_ATTACKER 1
+#define CG_MODE_PARTIAL  0x100 /* OR-ed into mode: step(action, agent_cnt != len(net)) -- no workload advance,
+                                  no arrivals, no step counters (volt_typhoon_env.py:1207, :1307) */
 
 /* ---- comm-log ring ---- */
 #define CG_LOG_RING 32       /* entries kept per env (fast scan reads 30)  */

@@ -543,7 +543,8 @@ static void step_one(env_t* e, const cygym_actions* a, const cygym_outputs* o, i
   e->occ = occ;
   e->isolate_iter = 0; e->scan_ord = 0; e->zeroday_occ = 0;
   e->tick = (uint32_t)e->ienv[CG_I_RNG_TICK];
-  const int mode = a->mode[idx];
+  const int partial = (a->mode[idx] & CG_MODE_PARTIAL) != 0 && a->n_groups[idx] == 0; /* agent_cnt mismatch :1207 */
+  const int mode = a->mode[idx] & 0xFF;
   const int ng = a->n_groups[idx];
   if (ng < 0) return; /* this env does not tick */
   const int16_t* devs = a->dev_idx + (size_t)idx * L;
@@ -570,8 +571,11 @@ static void step_one(env_t* e, const cygym_actions* a, const cygym_outputs* o, i
     } else {
       attacker(e, at, a->exploit + (size_t)idx * G * CG_MAX_EXPLOITS, a->n_exploit[(size_t)idx * G], &cost, srcs);
     }
-    current_work = advance_work(e);
-    arrivals(e, tmp);
+    current_work = 0;
+    if (!partial) {
+      current_work = advance_work(e);
+      arrivals(e, tmp);
+    }
     {
       int n_comp, n_dc;
       count_comp(e, &n_comp, &n_dc);
@@ -602,8 +606,10 @@ static void step_one(env_t* e, const cygym_actions* a, const cygym_outputs* o, i
     e->ienv[CG_I_LAST_ATYPE] = -1;
   }
   write_obs(e, o->obs + (size_t)idx * M * 6);
-  e->ienv[CG_I_STEP_NUM] += 1;
-  if (mode == CG_MODE_ATTACKER) e->ienv[CG_I_ATT_STEP] += 1; else e->ienv[CG_I_DEF_STEP] += 1;
+  if (!partial) { /* :1307-1312 */
+    e->ienv[CG_I_STEP_NUM] += 1;
+    if (mode == CG_MODE_ATTACKER) e->ienv[CG_I_ATT_STEP] += 1; else e->ienv[CG_I_DEF_STEP] += 1;
+  }
   int done = e->ienv[CG_I_STEP_NUM] > e->c->episode_limit;
   if (dirty || (e->ienv[CG_I_STEP_NUM] % e->c->evolve_period) == 0) evolve(e, newly);
   if (ng == 0) { /* :1330 */

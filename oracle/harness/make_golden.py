@@ -165,6 +165,21 @@ def s16_none():
     return res, 1
 
 
+@scenario("s16_partial")
+def s16_partial():
+    """step(action, agent_cnt != len(net)): no workload advance / arrivals / step counters (:1207, :1307)."""
+    M = 16
+    env0 = H.build_env(M, 13, init_seed=111, strip_vuln_frac=0.3, extra_reachable=1)
+    base = mixed_actions(M, ALL_DEF, ALL_ATT, 4)
+
+    def fn(e, t, env, rs):
+        mode, a = base(e, t, env, rs)
+        if rs.rand() < 0.35:
+            mode |= S.MODE_PARTIAL
+        return mode, a
+    return H.run_scenario(env0, 2, 160, fn, seed=25, env_id_base=20), 1
+
+
 @scenario("s600_sparse")
 def s600_sparse():
     """len(net) > 500: sparse attacker connect (:1344) and the lazy workload path (CDSimulator.py:325)."""

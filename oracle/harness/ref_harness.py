@@ -588,11 +588,14 @@ def run_scenario(env0, n_envs, n_ticks, action_fn, *, seed=0, env_id_base=0, pre
         acts = []
         for t in range(n_ticks):
             mode, action = action_fn(e, t, env, rs)
-            env.mode = "defender" if mode == S.MODE_DEFENDER else "attacker"
+            agent_cnt = None
+            if mode & S.MODE_PARTIAL:        # drive step(action, agent_cnt=<something else than len(net)>)
+                agent_cnt = len(env.simulator.subnet.net) + 1
+            env.mode = "defender" if (mode & 0xFF) == S.MODE_DEFENDER else "attacker"
             CTX.begin(seed, env_id, rng_tick, env)
             err = None
             try:
-                state, raw, shaped, done, info, logs = env.step(action)
+                state, raw, shaped, done, info, logs = env.step(action) if agent_cnt is None else env.step(action, agent_cnt)
             except ValueError as ex:   # malformed 11/12/13 actions raise in the reference
                 err = str(ex)
             finally:

@@ -90,7 +90,10 @@ class Fixture:
         return groups if ng > 0 else groups[0]
 
     def mode_name(self, e, t) -> str:
-        return "defender" if int(self.z["act_mode"][e, t]) == S.MODE_DEFENDER else "attacker"
+        return "defender" if (int(self.z["act_mode"][e, t]) & 0xFF) == S.MODE_DEFENDER else "attacker"
+
+    def is_partial(self, e, t) -> bool:
+        return bool(int(self.z["act_mode"][e, t]) & S.MODE_PARTIAL)
 
     def actions(self, t, alloc, flags=None):
         """Fill an action dict (oracle.driver.alloc_actions / torch mirror) for tick t.

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 NAMES = [n for n in gio.fixture_names()
-         if n.startswith(("s16_none", "s16_baselines", "s32_grouped", "s16_dups", "s16_mixed", "s16_zeroday"))]
+         if n.startswith(("s16_none", "s16_baselines", "s32_grouped", "s16_dups", "s16_mixed", "s16_zeroday", "s16_partial"))]
 
 
 @pytest.mark.parametrize("name", NAMES)
@@ -29,7 +29,8 @@ def test_view_matches_reference(name):
                 continue
             env.mode = fx.mode_name(e, t)
             action = fx.python_action(e, t)
-            state, raw, shaped, done, info, logs = env.step(action)
+            partial = fx.is_partial(e, t)
+            state, raw, shaped, done, info, logs = env.step(action, agent_cnt=fx.M + 1) if partial else env.step(action)
             if not fx.exp["topo_same"][e, t]:
                 alive[e] = False
                 continue
@@ -38,7 +39,7 @@ def test_view_matches_reference(name):
             assert abs(raw - fx.exp["raw"][e, t]) < 1e-9 and abs(shaped - fx.exp["shaped"][e, t]) < 1e-9
             assert done == bool(fx.exp["done"][e, t])
             grouped = int(fx.z["act_n_groups"][e, t]) > 0
-            assert info["step_count"] == int(exp_i[S.I_STEP_NUM]) - (0 if grouped else 1)
+            assert info["step_count"] == int(exp_i[S.I_STEP_NUM]) - (0 if (grouped or partial) else 1)
             assert info["work_done"] == int(exp_i[S.I_WORK_DONE])
             assert info["Compromised_devices"] == int(exp_i[S.I_COMP_CNT])
             assert info["Scan_count"] == int(exp_i[S.I_SCAN_CNT])
@@ -75,8 +76,6 @@ def test_view_errors_and_reset():
         env.step((11, [0], [], 0))                       # volt_typhoon_env.py:966
     with pytest.raises(KeyError):
         env.step((1, [0], [99], 0))                      # unknown device id
-    with pytest.raises(NotImplementedError):
-        env.step((8, [0], [], 0), agent_cnt=3)
     before = batch.state_numpy()["flags"].copy()
     s0 = env.reset()
     env.step((7, [0], [2, 3], 0))
