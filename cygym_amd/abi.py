@@ -13,7 +13,7 @@ import numpy as np
 from . import rng as R
 from . import spec as S
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 u8p = C.POINTER(C.c_uint8)
 u16p = C.POINTER(C.c_uint16)
@@ -26,7 +26,7 @@ f64p = C.POINTER(C.c_double)
 
 class Topology(C.Structure):
     _fields_ = [
-        ("n_devices", C.c_int32), ("n_exploits", C.c_int32), ("n_edges", C.c_int32), ("reserved0", C.c_int32),
+        ("n_devices", C.c_int32), ("n_exploits", C.c_int32), ("n_edges", C.c_int32), ("max_extra_edges", C.c_int32),
         ("dstatic", C.c_void_p), ("vuln", C.c_void_p), ("napps", C.c_void_p),
         ("os_val", C.c_void_p), ("version", C.c_void_p), ("anomaly", C.c_void_p),
         ("out_ptr", C.c_void_p), ("out_col", C.c_void_p), ("in_ptr", C.c_void_p),
@@ -53,7 +53,7 @@ class Buffers(C.Structure):
     _fields_ = [
         ("live", C.c_void_p), ("stash", C.c_void_p),
         ("blocked", C.c_void_p), ("blocked_in", C.c_void_p), ("ring", C.c_void_p), ("ienv", C.c_void_p),
-        ("fenv", C.c_void_p), ("n_envs", C.c_int32), ("reserved", C.c_int32),
+        ("fenv", C.c_void_p), ("extra", C.c_void_p), ("n_envs", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -74,7 +74,7 @@ BASELINES = {"Nash": 0, "No Defense": 1, "Preset": 2, "No Attack": 3}
 LIVE_PLANES = ("flags", "busy", "wl", "comp_by")          # order inside Buffers.live  [N][4][M]
 STASH_PLANES = ("st_flags", "st_busy", "st_wl", "st_comp_by")  # order inside Buffers.stash [N][4][M]
 STATE_PLANES = LIVE_PLANES + STASH_PLANES
-BUFFER_FIELDS = ("live", "stash", "blocked", "blocked_in", "ring", "ienv", "fenv")
+BUFFER_FIELDS = ("live", "stash", "blocked", "blocked_in", "ring", "ienv", "fenv", "extra")
 
 
 @dataclass
@@ -142,6 +142,7 @@ class TopologyArrays:
     in_ptr: np.ndarray
     in_col: np.ndarray
     in_eid: np.ndarray
+    max_extra: int = 0          # K: capacity of the per-env list of edges evolve_network may add
     _keep: list = field(default_factory=list, repr=False)
 
     @property
@@ -152,6 +153,11 @@ class TopologyArrays:
     def EW(self) -> int:
         return max(1, (self.E + 31) // 32)
 
+    @property
+    def XW(self) -> int:
+        """words of one env's extra-edge list (cygym_spec.h CG_X_WORDS)"""
+        return x_words(self.max_extra)
+
     def normalised(self) -> "TopologyArrays":
         def a(x, dt):
             return np.ascontiguousarray(np.asarray(x, dtype=dt))
@@ -159,7 +165,7 @@ class TopologyArrays:
             int(self.M), int(self.X), a(self.dstatic, np.uint8), a(self.vuln, np.uint8), a(self.napps, np.uint8),
             a(self.os_val, np.float32), a(self.version, np.float32), a(self.anomaly, np.float32),
             a(self.out_ptr, np.int32), a(self.out_col, np.int32), a(self.in_ptr, np.int32),
-            a(self.in_col, np.int32), a(self.in_eid, np.int32))
+            a(self.in_col, np.int32), a(self.in_eid, np.int32), int(self.max_extra))
 
     def validate(self):
         M, E = self.M, self.E
@@ -175,6 +181,8 @@ class TopologyArrays:
                 raise ValueError("malformed CSR row pointer")
             if c.shape != (E,) or (E and (c.min() < 0 or c.max() >= M)):
                 raise ValueError("malformed CSR column array")
+        if not (0 <= self.max_extra <= 4096):
+            raise ValueError("max_extra must be in [0, 4096]")
         if self.in_eid.shape != (E,):
             raise ValueError("in_eid must have shape (E,)")
         if E:
@@ -189,6 +197,7 @@ class TopologyArrays:
     def to_c(self) -> Topology:
         t = Topology()
         t.n_devices, t.n_exploits, t.n_edges = self.M, self.X, self.E
+        t.max_extra_edges = int(self.max_extra)
         for name in ("dstatic", "vuln", "napps", "os_val", "version", "anomaly",
                      "out_ptr", "out_col", "in_ptr", "in_col", "in_eid"):
             arr = getattr(self, name)
@@ -197,6 +206,29 @@ class TopologyArrays:
                 self._keep.append(arr)
             setattr(t, name, arr.ctypes.data)
         return t
+
+
+def x_words(K: int) -> int:
+    return int(K) + (int(K) + 31) // 32
+
+
+def pack_extra(edges, blocked, K: int) -> np.ndarray:
+    """(u, v) pairs + 0/1 blocked flags -> one env's extra-edge list u32 [x_words(K)] (keys ascending)."""
+    row = np.zeros(x_words(K), np.uint32)
+    keys = sorted(((int(u) << 16) | int(v), int(b)) for (u, v), b in zip(edges, blocked))
+    if len(keys) > K:
+        raise ValueError(f"{len(keys)} extra edges do not fit max_extra={K}")
+    for j, (k, b) in enumerate(keys):
+        row[j] = k
+        if b:
+            row[K + (j >> 5)] |= np.uint32(1 << (j & 31))
+    return row
+
+
+def unpack_extra(row: np.ndarray, n: int, K: int):
+    """-> [(u, v, blocked)] of the first n live entries"""
+    row = np.asarray(row, np.uint32)
+    return [(int(row[j]) >> 16, int(row[j]) & 0xFFFF, int((int(row[K + (j >> 5)]) >> (j & 31)) & 1)) for j in range(n)]
 
 
 def build_in_csr(M: int, out_ptr: np.ndarray, out_col: np.ndarray):

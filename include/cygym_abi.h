@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CYGYM_ABI_VERSION 1
+#define CYGYM_ABI_VERSION 2
 
 #define CYGYM_OK            0
 #define CYGYM_EINVAL       -1  /* bad argument / shape                       */
@@ -47,7 +47,8 @@ typedef struct cygym_topology {
   int32_t n_devices;        /* M  (= Max_network_size = len(subnet.net))       */
   int32_t n_exploits;       /* X  (= len(simulator.exploits)) <= 6             */
   int32_t n_edges;          /* E                                                */
-  int32_t reserved0;
+  int32_t max_extra_edges;  /* K: capacity of the per-env list of edges evolve_network may add (0: additions only
+                               raise CG_E_TOPO_OVF); rows must then be sorted by neighbour id      */
   const uint8_t* dstatic;   /* [M] CG_D_DC | CG_D_SERVER                        */
   const uint8_t* vuln;      /* [M] bit e: an app vuln id is in exploits[e].target */
   const uint8_t* napps;     /* [M] len(device.apps)                             */
@@ -115,6 +116,7 @@ typedef struct cygym_buffers {
   uint16_t* ring;       /* [N][CG_LOG_RING][2] last comm-log (from,to) pairs    */
   int32_t*  ienv;       /* [N][CG_I_COUNT]                                      */
   double*   fenv;       /* [N][CG_D_COUNT]                                      */
+  uint32_t* extra;      /* [N][CG_X_WORDS(K)] edges added by evolve_network (cygym_spec.h); NULL iff K == 0 */
   int32_t   n_envs;     /* leading dimension (N, or 1 for a broadcast snapshot) */
   int32_t   reserved;
 } cygym_buffers;

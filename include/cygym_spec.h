@@ -48,8 +48,20 @@
 #define CG_E_DET_TRAIN  0x04 /* simulator.detector.trained                 */
 #define CG_E_DET_RANDOM 0x08 /* simulator.detector.random_detection        */
 #define CG_E_PREV_SET   0x10 /* env._prev_att_potential is not None        */
-#define CG_E_TOPO_OVF   0x20 /* evolve wanted to add an edge (unsupported) */
+#define CG_E_TOPO_OVF   0x20 /* evolve wanted to add an edge that did not fit
+                                the per-env extra-edge list (max_extra_edges) */
 #define CG_E_BUSY_SAT   0x40 /* a busy counter saturated at 255            */
+#define CG_E_NX_SHIFT   16   /* bits 16..31: number of live entries of the env's
+                                extra-edge list (edges evolve_network added,
+                                CyberDefenseEnv.py:738-843)                   */
+#define CG_E_NX(f)      (((uint32_t)(f)) >> CG_E_NX_SHIFT)
+/* extra-edge list of one env, u32 [CG_X_WORDS(K)], K = max_extra_edges:
+ *   words [0, K)      keys (u << 16 | v) of the added directed edges, ascending; the first NX are live
+ *   words [K, K+KW)   blocked bit per list entry, KW = ceil(K/32)
+ * A row of the cached adjacency is then the base CSR row merged with the env's extra edges in
+ * ascending neighbour id (igraph returns neighbour lists sorted by vertex id; an added edge never
+ * duplicates an existing one, CyberDefenseEnv.py:756-759, :824).                                  */
+#define CG_X_WORDS(K)   ((K) + ((K) + 31) / 32)
 
 /* ---- per-env integer counters: column indices of `ienv` i32 [N][CG_I_COUNT] */
 enum {

@@ -39,6 +39,8 @@ typedef struct {
   int M, X, E, EW;
   uint8_t *flags, *busy, *wl, *comp_by, *st_flags, *st_busy, *st_wl, *st_comp_by;
   uint32_t* blocked;
+  uint32_t* extra; /* [CG_X_WORDS(K)] edges added by evolve_network, or NULL */
+  int K;
   uint16_t* ring;
   int32_t* ienv;
   double* fenv;
@@ -60,6 +62,51 @@ static void set_blocked_pair(env_t* e, int u, int v, int val) {
       if (val) e->blocked[k >> 5] |= (1u << (k & 31));
       else     e->blocked[k >> 5] &= ~(1u << (k & 31));
     }
+}
+/* ---- edges added by evolve_network (cygym_spec.h: extra-edge list) ---- */
+static int x_n(const env_t* e) { return e->extra ? (int)CG_E_NX(e->ienv[CG_I_FLAGS]) : 0; }
+static void x_set_n(env_t* e, int n) {
+  e->ienv[CG_I_FLAGS] = (int32_t)(((uint32_t)e->ienv[CG_I_FLAGS] & 0xFFFFu) | ((uint32_t)n << CG_E_NX_SHIFT));
+}
+static int x_blocked(const env_t* e, int j) { return (e->extra[e->K + (j >> 5)] >> (j & 31)) & 1u; }
+/* an entry of a merged adjacency row: the neighbour and where its blocked bit lives */
+typedef struct { int other; int ref; } ment_t; /* ref >= 0: base out-slot; ref < 0: extra entry -(ref+1) */
+static int ref_blocked(const env_t* e, int ref) { return ref >= 0 ? is_blocked(e, ref) : x_blocked(e, -(ref + 1)); }
+/* _outnbrs[u] after _rebuild_graph_cache: base row and u's added edges, by ascending neighbour id */
+static int merged_out(const env_t* e, int u, ment_t* m) {
+  const int xn = x_n(e);
+  int n = 0, j = 0;
+  while (j < xn && (int)(e->extra[j] >> 16) < u) ++j;
+  for (int k = e->t->out_ptr[u]; k < e->t->out_ptr[u + 1]; ++k) {
+    int v = e->t->out_col[k];
+    while (j < xn && (int)(e->extra[j] >> 16) == u && (int)(e->extra[j] & 0xFFFFu) < v) {
+      m[n].other = (int)(e->extra[j] & 0xFFFFu); m[n].ref = -(j + 1); ++n; ++j;
+    }
+    m[n].other = v; m[n].ref = k; ++n;
+  }
+  while (j < xn && (int)(e->extra[j] >> 16) == u) { m[n].other = (int)(e->extra[j] & 0xFFFFu); m[n].ref = -(j + 1); ++n; ++j; }
+  return n;
+}
+/* _innbrs[d]: base in-row and the added edges ending at d, by ascending source id */
+static int merged_in(const env_t* e, int d, ment_t* m) {
+  const int xn = x_n(e);
+  int n = 0, j = 0;
+  for (int k = e->t->in_ptr[d]; k <= e->t->in_ptr[d + 1]; ++k) {
+    int u = k < e->t->in_ptr[d + 1] ? e->t->in_col[k] : 0x10000;
+    for (; j < xn; ++j) {
+      if ((int)(e->extra[j] & 0xFFFFu) != d) continue;
+      if ((int)(e->extra[j] >> 16) >= u) break;
+      m[n].other = (int)(e->extra[j] >> 16); m[n].ref = -(j + 1); ++n;
+    }
+    if (k < e->t->in_ptr[d + 1]) { m[n].other = u; m[n].ref = e->t->in_eid[k]; ++n; }
+  }
+  return n;
+}
+static void set_blocked_ref(env_t* e, int u, int v, int ref, int val) {
+  if (ref >= 0) { set_blocked_pair(e, u, v, val); return; }
+  int j = -(ref + 1);
+  if (val) e->extra[e->K + (j >> 5)] |= (1u << (j & 31));
+  else     e->extra[e->K + (j >> 5)] &= ~(1u << (j & 31));
 }
 static void log_comm(env_t* e, int from, int to) { /* CDSimulator.py:120, :667 */
   uint32_t n = (uint32_t)e->ienv[CG_I_LOG_TOTAL];
@@ -142,18 +189,20 @@ static void do_clean(env_t* e, int d, double* cost) { /* :996-1011 / :676-690 */
   clear_wl(e, d);
 }
 
-/* pool of incident edges with the given blocked state; returns count, writes (u,v) */
-static int incident_pool(const env_t* e, int d, int want_blocked, int* pu, int* pv) {
+/* pool of incident edges with the given blocked state (:502-511); returns count, writes (u,v,ref) */
+static int incident_pool(const env_t* e, int d, int want_blocked, int* pu, int* pv, int* pr, ment_t* row) {
   int n = 0;
-  for (int k = e->t->out_ptr[d]; k < e->t->out_ptr[d + 1]; ++k)
-    if (is_blocked(e, k) == want_blocked) { pu[n] = d; pv[n] = e->t->out_col[k]; ++n; }
-  for (int k = e->t->in_ptr[d]; k < e->t->in_ptr[d + 1]; ++k)
-    if (is_blocked(e, e->t->in_eid[k]) == want_blocked) { pu[n] = e->t->in_col[k]; pv[n] = d; ++n; }
+  int len = merged_out(e, d, row);
+  for (int i = 0; i < len; ++i)
+    if (ref_blocked(e, row[i].ref) == want_blocked) { pu[n] = d; pv[n] = row[i].other; pr[n] = row[i].ref; ++n; }
+  len = merged_in(e, d, row);
+  for (int i = 0; i < len; ++i)
+    if (ref_blocked(e, row[i].ref) == want_blocked) { pu[n] = row[i].other; pv[n] = d; pr[n] = row[i].ref; ++n; }
   return n;
 }
 
 static void def_per_device(env_t* e, int at, const int16_t* dev, int L, int app, double* cost, int* dirty,
-                           int* pu, int* pv) {
+                           int* pu, int* pv, int* pr, ment_t* row) {
   const double ds = e->c->def_scale;
   const int M = e->M;
   for (int p = 0; p < L; ++p) {
@@ -201,11 +250,11 @@ static void def_per_device(env_t* e, int at, const int16_t* dev, int L, int app,
       case 6: { /* :1071-1080 */
         *cost += -0.5 * ds;
         e->fenv[CG_D_DEF_COST] += 0.5 * ds;
-        int n = incident_pool(e, d, 0, pu, pv);
+        int n = incident_pool(e, d, 0, pu, pv, pr, row);
         if (n > 0) {
           int b = e->occ[2 * M + d]++;
           int r = (int)cg_index(drw(e, CG_SITE_PICK_BLOCK, (uint32_t)d, (uint32_t)b), (uint32_t)n);
-          set_blocked_pair(e, pu[r], pv[r], 1);
+          set_blocked_ref(e, pu[r], pv[r], pr[r], 1);
           e->ienv[CG_I_EDGES_BLOCKED] += 1;
           *dirty = 1;
         }
@@ -222,11 +271,11 @@ static void def_per_device(env_t* e, int at, const int16_t* dev, int L, int app,
       case 9: { /* :1091-1100 */
         *cost += -0.5 * ds;
         e->fenv[CG_D_DEF_COST] += 0.5 * ds;
-        int n = incident_pool(e, d, 1, pu, pv);
+        int n = incident_pool(e, d, 1, pu, pv, pr, row);
         if (n > 0) {
           int b = e->occ[2 * M + d]++;
           int r = (int)cg_index(drw(e, CG_SITE_PICK_UNBLOCK, (uint32_t)d, (uint32_t)b), (uint32_t)n);
-          set_blocked_pair(e, pu[r], pv[r], 0);
+          set_blocked_ref(e, pu[r], pv[r], pr[r], 0);
           e->ienv[CG_I_EDGES_ADDED] += 1;
           *dirty = 1;
         }
@@ -265,7 +314,7 @@ static void def_per_device(env_t* e, int at, const int16_t* dev, int L, int app,
 }
 
 /* ---- attacker (:1126-1202) ---- */
-static void attacker(env_t* e, int at, const int32_t* expl, int n_expl, double* cost, int* srcs) {
+static void attacker(env_t* e, int at, const int32_t* expl, int n_expl, double* cost, int* srcs, ment_t* row) {
   const int M = e->M;
   int n_src = 0;
   for (int d = 0; d < M; ++d)
@@ -289,9 +338,10 @@ static void attacker(env_t* e, int at, const int32_t* expl, int n_expl, double* 
       for (int si = 0; si < n_src; ++si) {
         int s = srcs[si];
         int s_dc = e->t->dstatic[s] & CG_D_DC;
-        for (int k = e->t->out_ptr[s]; k < e->t->out_ptr[s + 1]; ++k) {
-          if (is_blocked(e, k)) continue;
-          int v = e->t->out_col[k];
+        const int len = merged_out(e, s, row);
+        for (int k = 0; k < len; ++k) {
+          if (ref_blocked(e, row[k].ref)) continue;
+          int v = row[k].other;
           log_comm(e, s, v);
           if (s_dc) { e->flags[v] |= CG_F_COMP; e->comp_by[v] |= ebit; break; }
           if (e->flags[v] & CG_F_REACH) { e->flags[v] |= CG_F_COMP; break; }
@@ -304,9 +354,10 @@ static void attacker(env_t* e, int at, const int32_t* expl, int n_expl, double* 
   } else if (at == 2) {
     if (n_src > 0) {
       int s = srcs[cg_index(drw(e, CG_SITE_PROBE_SRC, 0, 0), (uint32_t)n_src)];
-      for (int k = e->t->out_ptr[s]; k < e->t->out_ptr[s + 1]; ++k) {
-        if (is_blocked(e, k)) continue;
-        int v = e->t->out_col[k];
+      const int len = merged_out(e, s, row);
+      for (int k = 0; k < len; ++k) {
+        if (ref_blocked(e, row[k].ref)) continue;
+        int v = row[k].other;
         if (!(e->flags[v] & CG_F_KNOWN)) { e->flags[v] |= CG_F_KNOWN; *cost += 0.1; break; }
       }
     }
@@ -420,12 +471,31 @@ static int rank_select(const env_t* e, uint8_t mask, uint8_t want, int r) {
     if ((e->flags[d] & mask) == want) { if (r-- == 0) return d; }
   return -1;
 }
-static int has_edge(const env_t* e, int u, int v) {
+static int has_edge(const env_t* e, int u, int v) { /* g.get_eid(u, v, directed=True, error=False) != -1 */
   for (int k = e->t->out_ptr[u]; k < e->t->out_ptr[u + 1]; ++k) if (e->t->out_col[k] == v) return 1;
+  const uint32_t key = ((uint32_t)u << 16) | (uint32_t)v;
+  for (int j = 0; j < x_n(e); ++j) if (e->extra[j] == key) return 1;
   return 0;
 }
+static int degree_all(const env_t* e, int d) { /* g.degree(d): in + out, a loop counts twice */
+  int deg = (e->t->out_ptr[d + 1] - e->t->out_ptr[d]) + (e->t->in_ptr[d + 1] - e->t->in_ptr[d]);
+  for (int j = 0; j < x_n(e); ++j)
+    deg += ((int)(e->extra[j] >> 16) == d) + ((int)(e->extra[j] & 0xFFFFu) == d);
+  return deg;
+}
+/* g.add_edges([(u, v)]): sorted insert into the env's list; 1 when the edge went in */
+static int add_edge(env_t* e, int u, int v) {
+  const int n = x_n(e);
+  if (!e->extra || n >= e->K) { e->ienv[CG_I_FLAGS] |= CG_E_TOPO_OVF; return 0; }
+  const uint32_t key = ((uint32_t)u << 16) | (uint32_t)v;
+  int j = n;
+  while (j > 0 && e->extra[j - 1] > key) { e->extra[j] = e->extra[j - 1]; --j; }
+  e->extra[j] = key;
+  x_set_n(e, n + 1);
+  return 1;
+}
 
-static void evolve(env_t* e, uint8_t* newly) { /* CyberDefenseEnv.py:583-875 */
+static void evolve(env_t* e, uint8_t* newly, int* cdf) { /* CyberDefenseEnv.py:583-875 */
   const int M = e->M;
   if (!(e->ienv[CG_I_FLAGS] & CG_E_EVO_INIT)) { /* :654-659 */
     for (int d = 0; d < M; ++d) {
@@ -462,18 +532,39 @@ static void evolve(env_t* e, uint8_t* newly) { /* CyberDefenseEnv.py:583-875 */
       }
     }
   }
-  /* star reconnection :738-774 and PA attachment :776-843 would ADD edges: detect, flag */
+  int changed = 0;
+  /* star reconnection :738-774: hub = first active attacker-owned device in dict order */
   int hub = -1;
   for (int d = 0; d < M; ++d) {
     if ((e->flags[d] & (CG_F_OWNED | CG_F_EVOACT)) != (CG_F_OWNED | CG_F_EVOACT)) continue;
     if (hub < 0) { hub = d; continue; }
-    if (!has_edge(e, hub, d) || !has_edge(e, d, hub)) e->ienv[CG_I_FLAGS] |= CG_E_TOPO_OVF;
+    if (!has_edge(e, hub, d)) changed |= add_edge(e, hub, d);
+    if (!has_edge(e, d, hub)) changed |= add_edge(e, d, hub);
   }
-  for (int d = 0; d < M; ++d) {
-    if (!newly[d]) continue;
-    if (e->flags[d] & (CG_F_NYA | CG_F_OWNED)) continue;
-    int deg = (e->t->out_ptr[d + 1] - e->t->out_ptr[d]) + (e->t->in_ptr[d + 1] - e->t->in_ptr[d]);
-    if (deg < 1) e->ienv[CG_I_FLAGS] |= CG_E_TOPO_OVF;
+  /* PA attachment of isolated newcomers :776-843 (one degree snapshot, taken after the star edges) */
+  int need_pa = 0;
+  for (int d = 0; d < M && !need_pa; ++d)
+    if (newly[d] && !(e->flags[d] & (CG_F_NYA | CG_F_OWNED)) && degree_all(e, d) < 1) need_pa = 1;
+  if (need_pa) {
+    int total = 0;
+    for (int d = 0; d < M; ++d) { /* candidates: self._active_ids (ascending ids), weight degree + 1 */
+      if (e->flags[d] & CG_F_EVOACT) total += degree_all(e, d) + 1;
+      cdf[d] = total;
+    }
+    for (int d = 0; d < M && total > 0; ++d) {
+      if (!newly[d] || (e->flags[d] & (CG_F_NYA | CG_F_OWNED))) continue;
+      if (degree_all(e, d) >= 1) continue;
+      /* r = random.uniform(0, total); j = bisect_left(cdf, r): first candidate with cdf >= total * u / 2^32 */
+      const uint64_t r = (uint64_t)total * (uint64_t)drw(e, CG_SITE_EVO_PA, (uint32_t)d, 0);
+      int tgt = -1;
+      for (int a = 0; a < M; ++a)
+        if ((e->flags[a] & CG_F_EVOACT) && ((uint64_t)cdf[a] << 32) >= r) { tgt = a; break; }
+      if (tgt >= 0 && !has_edge(e, d, tgt)) changed |= add_edge(e, d, tgt);
+    }
+  }
+  if (changed) { /* _rebuild_graph_cache (volt_typhoon_env.py:456-481) starts from an empty _blocked set */
+    memset(e->blocked, 0, (size_t)e->EW * 4);
+    memset(e->extra + e->K, 0, (size_t)((e->K + 31) / 32) * 4);
   }
 }
 
@@ -527,7 +618,7 @@ static void rewards(env_t* e, int mode, double cost, int current_work, double* r
 
 static void snapshot_restore(env_t* e, const cygym_buffers* snap, int idx);
 
-typedef struct { uint8_t* newly; uint8_t* occ; int* srcs; int* pu; int* pv; kid_t* tmp; } scratch_t;
+typedef struct { uint8_t* newly; uint8_t* occ; int* srcs; int* pu; int* pv; int* pr; int* cdf; ment_t* row; kid_t* tmp; } scratch_t;
 
 static void step_one(env_t* e, const cygym_actions* a, const cygym_outputs* o, int idx, const scratch_t* sc,
                      const cygym_buffers* snap) {
@@ -538,6 +629,8 @@ static void step_one(env_t* e, const cygym_actions* a, const cygym_outputs* o, i
   int* srcs = sc->srcs;
   int* pu = sc->pu;
   int* pv = sc->pv;
+  int* pr = sc->pr;
+  ment_t* row = sc->row;
   kid_t* tmp = sc->tmp;
   memset(occ, 0, (size_t)(3 * M));
   e->occ = occ;
@@ -567,9 +660,9 @@ static void step_one(env_t* e, const cygym_actions* a, const cygym_outputs* o, i
       if (e->c->baseline != 0) at = 8;
       def_global(e, at, devs, Ld, &cost, &dirty, 0);
       if (at == 1 || at == 4 || at == 5 || at == 6 || at == 7 || at == 9 || at == 12 || at == 13)
-        def_per_device(e, at, devs, Ld, a->app[(size_t)idx * G], &cost, &dirty, pu, pv);
+        def_per_device(e, at, devs, Ld, a->app[(size_t)idx * G], &cost, &dirty, pu, pv, pr, row);
     } else {
-      attacker(e, at, a->exploit + (size_t)idx * G * CG_MAX_EXPLOITS, a->n_exploit[(size_t)idx * G], &cost, srcs);
+      attacker(e, at, a->exploit + (size_t)idx * G * CG_MAX_EXPLOITS, a->n_exploit[(size_t)idx * G], &cost, srcs, row);
     }
     current_work = 0;
     if (!partial) {
@@ -595,7 +688,7 @@ static void step_one(env_t* e, const cygym_actions* a, const cygym_outputs* o, i
       if (mode == CG_MODE_DEFENDER) {
         if (e->c->baseline != 0) at = 8;
         def_global(e, at, dp, Ld, &cost, &dirty, 1);
-        if (at == 1) def_per_device(e, 1, dp, Ld, -1, &cost, &dirty, pu, pv);
+        if (at == 1) def_per_device(e, 1, dp, Ld, -1, &cost, &dirty, pu, pv, pr, row);
       }
       dp += Ld; used += Ld;
     }
@@ -611,7 +704,7 @@ static void step_one(env_t* e, const cygym_actions* a, const cygym_outputs* o, i
     if (mode == CG_MODE_ATTACKER) e->ienv[CG_I_ATT_STEP] += 1; else e->ienv[CG_I_DEF_STEP] += 1;
   }
   int done = e->ienv[CG_I_STEP_NUM] > e->c->episode_limit;
-  if (dirty || (e->ienv[CG_I_STEP_NUM] % e->c->evolve_period) == 0) evolve(e, newly);
+  if (dirty || (e->ienv[CG_I_STEP_NUM] % e->c->evolve_period) == 0) evolve(e, newly, sc->cdf);
   if (ng == 0) { /* :1330 */
     for (int d = 0; d < M; ++d) {
       if (e->busy[d] > 0) e->flags[d] |= CG_F_BUSYC; else e->flags[d] &= (uint8_t)~CG_F_BUSYC;
@@ -631,6 +724,8 @@ static void bind_env(env_t* e, const cygym_topology* t, const cygym_config* c, c
   e->flags = b->live + o; e->busy = e->flags + e->M; e->wl = e->busy + e->M; e->comp_by = e->wl + e->M;
   e->st_flags = b->stash + o; e->st_busy = e->st_flags + e->M; e->st_wl = e->st_busy + e->M; e->st_comp_by = e->st_wl + e->M;
   e->blocked = b->blocked + (size_t)idx * e->EW;
+  e->K = b->extra ? t->max_extra_edges : 0;
+  e->extra = e->K > 0 ? b->extra + (size_t)idx * CG_X_WORDS(e->K) : NULL;
   e->ring = b->ring + (size_t)idx * CG_LOG_RING * 2;
   e->ienv = b->ienv + (size_t)idx * CG_I_COUNT;
   e->fenv = b->fenv + (size_t)idx * CG_D_COUNT;
@@ -644,6 +739,7 @@ static void snapshot_restore(env_t* e, const cygym_buffers* s, int idx) {
   memcpy(e->flags, s->live + o, (size_t)e->M * CG_PLANES);
   memcpy(e->st_flags, s->stash + o, (size_t)e->M * CG_PLANES);
   memcpy(e->blocked, s->blocked + (size_t)si * e->EW, (size_t)e->EW * 4);
+  if (e->extra && s->extra) memcpy(e->extra, s->extra + (size_t)si * CG_X_WORDS(e->K), (size_t)CG_X_WORDS(e->K) * 4);
   memcpy(e->ring, s->ring + (size_t)si * CG_LOG_RING * 2, CG_LOG_RING * 2 * 2);
   memcpy(e->ienv, s->ienv + (size_t)si * CG_I_COUNT, CG_I_COUNT * 4);
   memcpy(e->fenv, s->fenv + (size_t)si * CG_D_COUNT, CG_D_COUNT * 8);
@@ -655,19 +751,23 @@ int cgo_step(const cygym_topology* t, const cygym_config* c, const cygym_buffers
              int32_t env_begin, int32_t env_end) {
   size_t M = (size_t)t->n_devices, E = (size_t)t->n_edges;
   scratch_t sc;
+  const size_t K = (size_t)(t->max_extra_edges > 0 ? t->max_extra_edges : 0);
   sc.newly = (uint8_t*)malloc(M + 1);
   sc.occ = (uint8_t*)malloc(3 * M + 1);
   sc.srcs = (int*)malloc(sizeof(int) * (M + 1));
-  sc.pu = (int*)malloc(sizeof(int) * (2 * E + 2));
-  sc.pv = (int*)malloc(sizeof(int) * (2 * E + 2));
+  sc.pu = (int*)malloc(sizeof(int) * (2 * E + 2 * K + 2));
+  sc.pv = (int*)malloc(sizeof(int) * (2 * E + 2 * K + 2));
+  sc.pr = (int*)malloc(sizeof(int) * (2 * E + 2 * K + 2));
+  sc.cdf = (int*)malloc(sizeof(int) * (M + 1));
+  sc.row = (ment_t*)malloc(sizeof(ment_t) * (E + K + 2));
   sc.tmp = (kid_t*)malloc(sizeof(kid_t) * (M + 1));
-  if (!sc.newly || !sc.occ || !sc.srcs || !sc.pu || !sc.pv || !sc.tmp) return CYGYM_EINVAL;
+  if (!sc.newly || !sc.occ || !sc.srcs || !sc.pu || !sc.pv || !sc.pr || !sc.cdf || !sc.row || !sc.tmp) return CYGYM_EINVAL;
   for (int i = env_begin; i < env_end; ++i) {
     env_t e;
     bind_env(&e, t, c, b, i);
     step_one(&e, a, o, i, &sc, snapshot);
   }
-  free(sc.newly); free(sc.occ); free(sc.srcs); free(sc.pu); free(sc.pv); free(sc.tmp);
+  free(sc.newly); free(sc.occ); free(sc.srcs); free(sc.pu); free(sc.pv); free(sc.pr); free(sc.cdf); free(sc.row); free(sc.tmp);
   return CYGYM_OK;
 }
 

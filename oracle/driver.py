@@ -54,7 +54,7 @@ OTHER_SHAPES = {"blocked": ("EW", np.uint32), "ring": ("R", np.uint16), "ienv": 
 STATE_KEYS = abi.STATE_PLANES + tuple(OTHER_SHAPES)
 
 
-def alloc_state(n, M, EW):
+def alloc_state(n, M, EW, K=0):
     """Struct-of-arrays state.  `live` / `stash` are the [N][4][M] buffers of the ABI; the
     per-plane entries (flags, busy, ..., st_comp_by) are numpy VIEWS into them."""
     dims = {"EW": (EW,), "R": (S.LOG_RING, 2), "I": (S.I_COUNT,), "D": (S.D_COUNT,)}
@@ -66,6 +66,7 @@ def alloc_state(n, M, EW):
     for k, (d, dt) in OTHER_SHAPES.items():
         st[k] = np.zeros((n,) + dims[d], dt)
     st["blocked_in"] = np.zeros((n, EW), np.uint32)   # derived, library-side only: the oracle never reads it
+    st["extra"] = np.zeros((n, abi.x_words(K)), np.uint32)   # edges added by evolve_network (K = max_extra)
     st["ring"][:] = 0xFFFF
     return st
 
@@ -75,7 +76,7 @@ def state_struct(st) -> abi.Buffers:
     for k in abi.BUFFER_FIELDS:
         a = st[k]
         assert a.flags["C_CONTIGUOUS"], k
-        setattr(b, k, a.ctypes.data)
+        setattr(b, k, a.ctypes.data if a.size else None)
     b.n_envs = st["live"].shape[0]
     return b
 
@@ -115,7 +116,7 @@ class OracleBatch:
         self.cfg = cfg
         self.N = n_envs
         self.M = self.topo.M
-        self.state = alloc_state(n_envs, self.M, self.topo.EW)
+        self.state = alloc_state(n_envs, self.M, self.topo.EW, self.topo.max_extra)
         self.snapshot = None
         self.obs = np.zeros((n_envs, self.M, 6), np.float32)
         self.raw = np.zeros(n_envs, np.float64)
@@ -133,6 +134,10 @@ class OracleBatch:
             if k == "ring":
                 src = np.where(src.astype(np.int64) < 0, 0xFFFF, src)
             self.state[k][...] = src.astype(dt) if src.shape[0] == self.N else np.broadcast_to(src.astype(dt), self.state[k].shape)
+        self.state["extra"][...] = 0
+        if "extra" in init and self.state["extra"].size:
+            src = np.asarray(init["extra"], np.uint32)
+            self.state["extra"][...] = src if src.shape[0] == self.N else np.broadcast_to(src, self.state["extra"].shape)
         self.snapshot = copy_state(self.state)
 
     def step(self, act: dict, begin=0, end=None):

@@ -185,21 +185,64 @@ def s600_sparse():
     """len(net) > 500: sparse attacker connect (:1344) and the lazy workload path (CDSimulator.py:325)."""
     M = 600
     env0 = H.build_env(M, 520, init_seed=61, strip_vuln_frac=0.5, extra_reachable=5, prewarm_star=True)
-    return H.run_scenario(env0, 1, 70, mixed_actions(M, ALL_DEF, ALL_ATT, 40), seed=19), 1
+    # a removal event can deactivate the hub: the star then re-forms around the next owned device
+    return H.run_scenario(env0, 1, 70, mixed_actions(M, ALL_DEF, ALL_ATT, 40), seed=19, max_extra=128), 1
 
 
 @scenario("s16_randomize")
 def s16_randomize():
-    # several attacker-owned devices: after the reshuffle the reference adds star edges at the
-    # next evolve (CyberDefenseEnv.py:738-774) -> topo_same drops and parity ends there
-    """randomize_compromise_and_ownership() before the episode (do_agent.py:189)."""
+    """randomize_compromise_and_ownership() before the episode (do_agent.py:189): with several
+    attacker-owned devices the next evolve star-connects the reshuffled set (CyberDefenseEnv.py:738-774);
+    the added edges live in the env's extra-edge list."""
     M = 16
     env0 = H.build_env(M, 13, init_seed=71, strip_vuln_frac=0.3, overrides=dict(sv_attacker_fraction=0.25))
 
     def pre(e, env, rs):
         env.randomize_compromise_and_ownership()
         return True
-    return H.run_scenario(env0, 3, 60, mixed_actions(M, ALL_DEF, ALL_ATT, 4), seed=20, pre_fn=pre), 1
+    return H.run_scenario(env0, 3, 120, mixed_actions(M, ALL_DEF, ALL_ATT, 4), seed=20, pre_fn=pre, max_extra=32), 1
+
+
+def edge_heavy_actions(M, kmax, X=2):
+    """Block / unblock / spread / probe dominate, so that the added edges are walked, picked and flipped."""
+    def fn(e, t, env, rs):
+        if t % 2 == 0:
+            at = int(rs.choice([6, 6, 6, 9, 9, 1, 7, 5, 8, 13]))
+            owned = [d.id for d in env.simulator.subnet.net.values() if d.attacker_owned]
+            dv = dev_list(rs, M, kmax, unique=rs.rand() < 0.7)
+            if owned and rs.rand() < 0.7:       # aim at the star's endpoints
+                dv = [int(x) for x in rs.choice(owned, size=min(len(owned), 1 + int(rs.randint(0, 4))), replace=True)] + dv[:2]
+            return DEF, (at, np.array([0]), dv, 0)
+        at = int(rs.choice([1, 1, 1, 2, 2, 3]))
+        ne = 1 if rs.rand() < 0.7 else 2
+        return ATT, (at, np.array([int(rs.randint(0, X)) for _ in range(ne)]), [], 0)
+    return fn
+
+
+@scenario("s24_star")
+def s24_star():
+    """Attacker-owned devices keep appearing (p_attacker > 0) and the hub can be removed: the star grows
+    (CyberDefenseEnv.py:690-694, 738-774) while block / unblock / spread / probe run over the merged rows."""
+    M = 24
+    env0 = H.build_env(M, 12, init_seed=111, strip_vuln_frac=0.4, extra_reachable=1,
+                       overrides=dict(lambda_events=1.5, p_add=0.45, p_attacker=0.4, Min_network_size=4))
+    return H.run_scenario(env0, 3, 240, edge_heavy_actions(M, 5), seed=31, max_extra=256), 1
+
+
+@scenario("s20_pa")
+def s20_pa():
+    """Inactive devices with no edges at all: once activated they are attached by preferential attachment
+    (CyberDefenseEnv.py:776-843, random.uniform :817)."""
+    M = 20
+    env0 = H.build_env(M, 10, init_seed=121, strip_vuln_frac=0.3,
+                       overrides=dict(lambda_events=2.0, p_add=0.7, p_attacker=0.15, Min_network_size=4))
+    g = env0.simulator.subnet.graph
+    lonely = [d.id for d in env0.simulator.subnet.net.values() if d.Not_yet_added][:6]
+    kill = [e.index for e in g.es if e.source in lonely or e.target in lonely]
+    g.delete_edges(kill)
+    env0._rebuild_graph_cache()
+    H.install_ascending_sets(env0)   # the PA walk over env._active_ids is defined as ascending id (see ref_harness)
+    return H.run_scenario(env0, 3, 200, edge_heavy_actions(M, 4), seed=32, max_extra=64), 1
 
 
 @scenario("s16_coin")

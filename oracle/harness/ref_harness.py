@@ -40,6 +40,7 @@ if REPO not in sys.path:
 
 from cygym_amd import rng as R          # noqa: E402
 from cygym_amd import spec as S         # noqa: E402
+from cygym_amd import abi               # noqa: E402
 
 
 def reference_available() -> bool:
@@ -508,6 +509,13 @@ def flatten_dynamic(env, static):
         for j in range(lo, hi):
             if static["out_col"][j] == v:
                 blocked[j] = 1
+    # edges evolve_network added since the export (CyberDefenseEnv.py:738-843): the multiset difference
+    # between the live neighbour cache and the exported CSR, as the env's extra-edge list
+    K = int(static.get("max_extra", 0))
+    xe = extra_edges(env, static)
+    extra = abi.pack_extra(xe, [(u, v) in env._blocked for (u, v) in xe], K) if K > 0 else np.zeros(0, np.uint32)
+    if K == 0:
+        xe = []
     logs = env.simulator.logger.logs
     ring = np.full((S.LOG_RING, 2), -1, np.int32)
     tail = logs[-S.LOG_RING:]
@@ -532,7 +540,7 @@ def flatten_dynamic(env, static):
     if det.trained: ef |= S.E_DET_TRAIN
     if det.random_detection: ef |= S.E_DET_RANDOM
     if getattr(env, "_prev_att_potential", None) is not None: ef |= S.E_PREV_SET
-    ienv[S.I_FLAGS] = ef
+    ienv[S.I_FLAGS] = ef | (len(xe) << S.E_NX_SHIFT)
     ienv[S.I_LOG_TOTAL] = len(logs)
     disc = 0
     for e, ex in enumerate(env.simulator.exploits):
@@ -545,7 +553,66 @@ def flatten_dynamic(env, static):
     pp = getattr(env, "_prev_att_potential", None)
     fenv[S.D_PREV_ATT_POT] = 0.0 if pp is None else float(pp)
     return dict(flags=flags, busy=busy, wl=wl, comp_by=comp_by, st_flags=st_flags, st_busy=st_busy,
-                st_wl=st_wl, st_comp_by=st_comp_by, blocked=blocked, ring=ring, ienv=ienv, fenv=fenv)
+                st_wl=st_wl, st_comp_by=st_comp_by, blocked=blocked, ring=ring, ienv=ienv, fenv=fenv,
+                extra=extra)
+
+
+def extra_edges(env, static):
+    """Sorted (u, v) list of the edges present in env._outnbrs but not in the exported CSR.  Also checks
+    the two ordering facts the flat restatement relies on: a rebuilt neighbour row is the exported row
+    merged with the added edges by ascending neighbour id, and env._active_ids iterates ascending."""
+    from collections import Counter
+    M = static["M"]
+    op, oc = static["out_ptr"], static["out_col"]
+    ip, ic = static["in_ptr"], static["in_col"]
+    added = []
+    for u in range(M):
+        base = [int(v) for v in oc[op[u]:op[u + 1]]]
+        cur = [int(v) for v in env._outnbrs.get(u, [])]
+        diff = Counter(cur) - Counter(base)
+        assert not (Counter(base) - Counter(cur)), f"edges of {u} disappeared"
+        for v, c in diff.items():
+            assert c == 1 and v not in base, f"added edge ({u},{v}) duplicates an existing one"
+            added.append((u, int(v)))
+        if diff:
+            xs = sorted(diff)
+            merged, j = [], 0
+            for v in base:
+                while j < len(xs) and xs[j] < v:
+                    merged.append(xs[j]); j += 1
+                merged.append(v)
+            merged.extend(xs[j:])
+            assert merged == cur, f"row {u}: merged order {merged} != cache {cur}"
+    added.sort()
+    if added:
+        for d in {v for _, v in added}:
+            base = [int(u) for u in ic[ip[d]:ip[d + 1]]]
+            xs = sorted(u for (u, v) in added if v == d)
+            merged, j = [], 0
+            for u in base:
+                while j < len(xs) and xs[j] < u:
+                    merged.append(xs[j]); j += 1
+                merged.append(u)
+            merged.extend(xs[j:])
+            assert merged == [int(u) for u in env._innbrs.get(d, [])], f"in-row {d} order"
+    return added
+
+
+class AscendingSet(set):
+    """A set that iterates in ascending order.  evolve_network's preferential attachment walks
+    `self._active_ids` (CyberDefenseEnv.py:795) in CPython hash-table order, which depends on the whole
+    insertion / deletion history of the set (a re-added id lands behind its own tombstone).  The flat
+    restatement defines that walk as ascending device id; scenarios that reach the PA branch install this
+    class for env._active_ids / _inactive_ids so that the reference run follows the same definition."""
+    def __iter__(self):
+        return iter(sorted(set.__iter__(self)))
+
+
+def install_ascending_sets(env):
+    act, inact = AscendingSet(), AscendingSet()
+    for d in env.simulator.subnet.net.values():          # what evolve_network's first call builds (:654-659)
+        (act if not d.Not_yet_added else inact).add(d.id)
+    env._active_ids, env._inactive_ids = act, inact
 
 
 def topology_signature(env):
@@ -556,7 +623,7 @@ def topology_signature(env):
 # scenario runner
 # --------------------------------------------------------------------------
 def run_scenario(env0, n_envs, n_ticks, action_fn, *, seed=0, env_id_base=0, pre_fn=None,
-                 record_draws=False):
+                 record_draws=False, max_extra=0):
     """Deep-copy `env0` n_envs times, drive each with `action_fn(e, t, env, rs)` ->
     (mode, action) and record the flattened state after every tick.
 
@@ -564,6 +631,7 @@ def run_scenario(env0, n_envs, n_ticks, action_fn, *, seed=0, env_id_base=0, pre
     4-tuples for step_grouped).  Returns a dict of stacked arrays."""
     install_rng()
     static = flatten_static(env0)
+    static["max_extra"] = int(max_extra)   # capacity of the per-env extra-edge list in this fixture
     config = flatten_config(env0)
     sig0 = topology_signature(env0)
     M = static["M"]
@@ -674,6 +742,8 @@ def save_fixture(path, result, max_groups=1):
     T = len(envs[0]["ticks"])
     keys = ["flags", "busy", "wl", "comp_by", "st_flags", "st_busy", "st_wl", "st_comp_by",
             "blocked", "ring", "ienv", "fenv"]
+    if int(st.get("max_extra", 0)) > 0:
+        keys.append("extra")
     for k in keys:
         out[f"init_{k}"] = np.stack([e["init"][k] for e in envs])
         out[f"pre_{k}"] = np.stack([e["pre"][k] for e in envs])

@@ -29,7 +29,9 @@ class Fixture:
         self.topo = abi.TopologyArrays(
             M=int(st["M"]), X=int(st["X"]), dstatic=st["dstatic"], vuln=st["vuln"], napps=st["napps"],
             os_val=st["os_val"], version=st["version"], anomaly=st["anomaly"], out_ptr=st["out_ptr"],
-            out_col=st["out_col"], in_ptr=st["in_ptr"], in_col=st["in_col"], in_eid=st["in_eid"]).normalised()
+            out_col=st["out_col"], in_ptr=st["in_ptr"], in_col=st["in_col"], in_eid=st["in_eid"],
+            max_extra=int(st.get("max_extra", 0))).normalised()
+        self.K = self.topo.max_extra   # > 0: the fixture follows the edges evolve_network adds (extra-edge list)
         cfg = dict(zip([str(k) for k in z["config_keys"]], z["config_vals"]))
         inv = {v: k for k, v in abi.BASELINES.items()}
         self.cfg = abi.EnvConfig(
@@ -52,6 +54,11 @@ class Fixture:
         self.init = {k: z["init_" + k] for k in STATE_KEYS}
         self.pre = {k: z["pre_" + k] for k in STATE_KEYS} if "pre_flags" in z.files else None
         self.exp = {k: z["exp_" + k] for k in STATE_KEYS}
+        if self.K > 0:
+            self.init["extra"] = z["init_extra"]
+            self.exp["extra"] = z["exp_extra"]
+            if self.pre is not None:
+                self.pre["extra"] = z["pre_extra"]
         for k in ("raw", "shaped", "done", "obs", "obs_def", "obs_att", "topo_same"):
             self.exp[k] = z["exp_" + k]
         # per-env flat device lists -> padded [N][T][L]
@@ -124,7 +131,12 @@ class Fixture:
             if k == "ring":
                 v = np.where(v < 0, 0xFFFF, v).astype(np.uint16)
             out[k] = v
+        if self.K > 0:
+            out["extra"] = self.exp["extra"][:, t]
         return out
+
+    def follows_topology(self) -> bool:
+        return self.K > 0
 
 
 def compare_state(got: dict, exp: dict, label: str, ring_total=None):
@@ -158,6 +170,21 @@ def compare_state(got: dict, exp: dict, label: str, ring_total=None):
             if not np.array_equal(gr[e, j % S.LOG_RING], xr[e, j % S.LOG_RING]):
                 bad.append(f"{label}: ring env {e} slot {j % S.LOG_RING}: got {gr[e, j % S.LOG_RING]} exp {xr[e, j % S.LOG_RING]}")
                 break
+    if "extra" in exp and np.asarray(exp["extra"]).size:   # live entries of the extra-edge list + their blocked bits
+        gx = np.asarray(got["extra"]).astype(np.int64)
+        xx = np.asarray(exp["extra"]).astype(np.int64)
+        K = (xx.shape[1] * 32) // 33
+        while K + (K + 31) // 32 < xx.shape[1]:
+            K += 1
+        for e in range(gi.shape[0]):
+            n = int(xi[e, S.I_FLAGS]) >> S.E_NX_SHIFT
+            if not np.array_equal(gx[e, :n], xx[e, :n]):
+                bad.append(f"{label}: extra edges env {e}: got {[(k >> 16, k & 0xFFFF) for k in gx[e, :n]]} exp {[(k >> 16, k & 0xFFFF) for k in xx[e, :n]]}")
+                continue
+            gb = [(gx[e, K + (j >> 5)] >> (j & 31)) & 1 for j in range(n)]
+            xb = [(xx[e, K + (j >> 5)] >> (j & 31)) & 1 for j in range(n)]
+            if gb != xb:
+                bad.append(f"{label}: extra-edge blocked bits env {e}: got {gb} exp {xb}")
     gf = np.asarray(got["fenv"], np.float64)
     xf = np.asarray(exp["fenv"], np.float64)
     if not np.allclose(gf, xf, rtol=0, atol=1e-9):
