@@ -58,6 +58,9 @@ def main():
     ap.add_argument("--envs", type=int, default=0, help="override envs per GPU")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--max-extra", type=int, default=0,
+                    help="capacity of the per-env list of edges evolve_network may add; 0 (default): the fixed-topology "
+                         "roofline run of SURVEY.md 8d (lambda_events = 0 never adds an edge), lean kernel")
     ap.add_argument("--cpu-seconds", type=float, default=16.0)
     ap.add_argument("--fused", type=int, default=-1,
                     help="also time cygym_rollout with this many ticks per launch (0 = off, -1 = all K steps in one launch)")
@@ -91,7 +94,7 @@ def main():
     n_per_gpu, M, blocks, desc = WORKLOADS[args.workload]
     if args.envs:
         n_per_gpu = args.envs
-    topo, init, ck = make_topology(M, blocks, seed=args.seed)
+    topo, init, ck = make_topology(M, blocks, seed=args.seed, max_extra=args.max_extra)
     # fixed-topology roofline run: lambda_events = 0; everything else at reference defaults
     cfg = abi.EnvConfig(seed=args.seed, env_id_base=rank * n_per_gpu, auto_reset=1, lambda_events=0.0, **ck)
     L = max(1, M // 8)
@@ -139,7 +142,7 @@ def main():
         "ms_per_step": wall / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {desc}", "envs_per_gpu": n_per_gpu, "devices": M, "edges": topo.E,
-                   "exploits": topo.X, "lambda_events": 0.0, "parallelism": f"env-batch split x{world}, no step-path collective"},
+                   "exploits": topo.X, "lambda_events": 0.0, "max_extra_edges": topo.max_extra, "parallelism": f"env-batch split x{world}, no step-path collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "bytes_per_env_step": B, "layout_bytes_per_env_step": layout_bytes(M, topo.E),

@@ -19,15 +19,16 @@ from . import spec as S
 
 _BUF_DTYPES = {"live": torch.uint8, "stash": torch.uint8, "blocked": torch.int32, "blocked_in": torch.int32,
                "ring": torch.int16,
-               "ienv": torch.int32, "fenv": torch.float64}
+               "ienv": torch.int32, "fenv": torch.float64, "extra": torch.int32}
 _STATE_KEYS = abi.STATE_PLANES + ("blocked", "ring", "ienv", "fenv")
-_NP_VIEW = {"blocked": np.uint32, "ring": np.uint16}
+_NP_VIEW = {"blocked": np.uint32, "ring": np.uint16, "extra": np.uint32}
 
 
-def _alloc_state(n, M, EW, device):
-    """`live` / `stash` are the [N][4][M] buffers of the ABI; flags/busy/... are VIEWS into them."""
+def _alloc_state(n, M, EW, device, K=0):
+    """`live` / `stash` are the [N][4][M] buffers of the ABI; flags/busy/... are VIEWS into them.
+    `extra` is the per-env list of edges evolve_network added (K = topo.max_extra entries)."""
     dims = {"live": (4, M), "stash": (4, M), "blocked": (EW,), "blocked_in": (EW,), "ring": (S.LOG_RING, 2),
-            "ienv": (S.I_COUNT,), "fenv": (S.D_COUNT,)}
+            "ienv": (S.I_COUNT,), "fenv": (S.D_COUNT,), "extra": (abi.x_words(K),)}
     st = {k: torch.zeros((n,) + dims[k], dtype=dt, device=device) for k, dt in _BUF_DTYPES.items()}
     for i, k in enumerate(abi.LIVE_PLANES):
         st[k] = st["live"][:, i]
@@ -41,7 +42,7 @@ def _buffers_struct(st) -> abi.Buffers:
     for k in abi.BUFFER_FIELDS:
         t = st[k]
         assert t.is_contiguous()
-        setattr(b, k, t.data_ptr())
+        setattr(b, k, t.data_ptr() if t.numel() else None)
     b.n_envs = st["live"].shape[0]
     return b
 
@@ -93,11 +94,12 @@ class BatchedCyberDefenseEnv:
         with torch.cuda.device(self.device):
             rc = self.lib.cygym_create(C.byref(t), C.byref(c), self.N, self.device.index or 0, C.byref(self._h))
         _lib.check(rc, None, "cygym_create")
-        self.state = _alloc_state(self.N, self.M, self.EW, self.device)
+        self.K = self.topo.max_extra
+        self.state = _alloc_state(self.N, self.M, self.EW, self.device, self.K)
         lead = int(np.asarray(init_state["flags"]).shape[0])
         if lead not in (1, self.N):
             raise ValueError("init_state must have leading dimension 1 or n_envs")
-        self.snapshot = _alloc_state(lead, self.M, self.EW, self.device)
+        self.snapshot = _alloc_state(lead, self.M, self.EW, self.device, self.K)
         self._load(self.snapshot, init_state)
         _lib.check(self.lib.cygym_bind(self._h, C.byref(_buffers_struct(self.state))), self._h, "cygym_bind")
         self._snap_struct = _buffers_struct(self.snapshot)
@@ -144,6 +146,10 @@ class BatchedCyberDefenseEnv:
                     raise ValueError(f"{k} does not fit a byte plane")
                 a = a.astype(np.uint8)
             dst[k].copy_(torch.from_numpy(np.ascontiguousarray(a)).reshape(dst[k].shape))
+        dst["extra"].zero_()
+        if "extra" in src and dst["extra"].numel():
+            a = np.ascontiguousarray(np.asarray(src["extra"]).astype(np.uint32)).view(np.int32)
+            dst["extra"].copy_(torch.from_numpy(a).reshape(dst["extra"].shape))
 
     def _derive(self, st):
         """Fill the library-maintained derived buffers (blocked_in) of a state dict."""
@@ -177,7 +183,7 @@ class BatchedCyberDefenseEnv:
             self._load(self.state, state)
             self._derive(self.state)
         else:
-            tmp = _alloc_state(1, self.M, self.EW, self.device)
+            tmp = _alloc_state(1, self.M, self.EW, self.device, self.K)
             self._load(tmp, state)
             self._derive(tmp)
             for k in abi.BUFFER_FIELDS:

@@ -32,6 +32,9 @@
 #include <new>
 #include "cygym_abi.h"
 
+#ifndef CG_LB
+#define CG_LB 6
+#endif
 #define CG_E_STAR_OK 0x80  // kernel-private: star edges verified for the current owned set
 
 namespace {
@@ -48,6 +51,7 @@ struct DevTopo {
   const uint8_t* blob;
   int o_optr, o_ocol, o_os, o_ver, o_ano, o_dst, o_vul, o_nap, o_iptr, o_icol, o_ieid, o_oeid;
   int blob_bytes, lds_bytes, in_lds, multi;
+  int K, KW, x_bytes;   // extra-edge list: capacity, blocked-bit words, bytes of its per-wave LDS section
   // global views (host-side convenience; kernels outside the tick use them)
   const uint8_t *dstatic, *vuln, *napps;
   const float *os_val, *version, *anomaly;
@@ -141,6 +145,13 @@ struct Env {
   uint32_t* marks;   // [Mp/32 + 2]
   uint16_t* lsrc;    // [Mp] long-row sources of the spread
   int16_t* devl;     // [L] this tick's device lists (all groups, concatenated)
+  // edges added by evolve_network (cygym_spec.h: extra-edge list), staged only when the env has any
+  uint32_t* xk;      // [K] keys (u << 16 | v), ascending; the first x_cnt() are live
+  uint32_t* xb;      // [KW] blocked bit per list entry
+  uint64_t* xmo;     // [MC] devices with an added OUT edge (their rows are walked merged)
+  uint64_t* xmi;     // [MC] devices with an added edge at either end
+  int K;
+  bool x_dirty;
   // shared LDS (topology)
   const uint16_t *optr, *ocol;
   const uint8_t *dst, *vul, *nap;
@@ -237,6 +248,78 @@ __device__ __forceinline__ void bump_busy(Env& e) {
     B[w] = b + inc;
   }
 }
+
+// ---------------- edges added by evolve_network (extra-edge list, cygym_spec.h) ----------------
+__device__ __forceinline__ int x_cnt(const Env& e) { return (int)((uint32_t)e.eflags >> CG_E_NX_SHIFT); }
+__device__ __forceinline__ bool x_isout(const Env& e, int d) { return (e.xmo[d >> 6] >> (d & 63)) & 1ull; }
+__device__ __forceinline__ bool x_isinc(const Env& e, int d) { return (e.xmi[d >> 6] >> (d & 63)) & 1ull; }
+__device__ __forceinline__ bool x_blocked(const Env& e, int j) { return (e.xb[j >> 5] >> (j & 31)) & 1u; }
+// first list entry with key >= k (per lane; the list is short)
+__device__ __forceinline__ int x_lower(const Env& e, uint32_t k) {
+  int lo = 0, hi = x_cnt(e);
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (e.xk[mid] < k) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+// device masks of the live entries (uniform)
+__device__ __forceinline__ void x_masks(Env& e) {
+  uint32_t* mo = (uint32_t*)e.xmo; uint32_t* mi = (uint32_t*)e.xmi;
+#pragma nounroll
+  for (int i = e.lane; i < 2 * e.MC; i += WAVE) { mo[i] = 0; mi[i] = 0; }
+  wsync();
+  const int n = x_cnt(e);
+#pragma nounroll
+  for (int j = e.lane; j < n; j += WAVE) {
+    const uint32_t k = e.xk[j];
+    const int u = (int)(k >> 16), v = (int)(k & 0xFFFFu);
+    atomicOr(&mo[u >> 5], 1u << (u & 31));
+    atomicOr(&mi[u >> 5], 1u << (u & 31));
+    atomicOr(&mi[v >> 5], 1u << (v & 31));
+  }
+  wsync();
+}
+// g.add_edges([(u, v)]): sorted insert (uniform); false (and CG_E_TOPO_OVF) when the list is full
+__device__ __forceinline__ bool x_add(Env& e, int u, int v) {
+  const int n = x_cnt(e);
+  if (n >= e.K) { e.eflags |= CG_E_TOPO_OVF; return false; }
+  const uint32_t key = ((uint32_t)u << 16) | (uint32_t)v;
+  int pos = 0;
+#pragma nounroll
+  for (int j0 = 0; j0 < n; j0 += WAVE) { const int j = j0 + e.lane; pos += __popcll(ballot(j < n && e.xk[j] < key)); }
+#pragma nounroll
+  for (int j0 = n > 0 ? ((n - 1) / WAVE) * WAVE : -1; j0 >= 0; j0 -= WAVE) {   // shift the tail up, top chunk first
+    const int j = j0 + e.lane;
+    const bool mv = j < n && j >= pos;
+    const uint32_t k = mv ? e.xk[j] : 0u;
+    wsync();
+    if (mv) e.xk[j + 1] = k;
+    wsync();
+  }
+  if (e.lane == 0) e.xk[pos] = key;
+  wsync();
+  e.eflags += 1 << CG_E_NX_SHIFT;
+  e.x_dirty = true;
+  return true;
+}
+// per-lane walk over the MERGED out-row of a device: the base CSR row and the device's added edges, by
+// ascending neighbour id (what _rebuild_graph_cache makes of igraph's neighbour lists)
+struct XWalk {
+  int k, o1, j, n, s;
+  uint32_t vx;   // neighbour of the pending list entry, 0x10000 = none
+  __device__ __forceinline__ void load(const Env& e) {
+    const uint32_t key = j < n ? e.xk[j] : 0xFFFFFFFFu;
+    vx = (int)(key >> 16) == s ? (key & 0xFFFFu) : 0x10000u;
+  }
+  __device__ __forceinline__ void init(const Env& e, int src) {
+    s = src; k = e.optr[s]; o1 = e.optr[s + 1]; n = x_cnt(e);
+    j = x_lower(e, (uint32_t)s << 16);
+    load(e);
+  }
+  __device__ __forceinline__ bool done() const { return k >= o1 && vx == 0x10000u; }
+  __device__ __forceinline__ bool at_extra(const Env& e) const { return k >= o1 || vx < (uint32_t)e.ocol[k]; }
+  __device__ __forceinline__ void next(const Env& e, bool was_extra) {
+    if (was_extra) { ++j; load(e); } else ++k;
+  }
+};
 
 // ---------------- defender ----------------
 __device__ __forceinline__ void def_global(Env& e, const KParams& P, int at, const int16_t* dev, int L, double& cost,
@@ -398,6 +481,92 @@ __device__ __forceinline__ void pool_flip(const PoolPtrs q, bool multi, const Pi
   }
 }
 
+// Block / unblock on an env whose device list touches an endpoint of an ADDED edge: the incident pools are the
+// merged rows (:502-511).  Sequential over the list (the reference's own order), every step wave-cooperative.
+// Element r of a merged pool: walk the added-edge candidates in row order; candidate j has rank
+// (#added candidates before it) + (#base candidates with a smaller neighbour id).
+__device__ __forceinline__ void block_seq(Env& e, const PoolPtrs q, const int16_t* dev, int L, bool want, uint32_t site,
+                                          int& n_act, int& n_hit) {
+  const int M = e.M;
+  uint8_t* occ = (uint8_t*)(e.scr + e.MC * WAVE);
+#pragma nounroll
+  for (int i = e.lane; i < (e.MC * WAVE) / 4; i += WAVE) ((uint32_t*)occ)[i] = 0;
+  wsync();
+  const int n = x_cnt(e);
+#pragma nounroll
+  for (int p = 0; p < L; ++p) {
+    const int d = dev[p];
+    if (d < 0 || d >= M || (e.flags[d] & CG_F_NYA)) continue;
+    ++n_act;
+    const int o0 = e.optr[d], o1 = e.optr[d + 1], i0 = e.iptr(d), i1 = e.iptr(d + 1);
+    const int nbo = range_popc(q.blk, o0, o1), nbi = range_popc(q.bin, i0, i1);
+    const int b_out = want ? nbo : (o1 - o0) - nbo, b_in = want ? nbi : (i1 - i0) - nbi;
+    int x_out = 0, x_in = 0;
+#pragma nounroll
+    for (int j0 = 0; j0 < n; j0 += WAVE) {
+      const int j = j0 + e.lane;
+      const uint32_t k = j < n ? e.xk[j] : 0u;
+      const bool c = j < n && x_blocked(e, j) == want;
+      x_out += __popcll(ballot(c && (int)(k >> 16) == d));
+      x_in += __popcll(ballot(c && (int)(k & 0xFFFFu) == d));
+    }
+    const int total = b_out + x_out + b_in + x_in;
+    if (total == 0) continue;
+    const int occ_d = occ[d];
+    int r = (int)cg_index(e.draw(site, d, occ_d), (uint32_t)total);
+    const bool from_out = r < b_out + x_out;
+    if (!from_out) r -= b_out + x_out;
+    int pick_x = -1, x_before = 0;   // chosen added edge, or the number of added candidates ahead of element r
+#pragma nounroll
+    for (int j0 = 0; j0 < n && pick_x < 0; j0 += WAVE) {
+      const int j = j0 + e.lane;
+      const uint32_t kk = j < n ? e.xk[j] : 0u;
+      uint64_t xm = ballot(j < n && x_blocked(e, j) == want && (from_out ? (int)(kk >> 16) == d : (int)(kk & 0xFFFFu) == d));
+#pragma nounroll
+      while (xm) {
+        const int jj = j0 + __builtin_ctzll(xm);
+        xm &= xm - 1;
+        const uint32_t key = e.xk[jj];
+        const int other = from_out ? (int)(key & 0xFFFFu) : (int)(key >> 16);
+        int cb = 0;   // base candidates ahead of this added edge
+        if (from_out) {
+#pragma nounroll
+          for (int k0 = o0; k0 < o1; k0 += WAVE) {
+            const int k = k0 + e.lane;
+            cb += __popcll(ballot(k < o1 && (((q.blk[k >> 5] >> (k & 31)) & 1u) != 0) == want && (int)q.ocol[k] < other));
+          }
+        } else {
+#pragma nounroll
+          for (int k0 = i0; k0 < i1; k0 += WAVE) {
+            const int k = k0 + e.lane;
+            cb += __popcll(ballot(k < i1 && (((q.bin[k >> 5] >> (k & 31)) & 1u) != 0) == want && (int)q.icol[k] <= other));
+          }
+        }
+        if (r == x_before + cb) { pick_x = jj; break; }
+        if (r < x_before + cb) { xm = 0; j0 = n; break; }   // element r is a base candidate
+        ++x_before;
+      }
+    }
+    if (pick_x >= 0) {
+      if (e.lane == 0) {
+        if (!want) e.xb[pick_x >> 5] |= 1u << (pick_x & 31); else e.xb[pick_x >> 5] &= ~(1u << (pick_x & 31));
+      }
+      e.x_dirty = true;
+    } else {
+      Pick pk;
+      const int t = r - x_before;
+      if (from_out) { pk.slot = range_select(q.blk, o0, o1, want, t); pk.j = q.oeid[pk.slot]; pk.x = q.ocol[pk.slot]; }
+      else          { pk.j = range_select(q.bin, i0, i1, want, t); pk.slot = q.ieid[pk.j]; pk.x = q.icol[pk.j]; }
+      if (e.lane == 0) pool_flip(q, e.multi, pk, d, o0, o1, want);
+      e.blk_dirty = true;
+    }
+    if (e.lane == 0) occ[d] = (uint8_t)(occ_d + 1);
+    ++n_hit;
+    wsync();
+  }
+}
+
+template <bool XE>
 __device__ __forceinline__ void def_per_device(Env& e, const KParams& P, int at, const int16_t* dev, int L, int app,
                                                double& cost, bool& dirty, int32_t* ie, double* fe) {
   const double ds = P.c.def_scale;
@@ -418,7 +587,16 @@ __device__ __forceinline__ void def_per_device(Env& e, const KParams& P, int at,
     q.blk = e.blk; q.bin = e.bin; q.optr = e.optr; q.ocol = e.ocol; q.icol = e.icol_g; q.ieid = e.ieid_g; q.oeid = e.oeid_g;
     const bool multi = e.multi;
     int n_act = 0, n_hit = 0;
-    for (int p0 = 0; p0 < L; p0 += WAVE) {
+    bool seq = false;
+    if (XE && x_cnt(e) > 0) {   // does the list touch an endpoint of an added edge?
+      for (int p0 = 0; p0 < L; p0 += WAVE) {
+        const int p = p0 + e.lane;
+        const int d = p < L ? dev[p] : -1;
+        if (__any(d >= 0 && d < M && x_isinc(e, d))) seq = true;
+      }
+    }
+    if constexpr (XE) { if (seq) block_seq(e, q, dev, L, want, site, n_act, n_hit); }
+    for (int p0 = 0; p0 < L && !seq; p0 += WAVE) {
       // one lane per list entry: device, row bounds and the (occurrence 0) draw
       const int p = p0 + e.lane;
       int d = -1, o0 = 0, o1 = 0, i0 = 0, i1 = 0;
@@ -640,6 +818,61 @@ __device__ __forceinline__ int spread_scan_coop(const Env& e, const uint32_t* T,
   return o1;
 }
 
+// One fix-point round for the sources whose rows carry ADDED edges: per-lane walk of the merged row;
+// cur[s] = o0 + index in the merged row (o0 + merged length = nothing to take).  Kept out of the main
+// round loop so that its registers are not live there.
+__device__ __forceinline__ bool spread_x_round(const Env& e, uint32_t* T, uint16_t* cur, const uint16_t* slist, int n_src, int round) {
+  bool changed = false;
+#pragma nounroll
+  for (int b0 = 0; b0 < n_src; b0 += WAVE) {
+    const int i = b0 + e.lane;
+    if (i >= n_src) continue;
+    const int s = slist[i];
+    if (!x_isout(e, s)) continue;
+    const int o0 = e.optr[s], k0 = cur[s];
+    const bool dc = e.dst[s] & CG_D_DC;
+    XWalk w; w.init(e, s);
+    int m = 0, hit = -1, hv = 0;
+    const int m_from = k0 - o0;
+    while (!w.done()) {
+      const bool ex = w.at_extra(e);
+      const int v = ex ? (int)w.vx : (int)e.ocol[w.k];
+      const bool bl = ex ? x_blocked(e, w.j) : e.blocked(w.k);
+      if (m >= m_from && !bl && (dc || spread_ok(T, v, s))) { hit = m; hv = v; break; }
+      w.next(e, ex); ++m;
+    }
+    const int k = o0 + m;   // m == merged length when nothing can be taken
+    if (k != k0) { cur[s] = (uint16_t)k; changed = true; }
+    if (hit >= 0 && (round == 0 || k != k0)) spread_take(T, hv, s);
+  }
+  return changed;
+}
+// log entries of those sources (unblocked merged entries up to and including the pick) + DC attribution
+__device__ __forceinline__ int spread_x_counts(Env& e, const uint16_t* cur, const uint16_t* slist, uint16_t* cntv, int n_src, uint8_t ebit) {
+  int total = 0;
+#pragma nounroll
+  for (int b0 = 0; b0 < n_src; b0 += WAVE) {
+    const int i = b0 + e.lane;
+    int n = 0;
+    if (i < n_src && x_isout(e, slist[i])) {
+      const int s = slist[i];
+      XWalk w; w.init(e, s);
+      const int last = (int)cur[s] - (int)e.optr[s];
+      const bool dc = e.dst[s] & CG_D_DC;
+      for (int m = 0; !w.done() && m <= last; ++m) {
+        const bool ex = w.at_extra(e);
+        n += !(ex ? x_blocked(e, w.j) : e.blocked(w.k));
+        if (m == last && dc) byte_or(e.cby, ex ? (int)w.vx : (int)e.ocol[w.k], ebit);   // DC attribution :1163-1168
+        w.next(e, ex);
+      }
+      cntv[i] = (uint16_t)n;
+    }
+    total += wave_sum(n);
+  }
+  return total;
+}
+
+template <bool XE>
 __device__ __forceinline__ void attacker_spread(Env& e, const KParams& P, const int32_t* expl, int n_expl,
                                                 uint64_t* srcb) {
   const int M = e.M, MC = e.MC, Mp = MC * WAVE;
@@ -656,6 +889,7 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KParams& P, const 
     n_src += __popcll(sm);
   }
   wsync();
+  const bool xany = XE && x_cnt(e) > 0;   // this env has added edges: their sources walk merged rows
   int zocc = 0;
   for (int j = 0; j < n_expl; ++j) {
     int raw = expl[j];
@@ -698,14 +932,15 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KParams& P, const 
           o0 = e.optr[s]; o1 = e.optr[s + 1]; k0 = cur[s]; st = e.dst[s];
           const bool dc = st & CG_D_DC;
           int k = k0;
-          if (o1 - o0 <= LONG_ROW) k = spread_scan_lane(e, T, s, dc, k0, o1);
+          if (xany && x_isout(e, s)) {   // row with added edges: handled by spread_x_round below
+          } else if (o1 - o0 <= LONG_ROW) k = spread_scan_lane(e, T, s, dc, k0, o1);
           else if ((st & CG_D_FULLROW) && !dc) {
             if (!(k0 < o1 && !e.blocked(k0) && spread_ok(T, e.ocol[k0], s)))
               k = spread_scan_full(e, T, cand, s, round == 0 ? k0 : k0 + 1, o0, o1);
           } else {
             coop = round == 0 || (k0 < o1 && !(dc || spread_ok(T, e.ocol[k0], s)));
           }
-          if (!coop) {
+          if (!coop && !(xany && x_isout(e, s))) {
             if (k != k0) { cur[s] = (uint16_t)k; changed = true; }
             if (k < o1 && (round == 0 || k != k0)) spread_take(T, e.ocol[k], s);
           }
@@ -724,6 +959,7 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KParams& P, const 
           }
         }
       }
+      if constexpr (XE) { if (xany && spread_x_round(e, T, cur, slist, n_src, round)) changed = true; }
       wsync();
       if (!__any(changed)) break;
     }
@@ -737,13 +973,17 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KParams& P, const 
       if (i < n_src) {
         int s = slist[i];
         int o0 = e.optr[s], o1 = e.optr[s + 1];
-        int end = cur[s] < o1 ? cur[s] + 1 : o1;
-        n = (end - o0) - range_popc(e.blk, o0, end);
+        if (xany && x_isout(e, s)) {   // counted by spread_x_counts below
+        } else {
+          int end = cur[s] < o1 ? cur[s] + 1 : o1;
+          n = (end - o0) - range_popc(e.blk, o0, end);
+        }
       }
       cntv[i < Mp ? i : 0] = (uint16_t)n;
       total_new += wave_sum(n);
     }
     wsync();
+    if constexpr (XE) { if (xany) { total_new += spread_x_counts(e, cur, slist, cntv, n_src, ebit); wsync(); } }
     SUBSTAMP(12);
     // ring: only the last CG_LOG_RING entries (global order: source id, then row order) matter
     if (total_new > 0) {
@@ -760,8 +1000,23 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KParams& P, const 
         uint32_t off = cbase + (uint32_t)(incl - n);
         bool mine = n > 0 && off + (uint32_t)n > lo;
         int s = mine ? (int)slist[i] : 0;
-        bool is_long = mine && (e.optr[s + 1] - e.optr[s]) > LONG_ROW;
-        if (mine && !is_long) {
+        const bool xs = mine && xany && x_isout(e, s);
+        bool is_long = mine && !xs && (e.optr[s + 1] - e.optr[s]) > LONG_ROW;
+        if (xs) {
+          uint32_t idx = off;
+          XWalk w; w.init(e, s);
+          const int last = (int)cur[s] - (int)e.optr[s];
+          for (int m = 0; !w.done() && m <= last; ++m) {
+            const bool ex = w.at_extra(e);
+            const int v = ex ? (int)w.vx : (int)e.ocol[w.k];
+            if (!(ex ? x_blocked(e, w.j) : e.blocked(w.k))) {
+              if (idx >= lo) { e.ring[2 * (idx % CG_LOG_RING)] = (uint16_t)s; e.ring[2 * (idx % CG_LOG_RING) + 1] = (uint16_t)v; }
+              ++idx;
+            }
+            w.next(e, ex);
+          }
+        }
+        if (mine && !is_long && !xs) {
           uint32_t idx = off;
           int o1 = e.optr[s + 1];
           int last = cur[s] < o1 ? (int)cur[s] : o1 - 1;
@@ -800,13 +1055,16 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KParams& P, const 
       if ((T[d] >> 2) != T_TIME_INF && (T[d] >> 2) != 0u) e.flags[d] |= CG_F_COMP;
     for (int i = e.lane; i < n_src; i += WAVE) {
       int s = slist[i];
-      if ((e.dst[s] & CG_D_DC) && cur[s] < e.optr[s + 1]) byte_or(e.cby, e.ocol[cur[s]], ebit);
+      if (!(e.dst[s] & CG_D_DC)) continue;
+      if (xany && x_isout(e, s)) continue;   // attributed while its log entries were counted
+      if (cur[s] < e.optr[s + 1]) byte_or(e.cby, e.ocol[cur[s]], ebit);
     }
     wsync();
     SUBSTAMP(14);
   }
 }
 
+template <bool XE>
 __device__ __forceinline__ void attacker_probe(Env& e, const uint64_t* srcb, double& cost) {
   int n_src = 0;
   for (int c = 0; c < e.MC; ++c) n_src += __popcll(srcb[c]);
@@ -817,6 +1075,23 @@ __device__ __forceinline__ void attacker_probe(Env& e, const uint64_t* srcb, dou
     int k = __popcll(srcb[c]);
     if (r < k) { s = c * WAVE + nth_bit(srcb[c], r); break; }
     r -= k;
+  }
+  if (XE && x_cnt(e) > 0 && x_isout(e, s)) {   // row with added edges: uniform walk of the merged row
+    XWalk w; w.init(e, s);
+    int v = -1;
+    while (!w.done()) {
+      const bool ex = w.at_extra(e);
+      const int vv = ex ? (int)w.vx : (int)e.ocol[w.k];
+      if (!(ex ? x_blocked(e, w.j) : e.blocked(w.k)) && !(e.flags[vv] & CG_F_KNOWN)) { v = vv; break; }
+      w.next(e, ex);
+    }
+    wsync();
+    if (v >= 0) {
+      if (e.lane == 0) e.flags[v] |= CG_F_KNOWN;
+      cost += 0.1;
+    }
+    wsync();
+    return;
   }
   const int o0 = e.optr[s], o1 = e.optr[s + 1];
   for (int k0 = o0; k0 < o1; k0 += WAVE) {
@@ -958,15 +1233,26 @@ __device__ __forceinline__ int rank_select(const Env& e, uint8_t mask, uint8_t w
   }
   return -1;
 }
-__device__ __forceinline__ bool has_edge(const Env& e, int u, int v) {
+// g.get_eid(u, v, directed=True, error=False) != -1 over the base CSR and the env's added edges (uniform)
+template <bool XE>
+__device__ __forceinline__ bool edge_exists(const Env& e, int u, int v) {
   const int o0 = e.optr[u], o1 = e.optr[u + 1];
+#pragma nounroll
   for (int k0 = o0; k0 < o1; k0 += WAVE) {
-    int k = k0 + e.lane;
+    const int k = k0 + e.lane;
     if (ballot(k < o1 && e.ocol[k] == v)) return true;
+  }
+  const int n = XE ? x_cnt(e) : 0;
+  const uint32_t key = ((uint32_t)u << 16) | (uint32_t)v;
+#pragma nounroll
+  for (int j0 = 0; j0 < n; j0 += WAVE) {
+    const int j = j0 + e.lane;
+    if (ballot(j < n && e.xk[j] == key)) return true;
   }
   return false;
 }
 
+template <bool XE>
 __device__ __forceinline__ void evolve(Env& e, const KParams& P) {
   const int M = e.M, MC = e.MC;
   if (!(e.eflags & CG_E_EVO_INIT)) {   // :654-659
@@ -1030,34 +1316,97 @@ __device__ __forceinline__ void evolve(Env& e, const KParams& P) {
     }
     wsync();
   }
-  // star reconnection (:738-774) would ADD edges when hub<->owner links are missing: detect + flag.
+  bool changed = false;
+  // star reconnection (:738-774): hub = first active attacker-owned device; missing hub<->owner links are
+  // ADDED to the env's extra-edge list (a full list raises CG_E_TOPO_OVF and leaves the check pending).
+  // Cold code: loops are kept rolled and every helper has one call site (instruction-cache footprint).
   if (!(e.eflags & CG_E_STAR_OK)) {
     int hub = rank_select(e, CG_F_OWNED | CG_F_EVOACT, CG_F_OWNED | CG_F_EVOACT, 0);
     bool ok = true;
     if (hub >= 0) {
-      for (int c = 0; c < MC && ok; ++c) {
+#pragma nounroll
+      for (int c = 0; c < MC; ++c) {
         int d = c * WAVE + e.lane;
         uint64_t m = ballot(d < M && d != hub && (e.flags[d] & (CG_F_OWNED | CG_F_EVOACT)) == (CG_F_OWNED | CG_F_EVOACT));
-        while (m && ok) {
-          int o = c * WAVE + __builtin_ctzll(m);
-          m &= m - 1;
-          if (!has_edge(e, hub, o) || !has_edge(e, o, hub)) ok = false;
+#pragma nounroll
+        for (int it = 0; m; ++it) {   // two directed edges per owner: hub -> o, then o -> hub
+          const int o = c * WAVE + __builtin_ctzll(m);
+          const int u = (it & 1) ? o : hub, v = (it & 1) ? hub : o;
+          if (it & 1) m &= m - 1;
+          if (!edge_exists<XE>(e, u, v)) { if (XE && x_add(e, u, v)) changed = true; else { ok = false; e.eflags |= CG_E_TOPO_OVF; } }
         }
       }
     }
-    if (ok) e.eflags |= CG_E_STAR_OK; else e.eflags |= CG_E_TOPO_OVF;
+    if (ok) e.eflags |= CG_E_STAR_OK;
   }
-  // preferential attachment of isolated newcomers (:776-843) would add an edge: detect + flag.
+  // preferential attachment of isolated newcomers (:776-843): one degree snapshot (after the star edges),
+  // weights degree + 1 over the active devices in ascending id, r = random.uniform(0, total) (:817)
   if (any_new) {
+    const int n0 = x_cnt(e);
     bool iso = false;
+#pragma nounroll
     for (int c = 0; c < MC; ++c) {
       int d = c * WAVE + e.lane;
       if (d < M && ((newly[d >> 5] >> (d & 31)) & 1u) && !(e.flags[d] & (CG_F_NYA | CG_F_OWNED))) {
         int deg = (e.optr[d + 1] - e.optr[d]) + (e.iptr(d + 1) - e.iptr(d));
-        if (deg < 1) iso = true;
+        if (deg < 1) iso = true;   // candidates only: the added edges are counted below
       }
     }
-    if (__any(iso)) e.eflags |= CG_E_TOPO_OVF;
+    if (!XE && __any(iso)) e.eflags |= CG_E_TOPO_OVF;   // no extra-edge list in this build of the kernel
+    if (XE && __any(iso)) {
+      uint32_t* cdf = e.scr;   // [Mp] inclusive weight sums
+      int total = 0;
+#pragma nounroll
+      for (int c = 0; c < MC; ++c) {
+        const int d = c * WAVE + e.lane;
+        int w = 0;
+        if (d < M && (e.flags[d] & CG_F_EVOACT)) {
+          w = (e.optr[d + 1] - e.optr[d]) + (e.iptr(d + 1) - e.iptr(d)) + 1;
+#pragma nounroll
+          for (int j = 0; j < n0; ++j) { const uint32_t k = e.xk[j]; w += ((int)(k >> 16) == d) + ((int)(k & 0xFFFFu) == d); }
+        }
+        const int incl = wave_incl_scan(w, e.lane);
+        cdf[d] = (uint32_t)(total + incl);
+        total += __shfl(incl, 63);
+      }
+      wsync();
+#pragma nounroll
+      for (int c = 0; c < MC && total > 0; ++c) {
+        const int d0 = c * WAVE + e.lane;
+        uint64_t m = ballot(d0 < M && ((newly[d0 >> 5] >> (d0 & 31)) & 1u) && !(e.flags[d0] & (CG_F_NYA | CG_F_OWNED)) &&
+                            (e.optr[d0 + 1] - e.optr[d0]) + (e.iptr(d0 + 1) - e.iptr(d0)) < 1);
+#pragma nounroll
+        while (m) {
+          const int d = c * WAVE + __builtin_ctzll(m);
+          m &= m - 1;
+          // live degree (:809): an edge added earlier in this call may already touch d
+          int deg = 0;
+          const int n = x_cnt(e);
+#pragma nounroll
+          for (int j0 = 0; j0 < n; j0 += WAVE) {
+            const int j = j0 + e.lane;
+            const uint32_t k = j < n ? e.xk[j] : 0xFFFFFFFFu;
+            deg += __popcll(ballot(j < n && ((int)(k >> 16) == d || (int)(k & 0xFFFFu) == d)));
+          }
+          if (deg >= 1) continue;
+          const uint64_t r = (uint64_t)total * (uint64_t)e.draw(CG_SITE_EVO_PA, d, 0);
+          int tgt = -1;
+#pragma nounroll
+          for (int c2 = 0; c2 < MC && tgt < 0; ++c2) {   // bisect_left(cdf, r) over the active devices
+            const int a = c2 * WAVE + e.lane;
+            const uint64_t hit = ballot(a < M && (e.flags[a] & CG_F_EVOACT) && ((uint64_t)cdf[a] << 32) >= r);
+            if (hit) tgt = c2 * WAVE + __builtin_ctzll(hit);
+          }
+          if (tgt >= 0 && !edge_exists<XE>(e, d, tgt)) { if (x_add(e, d, tgt)) changed = true; }
+        }
+      }
+    }
+  }
+  if (XE && changed) {   // _rebuild_graph_cache (volt_typhoon_env.py:456-481) starts from an empty _blocked set
+    for (int w = e.lane; w < P.t.EW; w += WAVE) { e.blk[w] = 0; e.bin[w] = 0; }
+    for (int w = e.lane; w < P.t.KW; w += WAVE) e.xb[w] = 0;
+    e.blk_dirty = true;
+    x_masks(e);
   }
   wsync();
 }
@@ -1081,6 +1430,11 @@ __device__ __forceinline__ WaveAux env_setup(Env& e, uint8_t* smem, const KParam
   e.lsrc = (uint16_t*)(x.srcb + MC);
   e.devl = (int16_t*)(e.lsrc + Mp);
   x.park = (int32_t*)(wb + P.wave_lds - 128);   // [16 i32 + 3 f64] per-env scalars between fused ticks
+  e.xk = (uint32_t*)(wb + P.wave_lds - 128 - P.t.x_bytes);
+  e.xb = e.xk + P.t.K;
+  e.xmo = (uint64_t*)(e.xb + ((P.t.KW + 1) & ~1));
+  e.xmi = e.xmo + MC;
+  e.K = P.t.K;
   e.optr = (const uint16_t*)(smem + P.t.o_optr); e.ocol = (const uint16_t*)(smem + P.t.o_ocol);
   e.osv = (const float*)(smem + P.t.o_os); e.ver = (const float*)(smem + P.t.o_ver); e.ano = (const float*)(smem + P.t.o_ano);
   e.dst = smem + P.t.o_dst; e.vul = smem + P.t.o_vul; e.nap = smem + P.t.o_nap;
@@ -1097,8 +1451,8 @@ __device__ __forceinline__ WaveAux env_setup(Env& e, uint8_t* smem, const KParam
 
 // FUSED: cygym_rollout (n_ticks > 1).  The per-env scalars are parked in LDS between ticks so that they are
 // not loop-carried registers; the single-tick instantiation has a compile-time trip count of 1.
-template <int WPB, int MT, bool FUSED>
-__global__ __launch_bounds__(WPB * WAVE, FUSED ? 4 : 1) void step_kernel(const KParams P0) {
+template <int WPB, int MT, bool FUSED, bool XE>
+__global__ __launch_bounds__(WPB * WAVE, FUSED ? 4 : (XE ? CG_LB : 1)) void step_kernel(const KParams P0) {
   extern __shared__ __align__(16) uint8_t smem[];
   // every use below goes through `P`: the kernarg copy for the single-tick kernel, the device copy for the
   // fused one (so that it can be re-read, opaquely, at the top of every tick)
@@ -1116,7 +1470,7 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? 4 : 1) void step_kernel(const K
   uint64_t* srcb = aux.srcb;
   int32_t* park = aux.park;
   e.env = env;
-  e.blk_dirty = e.ring_dirty = false;
+  e.blk_dirty = e.ring_dirty = e.x_dirty = false;
 
   STAMP(0);
   // ---- issue every global load of this tick up front (one memory latency, not a chain) ----
@@ -1243,6 +1597,14 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? 4 : 1) void step_kernel(const K
   e.tick = (uint32_t)ie[CG_I_RNG_TICK];
   e.eflags = ie[CG_I_FLAGS];
   e.log_total = ie[CG_I_LOG_TOTAL];
+  if (XE && (!FUSED || tk == 0) && x_cnt(e) > 0) {   // this env carries edges evolve_network added: stage its list
+    const uint32_t* xg = P.b.extra + (size_t)env * (P.t.K + P.t.KW);
+    const int nx = x_cnt(e) < P.t.K ? x_cnt(e) : P.t.K;
+    for (int j = lane; j < nx; j += WAVE) e.xk[j] = xg[j];
+    for (int w = lane; w < P.t.KW; w += WAVE) e.xb[w] = xg[P.t.K + w];
+    wsync();
+    x_masks(e);
+  }
   double cost = 0.0;
   bool dirty = false;
   int last_atype = -1;
@@ -1263,7 +1625,7 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? 4 : 1) void step_kernel(const K
       if (P.c.baseline != 0) at = 8;   // :913-914
       def_global(e, P, at, devs, Ld, cost, dirty, false, ie, fe);
       if (at == 1 || at == 4 || at == 5 || at == 6 || at == 7 || at == 9 || at == 12 || at == 13)
-        if (Ld > 0) def_per_device(e, P, at, devs, Ld, app0, cost, dirty, ie, fe);
+        if (Ld > 0) def_per_device<XE>(e, P, at, devs, Ld, app0, cost, dirty, ie, fe);
     } else if (P.c.baseline != 3 && (at == 1 || at == 2)) {
 #pragma unroll
       for (int c = 0; c < MC; ++c) {   // :1127 snapshot of the sources
@@ -1276,10 +1638,10 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? 4 : 1) void step_kernel(const K
         int ne = nexp0;
         if (ne > CG_MAX_EXPLOITS) ne = CG_MAX_EXPLOITS;
         __builtin_amdgcn_s_setprio(3);   // the spread bounds the launch: win issue arbitration over short envs
-        attacker_spread(e, P, P.a.exploit + te * G * CG_MAX_EXPLOITS, ne, srcb);
+        attacker_spread<XE>(e, P, P.a.exploit + te * G * CG_MAX_EXPLOITS, ne, srcb);
         __builtin_amdgcn_s_setprio(0);
       } else {
-        attacker_probe(e, srcb, cost);
+        attacker_probe<XE>(e, srcb, cost);
       }
     }
     last_atype = at;
@@ -1394,7 +1756,7 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? 4 : 1) void step_kernel(const K
     if (mode == CG_MODE_ATTACKER) ie[CG_I_ATT_STEP] += 1; else ie[CG_I_DEF_STEP] += 1;
   }
   const bool done = ie[CG_I_STEP_NUM] > P.c.episode_limit;
-  if (dirty || (ie[CG_I_STEP_NUM] % P.c.evolve_period) == 0) evolve(e, P);
+  if (dirty || (ie[CG_I_STEP_NUM] % P.c.evolve_period) == 0) evolve<XE>(e, P);
   if (ng == 0) {   // :1330 rebuild of the cached busy set
     for (int w = lane; w < NW; w += WAVE) F[w] = (F[w] & ~(ONES * CG_F_BUSYC)) | (nz01(Bz[w]) << 6);
   }
@@ -1427,11 +1789,22 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? 4 : 1) void step_kernel(const K
     }
     if (lane < CG_LOG_RING) ((uint32_t*)e.ring)[lane] = ((const uint32_t*)(P.snap.ring + (size_t)si * CG_LOG_RING * 2))[lane];
     e.blk_dirty = e.ring_dirty = true;
+    if (XE && P.t.K > 0) {   // the snapshot's extra-edge list (normally empty) replaces the episode's
+      const int ns = P.snap.extra ? (int)((uint32_t)P.snap.ienv[(size_t)si * CG_I_COUNT + CG_I_FLAGS] >> CG_E_NX_SHIFT) : 0;
+      const uint32_t* xs = P.snap.extra + (size_t)si * (P.t.K + P.t.KW);
+      for (int j = lane; j < ns; j += WAVE) e.xk[j] = xs[j];
+      for (int w = lane; w < P.t.KW; w += WAVE) e.xb[w] = ns > 0 ? xs[P.t.K + w] : 0u;
+      e.eflags = (e.eflags & 0xFFFF) | (ns << CG_E_NX_SHIFT);
+      wsync();
+      x_masks(e);
+      e.x_dirty = true;
+    }
     const int32_t keep_tick = ie[CG_I_RNG_TICK];
     const int32_t* g = P.snap.ienv + (size_t)si * CG_I_COUNT;
 #pragma unroll
     for (int i = 0; i < CG_I_COUNT; ++i) ie[i] = g[i];
     ie[CG_I_RNG_TICK] = keep_tick;
+    if (!(P.t.K > 0 && P.snap.extra)) ie[CG_I_FLAGS] &= 0xFFFF;
     const double* gf = P.snap.fenv + (size_t)si * CG_D_COUNT;
 #pragma unroll
     for (int i = 0; i < CG_D_COUNT; ++i) fe[i] = gf[i];
@@ -1463,6 +1836,12 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? 4 : 1) void step_kernel(const K
     }
   if (e.ring_dirty && lane < CG_LOG_RING)
     ((uint32_t*)(P.b.ring + (size_t)env * CG_LOG_RING * 2))[lane] = ((const uint32_t*)e.ring)[lane];
+  if (XE && e.x_dirty) {
+    uint32_t* xg = P.b.extra + (size_t)env * (P.t.K + P.t.KW);
+    const int nx = (int)((uint32_t)ie[CG_I_FLAGS] >> CG_E_NX_SHIFT);
+    for (int j = lane; j < nx; j += WAVE) xg[j] = e.xk[j];
+    for (int w = lane; w < P.t.KW; w += WAVE) xg[P.t.K + w] = e.xb[w];
+  }
   if (lane == 0) {
     int32_t* g = P.b.ienv + (size_t)env * CG_I_COUNT;
 #pragma unroll
@@ -1498,9 +1877,13 @@ __global__ void reset_kernel(KParams P, const int32_t* env_ids, int n) {
   }
   if (lane < CG_LOG_RING)
     ((uint32_t*)(P.b.ring + (size_t)env * CG_LOG_RING * 2))[lane] = ((const uint32_t*)(P.snap.ring + (size_t)si * CG_LOG_RING * 2))[lane];
+  const int XW = P.t.K + P.t.KW;
+  if (P.t.K > 0 && P.snap.extra)
+    for (int w = lane; w < XW; w += WAVE) P.b.extra[(size_t)env * XW + w] = P.snap.extra[(size_t)si * XW + w];
   if (lane < CG_I_COUNT) {
     int32_t v = P.snap.ienv[(size_t)si * CG_I_COUNT + lane];
     if (lane == CG_I_RNG_TICK) v = tick;   // the draw counter is monotone across episodes
+    if (lane == CG_I_FLAGS && !(P.t.K > 0 && P.snap.extra)) v &= 0xFFFF;   // no extra-edge list to restore
     P.b.ienv[(size_t)env * CG_I_COUNT + lane] = v;
   }
   if (lane < CG_D_COUNT) P.b.fenv[(size_t)env * CG_D_COUNT + lane] = P.snap.fenv[(size_t)si * CG_D_COUNT + lane];
@@ -1677,20 +2060,28 @@ static int fail(cygym_handle* h, int code, const char* fmt, const char* detail) 
     if (_e != hipSuccess) return fail(h, CYGYM_EHIP, #call ": %s", hipGetErrorString(_e)); \
   } while (0)
 
-template <int MT, bool FUSED>
+template <int MT, bool FUSED, bool XE>
 static const void* kernel_for(int wpb) {
   switch (wpb) {
-    case 16: return (const void*)step_kernel<16, MT, FUSED>;
-    case 8: return (const void*)step_kernel<8, MT, FUSED>;
-    case 4: return (const void*)step_kernel<4, MT, FUSED>;
-    case 2: return (const void*)step_kernel<2, MT, FUSED>;
-    default: return (const void*)step_kernel<1, MT, FUSED>;
+    case 16: return (const void*)step_kernel<16, MT, FUSED, XE>;
+    case 8: return (const void*)step_kernel<8, MT, FUSED, XE>;
+    case 4: return (const void*)step_kernel<4, MT, FUSED, XE>;
+    case 2: return (const void*)step_kernel<2, MT, FUSED, XE>;
+    default: return (const void*)step_kernel<1, MT, FUSED, XE>;
   }
 }
+template <bool FUSED, bool XE>
+static const void* kernel_for_m(const cygym_handle* h) {
+  if (h->t.M == 256) return kernel_for<256, FUSED, XE>(h->wpb);
+  if (h->t.M == 64) return kernel_for<64, FUSED, XE>(h->wpb);
+  return kernel_for<0, FUSED, XE>(h->wpb);
+}
+// XE: the kernel that follows the edges evolve_network adds (max_extra_edges > 0).  With no extra-edge list
+// the lean instantiation runs: none of that code is in it.
 static const void* pick_kernel(const cygym_handle* h, bool fused) {
-  if (h->t.M == 256) return fused ? kernel_for<256, true>(h->wpb) : kernel_for<256, false>(h->wpb);
-  if (h->t.M == 64) return fused ? kernel_for<64, true>(h->wpb) : kernel_for<64, false>(h->wpb);
-  return fused ? kernel_for<0, true>(h->wpb) : kernel_for<0, false>(h->wpb);
+  const bool xe = h->t.K > 0;
+  if (fused) return xe ? kernel_for_m<true, true>(h) : kernel_for_m<true, false>(h);
+  return xe ? kernel_for_m<false, true>(h) : kernel_for_m<false, false>(h);
 }
 static hipError_t set_lds_attr(cygym_handle* h) {
   const int lds = h->shared_lds + h->wave_lds * h->wpb;
@@ -1710,7 +2101,7 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static size_t wave_lds_bytes(const DevTopo& t, int max_devs) {
   size_t w = align_up((size_t)4 * ((t.M + 3) & ~3), 16) + (size_t)t.Mp * 8 + (size_t)((t.EW + 3) & ~3) * 4 * 2 + CG_LOG_RING * 4 +
              (size_t)((t.Mp / 32 + 2) & ~1) * 4 + (size_t)t.MC * 8 + (size_t)t.Mp * 2 +
-             align_up((size_t)max_devs * 2, 16) + 128 /* scalar parking of the fused kernel */;
+             align_up((size_t)max_devs * 2, 16) + (size_t)t.x_bytes + 128 /* scalar parking of the fused kernel */;
   return align_up(w, 16);
 }
 // The in-CSR (iptr/icol/ieid/oeid, ~2/3 of the blob) is read by block/unblock only (~9 % of env-ticks):
@@ -1774,6 +2165,16 @@ int cygym_create(const cygym_topology* topo, const cygym_config* cfg, int32_t n_
     free(seen);
     if (!ok) return fail(nullptr, CYGYM_EINVAL, "in_eid does not match the out-CSR%s", "");
   }
+  {   // edges evolve_network may add are kept per env and merged into the rows by neighbour id
+    const int K = topo->max_extra_edges;
+    if (K < 0 || K > 4096 || E + K > 65535) return fail(nullptr, CYGYM_EINVAL, "max_extra_edges must be in [0, 4096] and n_edges + max_extra_edges <= 65535%s", "");
+    bool sorted = true;
+    for (int u = 0; u < M && sorted && K > 0; ++u) {
+      for (int k = topo->out_ptr[u] + 1; k < topo->out_ptr[u + 1] && sorted; ++k) sorted = topo->out_col[k - 1] <= topo->out_col[k];
+      for (int k = topo->in_ptr[u] + 1; k < topo->in_ptr[u + 1] && sorted; ++k) sorted = topo->in_col[k - 1] <= topo->in_col[k];
+    }
+    if (!sorted) return fail(nullptr, CYGYM_EINVAL, "max_extra_edges > 0 needs adjacency rows sorted by neighbour id%s", "");
+  }
   cygym_handle* h = new (std::nothrow) cygym_handle();
   if (!h) return fail(nullptr, CYGYM_EINVAL, "out of host memory%s", "");
   memset(h, 0, sizeof(*h));
@@ -1783,6 +2184,8 @@ int cygym_create(const cygym_topology* topo, const cygym_config* cfg, int32_t n_
   DevTopo& t = h->t;
   t.M = M; t.X = X; t.E = E; t.EW = (E + 31) / 32 > 0 ? (E + 31) / 32 : 1;
   t.MC = (M + WAVE - 1) / WAVE; t.Mp = t.MC * WAVE;
+  t.K = topo->max_extra_edges; t.KW = (t.K + 31) / 32;
+  t.x_bytes = t.K > 0 ? (int)align_up((size_t)4 * (t.K + ((t.KW + 1) & ~1)) + (size_t)16 * t.MC, 16) : 0;
   // one blob, laid out exactly as the LDS-shared section (see DevTopo)
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 16); return (int)o; };
@@ -1858,6 +2261,7 @@ int cygym_set_config(cygym_handle* h, const cygym_config* cfg) {
 static int check_buffers(cygym_handle* h, const cygym_buffers* b, bool snapshot) {
   if (!b || !b->live || !b->stash || !b->blocked || !b->blocked_in || !b->ring || !b->ienv || !b->fenv)
     return fail(h, CYGYM_EINVAL, "buffer struct has a null plane%s", "");
+  if (h->t.K > 0 && !b->extra) return fail(h, CYGYM_EINVAL, "max_extra_edges > 0 needs the `extra` plane%s", "");
   if (snapshot ? (b->n_envs != 1 && b->n_envs != h->n_envs) : (b->n_envs != h->n_envs))
     return fail(h, CYGYM_EINVAL, "buffer struct has the wrong leading dimension%s", "");
   return CYGYM_OK;

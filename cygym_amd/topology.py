@@ -27,8 +27,10 @@ from . import spec as S
 
 
 def make_topology(M: int, n_blocks: int = 1, seed: int = 0, n_exploits: int = 2, vuln_frac: float = 0.5,
-                  n_active: int | None = None):
-    """Returns (TopologyArrays, init_state dict with leading dim 1, EnvConfig defaults dict)."""
+                  n_active: int | None = None, max_extra: int | None = None):
+    """Returns (TopologyArrays, init_state dict with leading dim 1, EnvConfig defaults dict).
+    max_extra: capacity of the per-env list of edges evolve_network may add (None: room for two full
+    attacker stars, CyberDefenseEnv.py:738-774)."""
     rs = np.random.RandomState(seed * 7919 + M)
     n_active = M if n_active is None else int(n_active)
     blocks = np.array_split(np.arange(M), max(1, n_blocks))
@@ -105,6 +107,9 @@ def make_topology(M: int, n_blocks: int = 1, seed: int = 0, n_exploits: int = 2,
         os_val=np.arange(M, dtype=np.float32), version=rs.choice([1.0, 2.0, 3.0], size=M).astype(np.float32),
         anomaly=np.zeros(M, np.float32), out_ptr=out_ptr, out_col=out_col,
         in_ptr=in_ptr, in_col=in_col, in_eid=in_eid).normalised()
+    if max_extra is None:   # two stars of 2*(n_owned-1) edges, rounded up to a multiple of 4, at least 16
+        max_extra = max(16, (4 * max(0, n_owned - 1) + 12 + 3) & ~3)
+    topo.max_extra = int(max_extra)
 
     flags = np.zeros(M, np.uint8)
     active = np.zeros(M, bool)

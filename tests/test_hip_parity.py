@@ -38,8 +38,11 @@ def test_hip_matches_reference_fixture(name):
         got = env.state_numpy()
         same = fx.exp["topo_same"][:, t].astype(bool)
         ovf = (got["ienv"][:, S.I_FLAGS] & S.E_TOPO_OVF) != 0
-        assert np.array_equal(ovf[alive], ~same[alive]), f"{name} t={t}: TOPO_OVF {ovf} vs topo_same {same}"
-        alive &= same
+        if fx.follows_topology():   # the edges evolve_network adds are part of the compared state
+            assert not ovf.any(), f"{name} t={t}: extra-edge list overflowed"
+        else:
+            assert np.array_equal(ovf[alive], ~same[alive]), f"{name} t={t}: TOPO_OVF {ovf} vs topo_same {same}"
+            alive &= same
         if not alive.any():
             break
         sel = np.where(alive)[0]
@@ -115,6 +118,58 @@ def test_hip_matches_oracle_synthetic(M, blocks, N, ticks, n_active):
                                   ob.state["ienv"][:, S.I_FLAGS] & (S.E_TOPO_OVF | S.E_BUSY_SAT))
     if M < 500:   # dense attacker edges: the topology never needs to change
         assert not (ob.state["ienv"][:, S.I_FLAGS] & S.E_TOPO_OVF).any()
+    env.close()
+
+
+@pytest.mark.parametrize("M,blocks,N,ticks,n_active,max_extra", [(24, 1, 96, 300, 12, 160), (64, 4, 128, 240, 40, 160),
+                                                                 (256, 1, 96, 160, 200, 192), (24, 1, 64, 200, 12, 6)])
+def test_hip_matches_oracle_with_added_edges(M, blocks, N, ticks, n_active, max_extra):
+    """evolve_network ADDS edges (star around the attacker-owned hub, CyberDefenseEnv.py:738-774): ownership is
+    reshuffled before the episode and keeps changing (p_attacker > 0, removals), so the per-env extra-edge lists
+    fill up while spread / probe / block / unblock run over the merged rows.  max_extra=6 also overflows the
+    list: both sides must then raise CG_E_TOPO_OVF at the same tick and drop the same edges."""
+    from oracle import driver as od
+    topo, init, ck = make_topology(M, blocks, seed=9, n_active=n_active, max_extra=max_extra)
+    ck.update(dict(lambda_events=1.6, p_add=0.45, p_attacker=0.08, num_of_device=max(2, n_active // 2), min_network_size=2))
+    cfg = abi.EnvConfig(seed=17, env_id_base=5000, **ck)
+    L = max(1, M // 8)
+    env = _env(topo, cfg, N, init, max_groups=1, max_devs=L)
+    ob = od.OracleBatch(topo, cfg, N)
+    ob.load_state(init)
+    env.randomize()
+    ob.randomize()
+    seen_edges = 0
+    for t in range(ticks):
+        env.gen_actions(t)
+        act = gen_actions_numpy(cfg.seed, cfg.env_id_base, N, M, topo.X, t, L)
+        if t % 3 == 0:   # lean on block / unblock aimed at attacker-owned devices (the star's endpoints)
+            fl = ob.state["flags"]
+            for e in range(0, N, 2):
+                if act["mode"][e] != S.MODE_DEFENDER:
+                    continue
+                owned = np.flatnonzero(fl[e] & S.F_OWNED)
+                if owned.size:
+                    k = min(L, owned.size)
+                    act["atype"][e, 0] = 6 if (t // 3 + e) % 3 else 9
+                    act["dev_cnt"][e, 0] = k
+                    act["dev_idx"][e, :k] = owned[:k]
+            env.set_actions_numpy(act)
+        obs, raw, shaped, done = env.step()
+        o_obs, o_raw, o_shaped, o_done = ob.step(act)
+        np.testing.assert_allclose(raw.cpu().numpy(), o_raw, rtol=0, atol=1e-9, err_msg=f"raw t={t}")
+        if t % 4 == 0 or t == ticks - 1:
+            got = env.state_numpy()
+            got["ienv"] = got["ienv"].copy()
+            got["ienv"][:, S.I_FLAGS] &= ~0x80
+            np.testing.assert_array_equal(got["ienv"][:, S.I_FLAGS] & S.E_TOPO_OVF, ob.state["ienv"][:, S.I_FLAGS] & S.E_TOPO_OVF,
+                                          err_msg=f"TOPO_OVF t={t}")
+            bad = gio.compare_state(got, ob.state, f"M={M} t={t}")
+            assert not bad, "\n".join(bad[:8])
+            np.testing.assert_array_equal(obs.cpu().numpy(), o_obs, err_msg=f"obs t={t}")
+        seen_edges = max(seen_edges, int((ob.state["ienv"][:, S.I_FLAGS].astype(np.int64) >> S.E_NX_SHIFT).max()))
+    assert seen_edges > 0, "the scenario never added an edge"
+    ovf = (ob.state["ienv"][:, S.I_FLAGS] & S.E_TOPO_OVF) != 0
+    assert ovf.any() == (max_extra == 6)
     env.close()
 
 

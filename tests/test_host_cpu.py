@@ -142,10 +142,16 @@ def test_tick_kernels_do_not_spill():
     res = json.load(open(B.RESOURCES))
     ticks = {k: v for k, v in res.items() if "step_kernel" in k}
     assert ticks, "no step_kernel instantiations found in the resource report"
+    import re
+    seen = set()
     for name, r in ticks.items():
-        fused = "ELb1E" in name
-        if fused:
+        m = re.search(r"ELb([01])ELb([01])E", name)   # step_kernel<WPB, MT, FUSED, XE>
+        assert m, name
+        fused, xe = m.group(1) == "1", m.group(2) == "1"
+        seen.add((fused, xe))
+        if fused or xe:   # register-capped variants (128 / 80 VGPRs): a few cold spills are tolerated
             assert r["scratch"] <= 256, (name, r)
-        else:
+        else:             # the lean per-tick kernel: no scratch at all
             assert r["scratch"] == 0 and r.get("vgpr_spill", 0) == 0, (name, r)
             assert r["vgprs"] <= 128, (name, r)
+    assert seen == {(False, False), (False, True), (True, False), (True, True)}
