@@ -275,3 +275,43 @@ def test_rollout_equals_stepwise(M, blocks, N, T):
     assert not gio.compare_state(b, ob.state, "stepwise vs oracle")
     assert out["done"].any(), "the episode cap must have been crossed"
     env.close(); fused.close()
+
+
+@pytest.mark.parametrize("M,blocks,N,T,max_extra", [(24, 1, 64, 60, 160), (256, 1, 64, 40, 192)])
+def test_rollout_with_added_edges(M, blocks, N, T, max_extra):
+    """The fused rollout keeps the extra-edge list in LDS across ticks: edges added by evolve_network at tick t
+    are walked at tick t+1 inside the same launch, an episode cap restores the snapshot's (empty) list, and the
+    result equals stepping tick by tick and the oracle."""
+    from oracle import driver as od
+    from cygym_amd.batched_env import BatchedCyberDefenseEnv
+    topo, init, ck = make_topology(M, blocks, seed=23, n_active=max(4, M // 2), max_extra=max_extra)
+    ck.update(dict(lambda_events=1.6, p_add=0.45, p_attacker=0.08, num_of_device=max(2, M // 4), min_network_size=2,
+                   episode_limit=23, auto_reset=1))
+    cfg = abi.EnvConfig(seed=29, env_id_base=900, **ck)
+    L = max(1, M // 8)
+    env = _env(topo, cfg, N, init, max_groups=1, max_devs=L)
+    fused = BatchedCyberDefenseEnv(topo, cfg, N, init, device="cuda:0", max_groups=1, max_devs=L)
+    ob = od.OracleBatch(topo, cfg, N)
+    ob.load_state(init)
+    for b in (env, fused, ob):
+        b.randomize()
+    act, out = fused.alloc_rollout(T)
+    fused.gen_actions_rollout(0, act)
+    fused.rollout(act, out)
+    seen = 0
+    for t in range(T):
+        env.gen_actions(t)
+        obs, raw, shaped, done = env.step()
+        o_obs, o_raw, o_shaped, o_done = ob.step(gen_actions_numpy(cfg.seed, cfg.env_id_base, N, M, topo.X, t, L))
+        assert torch.equal(out["obs"][t], obs), f"obs t={t}"
+        assert torch.equal(out["raw"][t], raw) and torch.equal(out["done"][t], done), f"t={t}"
+        np.testing.assert_allclose(raw.cpu().numpy(), o_raw, rtol=0, atol=1e-9, err_msg=f"raw t={t}")
+        seen = max(seen, int((ob.state["ienv"][:, S.I_FLAGS].astype(np.int64) >> S.E_NX_SHIFT).max()))
+    a, b = fused.state_numpy(), env.state_numpy()
+    for k in ("live", "stash", "blocked", "blocked_in", "ring", "ienv", "fenv"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    a["ienv"] = a["ienv"].copy()
+    a["ienv"][:, S.I_FLAGS] &= ~0x80
+    assert not gio.compare_state(a, ob.state, "fused vs oracle")
+    assert seen > 0 and out["done"].any()
+    env.close(); fused.close()
