@@ -162,6 +162,11 @@ def main():
             out["roofline"]["algorithmic_bytes_per_launch"] = n_per_gpu * B
         except Exception:
             pass
+    if rank == 0:
+        # also price the kernel against a device-copy bandwidth measured on this box
+        bw = measured_copy_gbs(dev)
+        out["roofline"]["measured_copy_peak"] = bw
+        out["roofline"]["frac_of_measured_copy"] = achieved / bw if bw else None
     if args.fused:
         out["fused_rollout"] = fused_leg(env, init, scripts, W, K, args.fused, world, dev, n_per_gpu, B, backend)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -212,6 +217,25 @@ def fused_leg(env, init, scripts, W, K, T, world, dev, n_per_gpu, B, backend="nc
             "value": n_per_gpu * world * K / wall, "unit": "env-steps/s", "ms_per_tick": wall / K * 1e3,
             "roofline_frac": achieved / HBM_PEAK_GBS, "roofline_achieved_GBs": achieved,
             "last_raw_reward_sum": float(chunks[-1][1]["raw"][-1].sum())}
+
+
+def measured_copy_gbs(dev, mib=1024, reps=8):
+    """Device-to-device copy bandwidth (read + write bytes / time) of a 1 GiB buffer, HIP events."""
+    import torch
+    n = mib << 20
+    a = torch.empty(n, dtype=torch.uint8, device=dev)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1)
+    del a, b
+    return 2.0 * n * reps / (ms / 1e3) / 1e9 if ms > 0 else None
 
 
 def cpu_baseline(topo, init, cfg, M, L, scripts, W, budget_s):

@@ -84,6 +84,8 @@ struct KParams {
 #define SUBVAL(k, v) do {} while (0)
 #endif
 
+#define COLD(c) __builtin_expect(!!(c), 0)   // rarely-taken extra-edge paths: keep them out of the hot layout
+
 // ---------------- wave-level helpers ----------------
 __device__ __forceinline__ void wsync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -588,14 +590,14 @@ __device__ __forceinline__ void def_per_device(Env& e, const KParams& P, int at,
     const bool multi = e.multi;
     int n_act = 0, n_hit = 0;
     bool seq = false;
-    if (XE && x_cnt(e) > 0) {   // does the list touch an endpoint of an added edge?
+    if (COLD(XE && x_cnt(e) > 0)) {   // does the list touch an endpoint of an added edge?
       for (int p0 = 0; p0 < L; p0 += WAVE) {
         const int p = p0 + e.lane;
         const int d = p < L ? dev[p] : -1;
         if (__any(d >= 0 && d < M && x_isinc(e, d))) seq = true;
       }
     }
-    if constexpr (XE) { if (seq) block_seq(e, q, dev, L, want, site, n_act, n_hit); }
+    if constexpr (XE) { if (COLD(seq)) block_seq(e, q, dev, L, want, site, n_act, n_hit); }
     for (int p0 = 0; p0 < L && !seq; p0 += WAVE) {
       // one lane per list entry: device, row bounds and the (occurrence 0) draw
       const int p = p0 + e.lane;
@@ -932,7 +934,7 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KParams& P, const 
           o0 = e.optr[s]; o1 = e.optr[s + 1]; k0 = cur[s]; st = e.dst[s];
           const bool dc = st & CG_D_DC;
           int k = k0;
-          if (xany && x_isout(e, s)) {   // row with added edges: handled by spread_x_round below
+          if (COLD(xany && x_isout(e, s))) {   // row with added edges: handled by spread_x_round below
           } else if (o1 - o0 <= LONG_ROW) k = spread_scan_lane(e, T, s, dc, k0, o1);
           else if ((st & CG_D_FULLROW) && !dc) {
             if (!(k0 < o1 && !e.blocked(k0) && spread_ok(T, e.ocol[k0], s)))
@@ -959,7 +961,7 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KParams& P, const 
           }
         }
       }
-      if constexpr (XE) { if (xany && spread_x_round(e, T, cur, slist, n_src, round)) changed = true; }
+      if constexpr (XE) { if (COLD(xany)) { if (spread_x_round(e, T, cur, slist, n_src, round)) changed = true; } }
       wsync();
       if (!__any(changed)) break;
     }
@@ -973,7 +975,7 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KParams& P, const 
       if (i < n_src) {
         int s = slist[i];
         int o0 = e.optr[s], o1 = e.optr[s + 1];
-        if (xany && x_isout(e, s)) {   // counted by spread_x_counts below
+        if (COLD(xany && x_isout(e, s))) {   // counted by spread_x_counts below
         } else {
           int end = cur[s] < o1 ? cur[s] + 1 : o1;
           n = (end - o0) - range_popc(e.blk, o0, end);
@@ -983,7 +985,7 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KParams& P, const 
       total_new += wave_sum(n);
     }
     wsync();
-    if constexpr (XE) { if (xany) { total_new += spread_x_counts(e, cur, slist, cntv, n_src, ebit); wsync(); } }
+    if constexpr (XE) { if (COLD(xany)) { total_new += spread_x_counts(e, cur, slist, cntv, n_src, ebit); wsync(); } }
     SUBSTAMP(12);
     // ring: only the last CG_LOG_RING entries (global order: source id, then row order) matter
     if (total_new > 0) {
@@ -1002,7 +1004,7 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KParams& P, const 
         int s = mine ? (int)slist[i] : 0;
         const bool xs = mine && xany && x_isout(e, s);
         bool is_long = mine && !xs && (e.optr[s + 1] - e.optr[s]) > LONG_ROW;
-        if (xs) {
+        if (COLD(xs)) {
           uint32_t idx = off;
           XWalk w; w.init(e, s);
           const int last = (int)cur[s] - (int)e.optr[s];
@@ -1056,7 +1058,7 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KParams& P, const 
     for (int i = e.lane; i < n_src; i += WAVE) {
       int s = slist[i];
       if (!(e.dst[s] & CG_D_DC)) continue;
-      if (xany && x_isout(e, s)) continue;   // attributed while its log entries were counted
+      if (COLD(xany && x_isout(e, s))) continue;   // attributed while its log entries were counted
       if (cur[s] < e.optr[s + 1]) byte_or(e.cby, e.ocol[cur[s]], ebit);
     }
     wsync();
@@ -1076,7 +1078,7 @@ __device__ __forceinline__ void attacker_probe(Env& e, const uint64_t* srcb, dou
     if (r < k) { s = c * WAVE + nth_bit(srcb[c], r); break; }
     r -= k;
   }
-  if (XE && x_cnt(e) > 0 && x_isout(e, s)) {   // row with added edges: uniform walk of the merged row
+  if (COLD(XE && x_cnt(e) > 0 && x_isout(e, s))) {   // row with added edges: uniform walk of the merged row
     XWalk w; w.init(e, s);
     int v = -1;
     while (!w.done()) {
@@ -1333,7 +1335,7 @@ __device__ __forceinline__ void evolve(Env& e, const KParams& P) {
           const int o = c * WAVE + __builtin_ctzll(m);
           const int u = (it & 1) ? o : hub, v = (it & 1) ? hub : o;
           if (it & 1) m &= m - 1;
-          if (!edge_exists<XE>(e, u, v)) { if (XE && x_add(e, u, v)) changed = true; else { ok = false; e.eflags |= CG_E_TOPO_OVF; } }
+          if (COLD(!edge_exists<XE>(e, u, v))) { if (XE && x_add(e, u, v)) changed = true; else { ok = false; e.eflags |= CG_E_TOPO_OVF; } }
         }
       }
     }
@@ -1353,7 +1355,7 @@ __device__ __forceinline__ void evolve(Env& e, const KParams& P) {
       }
     }
     if (!XE && __any(iso)) e.eflags |= CG_E_TOPO_OVF;   // no extra-edge list in this build of the kernel
-    if (XE && __any(iso)) {
+    if (COLD(XE && __any(iso))) {
       uint32_t* cdf = e.scr;   // [Mp] inclusive weight sums
       int total = 0;
 #pragma nounroll
@@ -1402,7 +1404,7 @@ __device__ __forceinline__ void evolve(Env& e, const KParams& P) {
       }
     }
   }
-  if (XE && changed) {   // _rebuild_graph_cache (volt_typhoon_env.py:456-481) starts from an empty _blocked set
+  if (COLD(XE && changed)) {   // _rebuild_graph_cache (volt_typhoon_env.py:456-481) starts from an empty _blocked set
     for (int w = e.lane; w < P.t.EW; w += WAVE) { e.blk[w] = 0; e.bin[w] = 0; }
     for (int w = e.lane; w < P.t.KW; w += WAVE) e.xb[w] = 0;
     e.blk_dirty = true;
@@ -1597,7 +1599,7 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? 4 : (XE ? CG_LB : 1)) void step
   e.tick = (uint32_t)ie[CG_I_RNG_TICK];
   e.eflags = ie[CG_I_FLAGS];
   e.log_total = ie[CG_I_LOG_TOTAL];
-  if (XE && (!FUSED || tk == 0) && x_cnt(e) > 0) {   // this env carries edges evolve_network added: stage its list
+  if (COLD(XE && (!FUSED || tk == 0) && x_cnt(e) > 0)) {   // this env carries edges evolve_network added: stage its list
     const uint32_t* xg = P.b.extra + (size_t)env * (P.t.K + P.t.KW);
     const int nx = x_cnt(e) < P.t.K ? x_cnt(e) : P.t.K;
     for (int j = lane; j < nx; j += WAVE) e.xk[j] = xg[j];
@@ -1789,7 +1791,7 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? 4 : (XE ? CG_LB : 1)) void step
     }
     if (lane < CG_LOG_RING) ((uint32_t*)e.ring)[lane] = ((const uint32_t*)(P.snap.ring + (size_t)si * CG_LOG_RING * 2))[lane];
     e.blk_dirty = e.ring_dirty = true;
-    if (XE && P.t.K > 0) {   // the snapshot's extra-edge list (normally empty) replaces the episode's
+    if (COLD(XE && P.t.K > 0)) {   // the snapshot's extra-edge list (normally empty) replaces the episode's
       const int ns = P.snap.extra ? (int)((uint32_t)P.snap.ienv[(size_t)si * CG_I_COUNT + CG_I_FLAGS] >> CG_E_NX_SHIFT) : 0;
       const uint32_t* xs = P.snap.extra + (size_t)si * (P.t.K + P.t.KW);
       for (int j = lane; j < ns; j += WAVE) e.xk[j] = xs[j];
@@ -1836,7 +1838,7 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? 4 : (XE ? CG_LB : 1)) void step
     }
   if (e.ring_dirty && lane < CG_LOG_RING)
     ((uint32_t*)(P.b.ring + (size_t)env * CG_LOG_RING * 2))[lane] = ((const uint32_t*)e.ring)[lane];
-  if (XE && e.x_dirty) {
+  if (COLD(XE && e.x_dirty)) {
     uint32_t* xg = P.b.extra + (size_t)env * (P.t.K + P.t.KW);
     const int nx = (int)((uint32_t)ie[CG_I_FLAGS] >> CG_E_NX_SHIFT);
     for (int j = lane; j < nx; j += WAVE) xg[j] = e.xk[j];

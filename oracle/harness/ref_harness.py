@@ -428,6 +428,7 @@ def flatten_static(env):
 
 
 def flatten_config(env):
+    assert not env.turbo, "turbo=True (throttled workloads / skipped detector) is outside the restated path"
     return dict(
         num_of_device=int(env.numOfDevice), min_network_size=int(env.Min_network_size),
         max_exploits=int(env.MaxExploits), evolve_period=int(env._evolve_period),
