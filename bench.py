@@ -1,10 +1,15 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/sec of the batched CyGym tick on MI355X.
 
-One "step" = one tick (cygym_step) of every env of the batch, on synthetic input:
-the fixed-topology generator (cygym_amd/topology.py) and the alternating
-defender/attacker action script, pre-generated on device so
-that all inputs are resident in HBM when the timed region starts.
+One "step" = one tick of every env of the batch, on synthetic input: the fixed-topology
+generator (cygym_amd/topology.py) and the alternating defender/attacker action script
+(SURVEY.md section 8d), pre-generated on device so that all inputs are resident in HBM
+when the timed region starts.  The script is open loop by construction, so the K timed
+steps are issued the way the library runs an open-loop rollout: cygym_rollout, K ticks in
+one launch, state on chip between ticks, every tick's observation / reward / done written
+to HBM (`value`, `roofline`).  The same K steps issued as K cygym_step launches -- what a
+closed-loop policy would drive -- are timed too and reported under `per_tick_stepping`
+(`--headline per_tick` swaps the two).
 
 Contract (see the task description): `python bench.py --gpus N --steps K --warmup W`;
 for N > 1 the driver launches one rank per GPU with torch.distributed.run.  Envs are
@@ -35,6 +40,7 @@ WORKLOADS = {
 }
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PMC_SUMMARY = "r01_v6_target_pmc_summary.json"
 
 
 def algorithmic_bytes(M: int, E: int) -> float:
@@ -63,7 +69,9 @@ def main():
                          "roofline run of SURVEY.md 8d (lambda_events = 0 never adds an edge), lean kernel")
     ap.add_argument("--cpu-seconds", type=float, default=16.0)
     ap.add_argument("--fused", type=int, default=-1,
-                    help="also time cygym_rollout with this many ticks per launch (0 = off, -1 = all K steps in one launch)")
+                    help="ticks per cygym_rollout launch (-1 = all K steps in one launch, 0 = skip the rollout leg)")
+    ap.add_argument("--headline", default="rollout", choices=["rollout", "per_tick"],
+                    help="which way of issuing the K steps fills value / roofline (the other one is reported beside it)")
     args = ap.parse_args()
 
     import torch
@@ -131,44 +139,57 @@ def main():
         wall, ev_ms = float(tt[0]), float(tt[1])
 
     total_envs = n_per_gpu * world
-    value = total_envs * K / wall
     launch_s = (ev_ms / 1e3) / K      # average launch duration over the timed region (incl. inter-kernel gaps)
     B = algorithmic_bytes(M, topo.E)
-    achieved = n_per_gpu * B / launch_s / 1e9
     ret_sum = float(env.raw.sum())
+    per_tick = {"what": "K launches of cygym_step (what a closed-loop policy drives)",
+                "value": total_envs * K / wall, "unit": "env-steps/s", "ms_per_step": wall / K * 1e3,
+                "roofline": roofline_block(n_per_gpu * B, launch_s, "step_kernel<.., FUSED=0>", 1),
+                "last_raw_reward_sum": ret_sum}
+    rollout = None
+    if args.fused:
+        rollout = fused_leg(env, init, scripts, W, K, args.fused, world, dev, n_per_gpu, B, backend)
+    head = rollout if (rollout is not None and args.headline == "rollout") else per_tick
+    other = per_tick if head is rollout else rollout
 
     out = {
-        "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": wall / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "metric": "env-steps/sec", "value": head["value"], "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {desc}", "envs_per_gpu": n_per_gpu, "devices": M, "edges": topo.E,
-                   "exploits": topo.X, "lambda_events": 0.0, "max_extra_edges": topo.max_extra, "parallelism": f"env-batch split x{world}, no step-path collective"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "bytes_per_env_step": B, "layout_bytes_per_env_step": layout_bytes(M, topo.E),
-                     "kernel": "step_kernel", "launch_us": launch_s * 1e6},
-        "check": {"last_raw_reward_sum": ret_sum},
+                   "exploits": topo.X, "lambda_events": 0.0, "max_extra_edges": topo.max_extra,
+                   "stepping": head["what"],
+                   "parallelism": f"env-batch split x{world}, no step-path collective"},
+        "roofline": head["roofline"],
+        "check": {"last_raw_reward_sum": head["last_raw_reward_sum"],
+                  "same_trajectory_both_ways": (rollout is None) or (rollout["last_raw_reward_sum"] == ret_sum)},
     }
+    out["roofline"].update({"bytes_per_env_step": B, "layout_bytes_per_env_step": layout_bytes(M, topo.E)})
+    if other is not None:
+        out["per_tick_stepping" if other is per_tick else "fused_rollout"] = other
 
-    # HBM traffic of the dominant kernel from the committed PMC pass of this same command
+    # HBM traffic of each kernel from the committed PMC passes of this same command
     # (profiles/: separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled per the gfx950 note)
-    pmc = os.path.join(ROOT, "profiles", "r01_v5_target_pmc_summary.json")
+    pmc = os.path.join(ROOT, "profiles", PMC_SUMMARY)
     if args.workload == "target" and not args.envs and os.path.exists(pmc):
         try:
-            c = json.load(open(pmc))["per_tick"]
-            out["roofline"]["traffic"] = (2.0 * c["FETCH_SIZE"]["mean_per_launch"] + c["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
-            out["roofline"]["traffic_unit"] = "bytes per launch"
-            out["roofline"]["traffic_source"] = "profiles/r01_v5_target_pmc_summary.json (rocprofv3 --pmc, same command)"
-            out["roofline"]["algorithmic_bytes_per_launch"] = n_per_gpu * B
+            c = json.load(open(pmc))
+            for leg, key in ((per_tick, "per_tick"), (rollout, "fused")):
+                if leg is None or key not in c:
+                    continue
+                kb = 2.0 * c[key]["FETCH_SIZE"]["mean_per_launch"] + c[key]["WRITE_SIZE"]["mean_per_launch"]
+                ticks_pmc = float(c[key].get("ticks_per_launch", 1))
+                r = leg["roofline"]
+                r["traffic"] = kb * 1024.0 / ticks_pmc * r["ticks_per_launch"]
+                r["traffic_unit"] = "bytes per launch"
+                r["traffic_source"] = f"profiles/{PMC_SUMMARY} (rocprofv3 --pmc passes of this command, tools_profile.py)"
         except Exception:
             pass
     if rank == 0:
         # also price the kernel against a device-copy bandwidth measured on this box
         bw = measured_copy_gbs(dev)
         out["roofline"]["measured_copy_peak"] = bw
-        out["roofline"]["frac_of_measured_copy"] = achieved / bw if bw else None
-    if args.fused:
-        out["fused_rollout"] = fused_leg(env, init, scripts, W, K, args.fused, world, dev, n_per_gpu, B, backend)
+        out["roofline"]["frac_of_measured_copy"] = out["roofline"]["achieved"] / bw if bw else None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(topo, init, cfg, M, L, scripts, W, args.cpu_seconds)
     if rank == 0:
@@ -186,7 +207,7 @@ def fused_leg(env, init, scripts, W, K, T, world, dev, n_per_gpu, B, backend="nc
     import torch.distributed as dist
     T = K if T < 0 else min(T, K)
     env.load_state(init)
-    for t in range(W):
+    for t in range(W):   # the W untimed warm-up steps
         env.step(scripts[t])
     n_launch = (K + T - 1) // T
     chunks = []
@@ -195,9 +216,17 @@ def fused_leg(env, init, scripts, W, K, T, world, dev, n_per_gpu, B, backend="nc
         act = {k: torch.stack([scripts[t][k] for t in range(lo, hi)]).contiguous() for k in scripts[0]}
         _, out = env.alloc_rollout(hi - lo)
         chunks.append((act, out))
+    # warm the rollout kernel with a throw-away pass of the same launches, then put the state back at tick W
+    keep = {k: env.state[k].clone() for k in abi_buffer_fields()}
+    for act, out in chunks:
+        env.rollout(act, out)
+    for k, v in keep.items():
+        env.state[k].copy_(v)
+    del keep
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
+    torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     env.timer_start()
     for act, out in chunks:
@@ -211,12 +240,24 @@ def fused_leg(env, init, scripts, W, K, T, world, dev, n_per_gpu, B, backend="nc
         tt = torch.tensor([wall, ev_ms], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall, ev_ms = float(tt[0]), float(tt[1])
-    achieved = n_per_gpu * K * B / (ev_ms / 1e3) / 1e9
-    return {"what": "cygym_rollout: open-loop, actions of all ticks pre-staged, state on chip between ticks, "
-                    "every tick's obs/reward written", "ticks_per_launch": T,
-            "value": n_per_gpu * world * K / wall, "unit": "env-steps/s", "ms_per_tick": wall / K * 1e3,
-            "roofline_frac": achieved / HBM_PEAK_GBS, "roofline_achieved_GBs": achieved,
+    n_launch = len(chunks)
+    return {"what": f"cygym_rollout: {T} ticks per launch (open loop, pre-staged action script; state on chip between "
+                    "ticks; every tick's obs / reward / done written to HBM)",
+            "value": n_per_gpu * world * K / wall, "unit": "env-steps/s", "ms_per_step": wall / K * 1e3,
+            "roofline": roofline_block(n_per_gpu * B * K / n_launch, (ev_ms / 1e3) / n_launch, "step_kernel<.., FUSED=1>", K / n_launch),
             "last_raw_reward_sum": float(chunks[-1][1]["raw"][-1].sum())}
+
+
+def abi_buffer_fields():
+    from cygym_amd import abi
+    return abi.BUFFER_FIELDS
+
+
+def roofline_block(bytes_per_launch, launch_s, kernel, ticks_per_launch):
+    achieved = bytes_per_launch / launch_s / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None, "kernel": kernel, "launch_us": launch_s * 1e6, "ticks_per_launch": ticks_per_launch,
+            "algorithmic_bytes_per_launch": bytes_per_launch}
 
 
 def measured_copy_gbs(dev, mib=1024, reps=8):
@@ -245,12 +286,15 @@ def cpu_baseline(topo, init, cfg, M, L, scripts, W, budget_s):
     independent, so each thread owns a contiguous env range -- the same sharding the GPU ranks use)."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import driver as od
-    per = min(1024, scripts[0]["mode"].shape[0])
+    n_all = scripts[0]["mode"].shape[0]
+    per = min(1024, n_all)
+    if n_all // per < 16:   # give every host core of the share a contiguous env range
+        per = max(64, n_all // 16)
     try:
         share = len(os.sched_getaffinity(0))
     except AttributeError:
         share = os.cpu_count() or 1
-    threads = max(1, min(share, 16, scripts[0]["mode"].shape[0] // per))
+    threads = max(1, min(share, 16, n_all // per))
 
     def leg(n_thr, seconds):
         n = per * n_thr
