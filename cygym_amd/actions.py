@@ -1,4 +1,4 @@
-"""numpy mirror of gen_actions_kernel (cygym_amd/csrc/cygym_hip.hip): the synthetic
+"""numpy mirror of gen_actions_kernel (cygym_amd/csrc/cg_aux_kernels.hpp): the synthetic
 action script of bench.py -- alternating defender / attacker
 turns, defender type uniform over {1,4,5,6,7,8,9,11,12,13,2} on k ~ U[1, M/8]
 distinct devices, attacker uniform over {1,2,3}, exploit uniform over X.

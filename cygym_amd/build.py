@@ -16,7 +16,9 @@ def needs_build() -> bool:
     if not os.path.exists(SO):
         return True
     t = os.path.getmtime(SO)
+    import glob
     deps = [SRC, os.path.join(INC, "cygym_abi.h"), os.path.join(INC, "cygym_spec.h")]
+    deps += glob.glob(os.path.join(os.path.dirname(SRC), "*.hpp"))   # the kernel sources included by SRC
     return any(os.path.getmtime(d) > t for d in deps)
 
 

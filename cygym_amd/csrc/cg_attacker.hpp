@@ -1,0 +1,353 @@
+// cg_attacker.hpp -- Attacker actions: spread fix point and probe (volt_typhoon_env.py:1126-1202).
+// Part of cygym_hip.hip (included inside its anonymous namespace, in order); not a standalone header.
+#ifndef CG_ATTACKER_HPP
+#define CG_ATTACKER_HPP
+
+// ---------------- attacker ----------------
+#define T_INF 0xFFFFFFFFu
+constexpr int LONG_ROW = 8;
+#define CG_D_FULLROW 0x04  // library-private static bit: the out-row is "every other device, ascending"
+
+// T[v] = (first-compromise time << 2) | eligibility bits (bit0 reachable, bit1 known & vulnerable to this
+// exploit): one LDS word answers "can source s take v".  atomicMin keeps the (constant) low bits intact.
+#define T_TIME_INF 0x3FFFFFFFu
+__device__ __forceinline__ bool spread_ok(const uint32_t* T, int v, int s) {
+  const uint32_t t = T[v];
+  return (t & 1u) || ((t & 2u) && ((t >> 2) >= (uint32_t)(s + 1)));
+}
+__device__ __forceinline__ void spread_take(uint32_t* T, int v, int s) {
+  atomicMin(&T[v], ((uint32_t)(s + 1) << 2) | (T[v] & 3u));
+}
+// first slot k in [from, o1) that source s can take, or o1
+__device__ __forceinline__ int spread_scan_lane(const Env& e, const uint32_t* T, int s, bool dc,
+                                                int from, int o1) {
+  for (int k = from; k < o1; ++k) {
+    if (e.blocked(k)) continue;
+    if (dc || spread_ok(T, e.ocol[k], s)) return k;
+  }
+  return o1;
+}
+// same for a FULL row (slot k <-> device v = k - o0 + (k - o0 >= s)): walk the candidate-device bitmask
+// instead of the row; `cand` holds reach | (known & vulnerable & not compromised at the start)
+__device__ __forceinline__ int spread_scan_full(const Env& e, const uint32_t* T, const uint64_t* cand,
+                                                int s, int from, int o0, int o1) {
+  if (from >= o1) return o1;
+  int v_from = from - o0; if (v_from >= s) ++v_from;
+  for (int w = v_from >> 6; w < e.MC; ++w) {
+    uint64_t m = cand[w];
+    if (w == (v_from >> 6)) m &= ~0ull << (v_from & 63);
+    while (m) {
+      int v = (w << 6) + __builtin_ctzll(m);
+      m &= m - 1;
+      if (v == s) continue;
+      int k = o0 + v - (v > s ? 1 : 0);
+      if (e.blocked(k)) continue;
+      if (spread_ok(T, v, s)) return k;
+    }
+  }
+  return o1;
+}
+__device__ __forceinline__ int spread_scan_coop(const Env& e, const uint32_t* T, int s, bool dc,
+                                                int from, int o1) {
+  for (int k0 = from; k0 < o1; k0 += WAVE) {
+    int k = k0 + e.lane;
+    bool p = false;
+    if (k < o1 && !e.blocked(k)) p = dc || spread_ok(T, e.ocol[k], s);
+    uint64_t m = ballot(p);
+    if (m) return k0 + __builtin_ctzll(m);
+  }
+  return o1;
+}
+
+// One fix-point round for the sources whose rows carry ADDED edges: per-lane walk of the merged row;
+// cur[s] = o0 + index in the merged row (o0 + merged length = nothing to take).  Kept out of the main
+// round loop so that its registers are not live there.
+__device__ __forceinline__ bool spread_x_round(const Env& e, uint32_t* T, uint16_t* cur, const uint16_t* slist, int n_src, int round) {
+  bool changed = false;
+#pragma nounroll
+  for (int b0 = 0; b0 < n_src; b0 += WAVE) {
+    const int i = b0 + e.lane;
+    if (i >= n_src) continue;
+    const int s = slist[i];
+    if (!x_isout(e, s)) continue;
+    const int o0 = e.optr[s], k0 = cur[s];
+    const bool dc = e.dst[s] & CG_D_DC;
+    XWalk w; w.init(e, s);
+    int m = 0, hit = -1, hv = 0;
+    const int m_from = k0 - o0;
+    while (!w.done()) {
+      const bool ex = w.at_extra(e);
+      const int v = ex ? (int)w.vx : (int)e.ocol[w.k];
+      const bool bl = ex ? x_blocked(e, w.j) : e.blocked(w.k);
+      if (m >= m_from && !bl && (dc || spread_ok(T, v, s))) { hit = m; hv = v; break; }
+      w.next(e, ex); ++m;
+    }
+    const int k = o0 + m;   // m == merged length when nothing can be taken
+    if (k != k0) { cur[s] = (uint16_t)k; changed = true; }
+    if (hit >= 0 && (round == 0 || k != k0)) spread_take(T, hv, s);
+  }
+  return changed;
+}
+// log entries of those sources (unblocked merged entries up to and including the pick) + DC attribution
+__device__ __forceinline__ int spread_x_counts(Env& e, const uint16_t* cur, const uint16_t* slist, uint16_t* cntv, int n_src, uint8_t ebit) {
+  int total = 0;
+#pragma nounroll
+  for (int b0 = 0; b0 < n_src; b0 += WAVE) {
+    const int i = b0 + e.lane;
+    int n = 0;
+    if (i < n_src && x_isout(e, slist[i])) {
+      const int s = slist[i];
+      XWalk w; w.init(e, s);
+      const int last = (int)cur[s] - (int)e.optr[s];
+      const bool dc = e.dst[s] & CG_D_DC;
+      for (int m = 0; !w.done() && m <= last; ++m) {
+        const bool ex = w.at_extra(e);
+        n += !(ex ? x_blocked(e, w.j) : e.blocked(w.k));
+        if (m == last && dc) byte_or(e.cby, ex ? (int)w.vx : (int)e.ocol[w.k], ebit);   // DC attribution :1163-1168
+        w.next(e, ex);
+      }
+      cntv[i] = (uint16_t)n;
+    }
+    total += wave_sum(n);
+  }
+  return total;
+}
+
+template <bool XE>
+__device__ __forceinline__ void attacker_spread(Env& e, const KParams& P, const int32_t* expl, int n_expl,
+                                                uint64_t* srcb) {
+  const int M = e.M, MC = e.MC, Mp = MC * WAVE;
+  uint32_t* T = e.scr;                          // [Mp] first-compromise time (source id + 1)
+  uint16_t* cur = (uint16_t*)(e.scr + Mp);      // [Mp] current pick (slot) per source DEVICE, row end = none
+  uint16_t* cntv = cur + Mp;                    // [Mp] log entries per COMPACT source index
+  uint16_t* slist = e.lsrc;                     // [Mp] the sources in id order (snapshot :1127)
+  uint64_t* cand = (uint64_t*)e.marks;          // [MC] candidate-device bitmask for full rows
+  int n_src = 0;
+#pragma unroll
+  for (int c = 0; c < MC; ++c) {   // the sources in id order (compact list)
+    const uint64_t sm = srcb[c];
+    if ((sm >> e.lane) & 1ull) slist[n_src + below(sm)] = (uint16_t)(c * WAVE + e.lane);
+    n_src += __popcll(sm);
+  }
+  wsync();
+  const bool xany = XE && x_cnt(e) > 0;   // this env has added edges: their sources walk merged rows
+  int zocc = 0;
+  for (int j = 0; j < n_expl; ++j) {
+    int raw = expl[j];
+    if (P.c.zero_day) {  // :1131-1146
+      uint32_t mask = (uint32_t)P.c.zero_day_owned_mask;
+      bool in = raw >= 0 && raw < 32 && ((mask >> raw) & 1u);
+      if (!in) {
+        int cnt = __popc(mask);
+        if (cnt == 0) continue;
+        int r = (int)cg_index(e.draw(CG_SITE_ZERODAY, zocc++, 0), (uint32_t)cnt);
+        raw = nth_bit32(mask, r);
+      }
+    }
+    if (raw < 0 || raw >= P.t.X) continue;
+    const uint8_t ebit = (uint8_t)(1u << raw);
+#pragma unroll
+    for (int c = 0; c < MC; ++c) {
+      int d = c * WAVE + e.lane;
+      uint8_t f = d < M ? e.flags[d] : 0;
+      uint8_t x = (uint8_t)(((f & CG_F_REACH) ? 1 : 0) | (((f & CG_F_KNOWN) && d < M && (e.vul[d] & ebit)) ? 2 : 0));
+      T[d] = (((f & CG_F_COMP) ? 0u : T_TIME_INF) << 2) | x;
+      cur[d] = d < M ? e.optr[d] : 0;
+      uint64_t cm = ballot((x & 1) || ((x & 2) && !(f & CG_F_COMP)));
+      if (e.lane == 0) cand[c] = cm;
+    }
+    wsync();
+    SUBSTAMP(10);
+    int n_rounds = 0;
+    // fix-point rounds: a source re-examines its pick and, if an earlier source took it, resumes the scan
+    for (int round = 0; round <= M + 1; ++round) {
+      ++n_rounds;
+      bool changed = round == 0;
+      for (int b0 = 0; b0 < n_src; b0 += WAVE) {
+        const int i = b0 + e.lane;
+        bool coop = false;
+        int s = 0, o0 = 0, o1 = 0, k0 = 0;
+        uint8_t st = 0;
+        if (i < n_src) {
+          s = slist[i];
+          o0 = e.optr[s]; o1 = e.optr[s + 1]; k0 = cur[s]; st = e.dst[s];
+          const bool dc = st & CG_D_DC;
+          int k = k0;
+          if (COLD(xany && x_isout(e, s))) {   // row with added edges: handled by spread_x_round below
+          } else if (o1 - o0 <= LONG_ROW) k = spread_scan_lane(e, T, s, dc, k0, o1);
+          else if ((st & CG_D_FULLROW) && !dc) {
+            if (!(k0 < o1 && !e.blocked(k0) && spread_ok(T, e.ocol[k0], s)))
+              k = spread_scan_full(e, T, cand, s, round == 0 ? k0 : k0 + 1, o0, o1);
+          } else {
+            coop = round == 0 || (k0 < o1 && !(dc || spread_ok(T, e.ocol[k0], s)));
+          }
+          if (!coop && !(xany && x_isout(e, s))) {
+            if (k != k0) { cur[s] = (uint16_t)k; changed = true; }
+            if (k < o1 && (round == 0 || k != k0)) spread_take(T, e.ocol[k], s);
+          }
+        }
+        uint64_t nm = ballot(coop);   // long rows that are not "full": wave-cooperative (re)scan
+        while (nm) {
+          const int src_lane = __builtin_ctzll(nm);
+          nm &= nm - 1;
+          const int ls = __shfl(s, src_lane), lo1 = __shfl(o1, src_lane), lk0 = __shfl(k0, src_lane);
+          const int lst = __shfl((int)st, src_lane);
+          int k = spread_scan_coop(e, T, ls, lst & CG_D_DC, round == 0 ? lk0 : lk0 + 1, lo1);
+          if (k != lk0) changed = true;
+          if (e.lane == 0) {
+            cur[ls] = (uint16_t)k;
+            if (k < lo1) spread_take(T, e.ocol[k], ls);
+          }
+        }
+      }
+      if constexpr (XE) { if (COLD(xany)) { if (spread_x_round(e, T, cur, slist, n_src, round)) changed = true; } }
+      wsync();
+      if (!__any(changed)) break;
+    }
+    SUBSTAMP(11);
+    SUBVAL(15, n_rounds);
+    // log entries of every source: unblocked out-entries up to and including its pick
+    int total_new = 0;
+    for (int b0 = 0; b0 < n_src; b0 += WAVE) {
+      const int i = b0 + e.lane;
+      int n = 0;
+      if (i < n_src) {
+        int s = slist[i];
+        int o0 = e.optr[s], o1 = e.optr[s + 1];
+        if (COLD(xany && x_isout(e, s))) {   // counted by spread_x_counts below
+        } else {
+          int end = cur[s] < o1 ? cur[s] + 1 : o1;
+          n = (end - o0) - range_popc(e.blk, o0, end);
+        }
+      }
+      cntv[i < Mp ? i : 0] = (uint16_t)n;
+      total_new += wave_sum(n);
+    }
+    wsync();
+    if constexpr (XE) { if (COLD(xany)) { total_new += spread_x_counts(e, cur, slist, cntv, n_src, ebit); wsync(); } }
+    SUBSTAMP(12);
+    // ring: only the last CG_LOG_RING entries (global order: source id, then row order) matter
+    if (total_new > 0) {
+      const uint32_t base = (uint32_t)e.log_total;
+      const uint32_t end = base + (uint32_t)total_new;
+      const uint32_t lo = end > CG_LOG_RING ? end - CG_LOG_RING : 0;
+      uint32_t after = end;   // global index just past the current block of sources
+      for (int b0 = ((n_src - 1) / WAVE) * WAVE; b0 >= 0 && after > lo; b0 -= WAVE) {
+        const int i = b0 + e.lane;
+        int n = i < n_src ? cntv[i] : 0;
+        int incl = wave_incl_scan(n, e.lane);
+        int blk_total = __shfl(incl, 63);
+        uint32_t cbase = after - (uint32_t)blk_total;
+        uint32_t off = cbase + (uint32_t)(incl - n);
+        bool mine = n > 0 && off + (uint32_t)n > lo;
+        int s = mine ? (int)slist[i] : 0;
+        const bool xs = mine && xany && x_isout(e, s);
+        bool is_long = mine && !xs && (e.optr[s + 1] - e.optr[s]) > LONG_ROW;
+        if (COLD(xs)) {
+          uint32_t idx = off;
+          XWalk w; w.init(e, s);
+          const int last = (int)cur[s] - (int)e.optr[s];
+          for (int m = 0; !w.done() && m <= last; ++m) {
+            const bool ex = w.at_extra(e);
+            const int v = ex ? (int)w.vx : (int)e.ocol[w.k];
+            if (!(ex ? x_blocked(e, w.j) : e.blocked(w.k))) {
+              if (idx >= lo) { e.ring[2 * (idx % CG_LOG_RING)] = (uint16_t)s; e.ring[2 * (idx % CG_LOG_RING) + 1] = (uint16_t)v; }
+              ++idx;
+            }
+            w.next(e, ex);
+          }
+        }
+        if (mine && !is_long && !xs) {
+          uint32_t idx = off;
+          int o1 = e.optr[s + 1];
+          int last = cur[s] < o1 ? (int)cur[s] : o1 - 1;
+          for (int k = e.optr[s]; k <= last; ++k) {
+            if (e.blocked(k)) continue;
+            if (idx >= lo) { e.ring[2 * (idx % CG_LOG_RING)] = (uint16_t)s; e.ring[2 * (idx % CG_LOG_RING) + 1] = e.ocol[k]; }
+            ++idx;
+          }
+        }
+        uint64_t lm = ballot(is_long);
+        while (lm) {
+          int ll = __builtin_ctzll(lm);
+          lm &= lm - 1;
+          int ls = __shfl(s, ll);
+          uint32_t idx0 = __shfl(off, ll);
+          int o0 = e.optr[ls], o1 = e.optr[ls + 1];
+          int last = cur[ls] < o1 ? (int)cur[ls] : o1 - 1;
+          for (int k0 = o0; k0 <= last; k0 += WAVE) {
+            int k = k0 + e.lane;
+            bool p = k <= last && !e.blocked(k);
+            uint64_t m = ballot(p);
+            uint32_t idx = idx0 + (uint32_t)below(m);
+            if (p && idx >= lo) { e.ring[2 * (idx % CG_LOG_RING)] = (uint16_t)ls; e.ring[2 * (idx % CG_LOG_RING) + 1] = e.ocol[k]; }
+            idx0 += (uint32_t)__popcll(m);
+          }
+        }
+        after = cbase;
+      }
+      e.log_total = (int)end;
+      e.ring_dirty = true;
+    }
+    wsync();
+    SUBSTAMP(13);
+    // apply: compromise flags + DC attribution (:1163-1185)
+    for (int d = e.lane; d < M; d += WAVE)
+      if ((T[d] >> 2) != T_TIME_INF && (T[d] >> 2) != 0u) e.flags[d] |= CG_F_COMP;
+    for (int i = e.lane; i < n_src; i += WAVE) {
+      int s = slist[i];
+      if (!(e.dst[s] & CG_D_DC)) continue;
+      if (COLD(xany && x_isout(e, s))) continue;   // attributed while its log entries were counted
+      if (cur[s] < e.optr[s + 1]) byte_or(e.cby, e.ocol[cur[s]], ebit);
+    }
+    wsync();
+    SUBSTAMP(14);
+  }
+}
+
+template <bool XE>
+__device__ __forceinline__ void attacker_probe(Env& e, const uint64_t* srcb, double& cost) {
+  int n_src = 0;
+  for (int c = 0; c < e.MC; ++c) n_src += __popcll(srcb[c]);
+  if (n_src == 0) return;
+  int r = (int)cg_index(e.draw(CG_SITE_PROBE_SRC, 0, 0), (uint32_t)n_src);
+  int s = -1;
+  for (int c = 0; c < e.MC; ++c) {
+    int k = __popcll(srcb[c]);
+    if (r < k) { s = c * WAVE + nth_bit(srcb[c], r); break; }
+    r -= k;
+  }
+  if (COLD(XE && x_cnt(e) > 0 && x_isout(e, s))) {   // row with added edges: uniform walk of the merged row
+    XWalk w; w.init(e, s);
+    int v = -1;
+    while (!w.done()) {
+      const bool ex = w.at_extra(e);
+      const int vv = ex ? (int)w.vx : (int)e.ocol[w.k];
+      if (!(ex ? x_blocked(e, w.j) : e.blocked(w.k)) && !(e.flags[vv] & CG_F_KNOWN)) { v = vv; break; }
+      w.next(e, ex);
+    }
+    wsync();
+    if (v >= 0) {
+      if (e.lane == 0) e.flags[v] |= CG_F_KNOWN;
+      cost += 0.1;
+    }
+    wsync();
+    return;
+  }
+  const int o0 = e.optr[s], o1 = e.optr[s + 1];
+  for (int k0 = o0; k0 < o1; k0 += WAVE) {
+    int k = k0 + e.lane;
+    bool p = k < o1 && !e.blocked(k) && !(e.flags[e.ocol[k]] & CG_F_KNOWN);
+    uint64_t m = ballot(p);
+    if (m) {
+      int v = e.ocol[k0 + __builtin_ctzll(m)];
+      wsync();
+      if (e.lane == 0) e.flags[v] |= CG_F_KNOWN;
+      cost += 0.1;   // :1199 (not scaled)
+      break;
+    }
+  }
+  wsync();
+}
+
+#endif  // CG_ATTACKER_HPP

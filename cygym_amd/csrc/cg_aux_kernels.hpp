@@ -1,0 +1,172 @@
+// cg_aux_kernels.hpp -- reset / randomize / derive / observe kernels and the synthetic action script of bench.py.
+// Part of cygym_hip.hip (included inside its anonymous namespace, in order); not a standalone header.
+#ifndef CG_AUX_KERNELS_HPP
+#define CG_AUX_KERNELS_HPP
+
+// ---------------- reset / randomize / observe / action script ----------------
+__global__ void reset_kernel(KParams P, const int32_t* env_ids, int n) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= n) return;
+  const int env = env_ids ? env_ids[wave] : wave;
+  if (env < 0 || env >= P.n_envs) return;
+  const int M = P.t.M;
+  const int si = P.snap.n_envs == 1 ? 0 : env;
+  const size_t so = (size_t)env * 4 * M, ss = (size_t)si * 4 * M;
+  int32_t tick = P.b.ienv[(size_t)env * CG_I_COUNT + CG_I_RNG_TICK];
+  for (int i = lane; i < 4 * M; i += WAVE) {
+    P.b.live[so + i] = P.snap.live[ss + i];
+    P.b.stash[so + i] = P.snap.stash[ss + i];
+  }
+  for (int w = lane; w < P.t.EW; w += WAVE) {
+    P.b.blocked[(size_t)env * P.t.EW + w] = P.snap.blocked[(size_t)si * P.t.EW + w];
+    P.b.blocked_in[(size_t)env * P.t.EW + w] = P.snap.blocked_in[(size_t)si * P.t.EW + w];
+  }
+  if (lane < CG_LOG_RING)
+    ((uint32_t*)(P.b.ring + (size_t)env * CG_LOG_RING * 2))[lane] = ((const uint32_t*)(P.snap.ring + (size_t)si * CG_LOG_RING * 2))[lane];
+  const int XW = P.t.K + P.t.KW;
+  if (P.t.K > 0 && P.snap.extra)
+    for (int w = lane; w < XW; w += WAVE) P.b.extra[(size_t)env * XW + w] = P.snap.extra[(size_t)si * XW + w];
+  if (lane < CG_I_COUNT) {
+    int32_t v = P.snap.ienv[(size_t)si * CG_I_COUNT + lane];
+    if (lane == CG_I_RNG_TICK) v = tick;   // the draw counter is monotone across episodes
+    if (lane == CG_I_FLAGS && !(P.t.K > 0 && P.snap.extra)) v &= 0xFFFF;   // no extra-edge list to restore
+    P.b.ienv[(size_t)env * CG_I_COUNT + lane] = v;
+  }
+  if (lane < CG_D_COUNT) P.b.fenv[(size_t)env * CG_D_COUNT + lane] = P.snap.fenv[(size_t)si * CG_D_COUNT + lane];
+}
+
+// randomize_compromise_and_ownership volt_typhoon_env.py:330-383; wave per env, global memory only.
+__global__ void randomize_kernel(KParams P, const int32_t* env_ids, int n, uint32_t* keybuf) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= n) return;
+  const int env = env_ids ? env_ids[wave] : wave;
+  if (env < 0 || env >= P.n_envs) return;
+  const int M = P.t.M, MC = P.t.MC;
+  uint8_t* flags = P.b.live + (size_t)env * 4 * M;
+  int32_t* ie = P.b.ienv + (size_t)env * CG_I_COUNT;
+  const uint32_t tick = (uint32_t)ie[CG_I_RNG_TICK];
+  const uint32_t env_id = (uint32_t)(P.c.env_id_base + env);
+  uint32_t* key = keybuf + (size_t)wave * MC * WAVE;
+  int cnt = 0, k_owned = 0, k_comp = 0;
+  for (int c = 0; c < MC; ++c) {
+    int d = c * WAVE + lane;
+    bool el = d < M && !(flags[d] & CG_F_NYA) && !(P.t.dstatic[d] & CG_D_DC);
+    if (d < MC * WAVE) key[d] = el ? cg_draw(P.c.seed, env_id, tick, CG_SITE_SHUFFLE, d, 0) : 0u;
+    cnt += __popcll(ballot(el));
+    k_owned += __popcll(ballot(el && (flags[d] & CG_F_OWNED)));
+    k_comp += __popcll(ballot(el && (flags[d] & CG_F_COMP)));
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  if (lane == 0) ie[CG_I_RNG_TICK] = (int32_t)(tick + 1);
+  if (lane == 0) ie[CG_I_FLAGS] &= ~CG_E_STAR_OK;
+  if (cnt == 0 || (k_owned == 0 && k_comp == 0)) return;
+  int extra = k_comp - k_owned; if (extra < 0) extra = 0;
+  for (int c = 0; c < MC; ++c) {
+    int d = c * WAVE + lane;
+    bool el = d < M && !(flags[d] & CG_F_NYA) && !(P.t.dstatic[d] & CG_D_DC);
+    if (!el) continue;
+    uint32_t kd = key[d];
+    int rank = 0;
+    for (int o = 0; o < M; ++o) {
+      bool eo = !(flags[o] & CG_F_NYA) && !(P.t.dstatic[o] & CG_D_DC);
+      uint32_t ko = key[o];
+      rank += (eo && (ko < kd || (ko == kd && o < d))) ? 1 : 0;
+    }
+    uint8_t f = (uint8_t)(flags[d] & ~(CG_F_OWNED | CG_F_COMP | CG_F_KNOWN));
+    if (rank < k_owned) f |= (CG_F_OWNED | CG_F_COMP | CG_F_KNOWN);
+    else if (rank < k_owned + extra) f |= (CG_F_COMP | CG_F_KNOWN);
+    // flags are rewritten after every lane has read the eligibility bits (NYA/DC do not change)
+    flags[d] = f;
+  }
+}
+
+// blocked_in[j] = blocked[in_eid[j]]: the derived in-order mirror of the blocked bits (wave per env)
+__global__ void derive_kernel(KParams P, cygym_buffers bufs) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= bufs.n_envs) return;
+  const uint32_t* blk = bufs.blocked + (size_t)wave * P.t.EW;
+  uint32_t* bin = bufs.blocked_in + (size_t)wave * P.t.EW;
+  for (int j0 = 0; j0 < P.t.EW * 32; j0 += WAVE) {
+    const int j = j0 + lane;
+    bool bit = false;
+    if (j < P.t.E) { const int k = P.t.in_eid[j]; bit = (blk[k >> 5] >> (k & 31)) & 1u; }
+    const uint64_t m = __ballot(bit);
+    if (lane == 0) {
+      bin[j0 >> 5] = (uint32_t)m;
+      if ((j0 >> 5) + 1 < P.t.EW) bin[(j0 >> 5) + 1] = (uint32_t)(m >> 32);
+    }
+  }
+}
+
+// role views: CyberDefenseEnv.py:146-257
+__global__ void observe_kernel(KParams P, int role, float* out) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= P.n_envs) return;
+  const int env = wave, M = P.t.M;
+  const uint8_t* flags = P.b.live + (size_t)env * 4 * M;
+  if (role == 0 || role == 1) {
+    float* o = out + (size_t)env * 6 * M;
+    for (int i = lane; i < 6 * M; i += WAVE) {
+      int d = i / 6, col = i - d * 6;
+      uint8_t f = flags[d];
+      float x = col == 0 ? P.t.os_val[d] : col == 1 ? P.t.version[d] : col == 2 ? ((f & CG_F_COMP) ? 1.f : 0.f)
+              : col == 3 ? P.t.anomaly[d] : col == 4 ? ((f & CG_F_KNOWN) ? 1.f : 0.f) : ((f & CG_F_NYA) ? 1.f : 0.f);
+      if (role == 1 && ((f & CG_F_NYA) || !(f & CG_F_OWNED) || col == 2)) x = -1.f;
+      o[i] = x;
+    }
+  } else {
+    const int W = 4 * M + P.c.max_exploits;
+    float* o = out + (size_t)env * W;
+    for (int i = lane; i < W; i += WAVE) {
+      float x;
+      if (i < 4 * M) {
+        int d = i >> 2, col = i & 3;
+        uint8_t f = flags[d];
+        bool vis = (f & CG_F_KNOWN) && !(f & CG_F_NYA) && (f & CG_F_OWNED);
+        x = !vis ? -1.f : col == 0 ? P.t.os_val[d] : col == 1 ? P.t.version[d]
+          : col == 2 ? ((f & CG_F_COMP) ? 1.f : 0.f) : ((f & CG_F_KNOWN) ? 1.f : 0.f);
+      } else {
+        x = (i - 4 * M) < P.t.X ? 1.f : 0.f;
+      }
+      o[i] = x;
+    }
+  }
+}
+
+// Synthetic action script of bench.py: alternating defender / attacker turns.
+// Mirrored in numpy by cygym_amd/actions.py (tests check equality).
+__global__ void gen_actions_kernel(KParams P, int tick, int32_t* mode, int32_t* n_groups, int32_t* atype,
+                                   int32_t* n_exploit, int32_t* exploit, int32_t* app, int32_t* dev_cnt,
+                                   int16_t* dev_idx, int max_devs) {
+  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= P.n_envs) return;
+  const int M = P.t.M;
+  const uint32_t env_id = (uint32_t)(P.c.env_id_base + env);
+  cg_u32x4 r = cg_philox4x32_10(env_id, (uint32_t)tick, CG_SITE_ACTGEN, 0u, (uint32_t)P.c.seed, (uint32_t)(P.c.seed >> 32));
+  const int m = tick & 1;
+  mode[env] = m;
+  n_groups[env] = 0;
+  n_exploit[env] = 1;
+  for (int j = 0; j < CG_MAX_EXPLOITS; ++j) exploit[(size_t)env * CG_MAX_EXPLOITS + j] = -1;
+  exploit[(size_t)env * CG_MAX_EXPLOITS] = (int)cg_index(r.v[1], (uint32_t)(P.t.X > 0 ? P.t.X : 1));
+  app[env] = (int)cg_index(r.v[2], 4u);
+  int k = 0;
+  if (m == CG_MODE_DEFENDER) {
+    const int types[11] = {1, 4, 5, 6, 7, 8, 9, 11, 12, 13, 2};
+    atype[env] = types[cg_index(r.v[0], 11u)];
+    int kmax = M / 8 > 1 ? M / 8 : 1;
+    if (kmax > max_devs) kmax = max_devs;
+    k = 1 + (int)cg_index(r.v[3], (uint32_t)kmax);
+    cg_u32x4 q = cg_philox4x32_10(env_id, (uint32_t)tick, CG_SITE_ACTGEN, 1u, (uint32_t)P.c.seed, (uint32_t)(P.c.seed >> 32));
+    int a = (int)cg_index(q.v[0], (uint32_t)M);
+    int stride = ((M & (M - 1)) == 0 && M > 1) ? (int)(2u * cg_index(q.v[1], (uint32_t)(M / 2)) + 1u) : 1;
+    for (int j = 0; j < k; ++j) dev_idx[(size_t)env * max_devs + j] = (int16_t)((a + (long long)j * stride) % M);
+  } else {
+    atype[env] = 1 + (int)cg_index(r.v[0], 3u);
+  }
+  dev_cnt[env] = k;
+}
+
+#endif  // CG_AUX_KERNELS_HPP

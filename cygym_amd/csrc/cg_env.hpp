@@ -1,0 +1,121 @@
+// cg_env.hpp -- Per-wave view of one environment in LDS and the list / bit-range helpers shared by the actions.
+// Part of cygym_hip.hip (included inside its anonymous namespace, in order); not a standalone header.
+#ifndef CG_ENV_HPP
+#define CG_ENV_HPP
+
+// ---------------- per-wave environment view ----------------
+struct Env {
+  // LDS, planes at stride MS = round_up(M, 4); padding bytes of `flags` hold CG_F_NYA
+  uint8_t *flags, *busy, *wl, *cby;
+  uint32_t* scr;     // [2*Mp] scratch (8 bytes per device)
+  uint32_t* blk;     // [EWp] blocked bit per out-slot
+  uint32_t* bin;     // [EWp] the same bits in in-CSR entry order
+  uint16_t* ring;    // [2*CG_LOG_RING]
+  uint32_t* marks;   // [Mp/32 + 2]
+  uint16_t* lsrc;    // [Mp] long-row sources of the spread
+  int16_t* devl;     // [L] this tick's device lists (all groups, concatenated)
+  // edges added by evolve_network (cygym_spec.h: extra-edge list), staged only when the env has any
+  uint32_t* xk;      // [K] keys (u << 16 | v), ascending; the first x_cnt() are live
+  uint32_t* xb;      // [KW] blocked bit per list entry
+  uint64_t* xmo;     // [MC] devices with an added OUT edge (their rows are walked merged)
+  uint64_t* xmi;     // [MC] devices with an added edge at either end
+  int K;
+  bool x_dirty;
+  // shared LDS (topology)
+  const uint16_t *optr, *ocol;
+  const uint8_t *dst, *vul, *nap;
+  const float *osv, *ver, *ano;
+  // in-CSR + slot<->entry maps: global memory (L2-resident blob); read by block/unblock and evolve only
+  const uint16_t *iptr_g, *icol_g, *ieid_g, *oeid_g;
+  uint8_t* stash;    // global [4][M] of this env
+  // misc
+  int M, MC, MS, lane, env;
+  int cbits;         // bits needed for a per-lane device count
+  uint32_t env_id, tick;
+  uint64_t seed;
+  int eflags;        // CG_I_FLAGS (uniform except BUSY_SAT, OR-reduced at write-back)
+  bool blk_dirty, ring_dirty;
+  bool multi;        // topology has duplicate (u,v) out-entries
+  int log_total;
+
+  __device__ __forceinline__ uint32_t draw(uint32_t site, uint32_t a, uint32_t b) const {
+    return cg_draw(seed, env_id, tick, site, a, b);
+  }
+  __device__ __forceinline__ bool blocked(int slot) const { return (blk[slot >> 5] >> (slot & 31)) & 1u; }
+  __device__ __forceinline__ int iptr(int d) const { return iptr_g[d]; }
+  __device__ __forceinline__ void set_busy(int d, int v) {
+    if (v > 255) { v = 255; eflags |= CG_E_BUSY_SAT; }
+    busy[d] = (uint8_t)v;
+  }
+};
+
+__device__ __forceinline__ void byte_or(uint8_t* base, int d, uint32_t bits) {
+  atomicOr((unsigned int*)(base + (d & ~3)), bits << ((d & 3) * 8));
+}
+
+// number of set bits of blk in slot range [a, b)  (uniform; broadcast LDS reads)
+__device__ __forceinline__ int range_popc(const uint32_t* blk, int a, int b) {
+  if (a >= b) return 0;
+  const int w0 = a >> 5, w1 = (b - 1) >> 5;
+  int n = 0;
+  for (int w = w0; w <= w1; ++w) {
+    uint32_t x = blk[w];
+    if (w == w0) x &= 0xFFFFFFFFu << (a & 31);
+    if (w == w1 && ((b & 31) != 0)) x &= 0xFFFFFFFFu >> (32 - (b & 31));
+    n += __popc(x);
+  }
+  return n;
+}
+// slot of the r-th entry in [a, b) whose blocked bit == want (uniform); r must be in range
+__device__ __forceinline__ int range_select(const uint32_t* blk, int a, int b, bool want, int r) {
+  const int w0 = a >> 5, w1 = (b - 1) >> 5;
+  for (int w = w0; w <= w1; ++w) {
+    uint32_t x = want ? blk[w] : ~blk[w];
+    if (w == w0) x &= 0xFFFFFFFFu << (a & 31);
+    if (w == w1 && ((b & 31) != 0)) x &= 0xFFFFFFFFu >> (32 - (b & 31));
+    int c = __popc(x);
+    if (r < c) return (w << 5) + nth_bit32(x, r);
+    r -= c;
+  }
+  return -1;
+}
+
+// multiplicity of every device in a list -> bytes in scr (as uint8 [Mp]); ids >= M ignored.
+__device__ __forceinline__ void list_counts(Env& e, const int16_t* dev, int L) {
+  uint32_t* w = e.scr;
+  for (int i = e.lane; i < (e.MC * WAVE) / 4; i += WAVE) w[i] = 0;
+  wsync();
+  for (int p = e.lane; p < L; p += WAVE) {
+    int d = dev[p];
+    if (d >= 0 && d < e.M) atomicAdd(&w[d >> 2], 1u << ((d & 3) * 8));
+  }
+  wsync();
+}
+
+// true when the list fits one wave pass and holds no device twice (uniform)
+__device__ __forceinline__ bool list_is_simple(Env& e, const int16_t* dev, int L) {
+  if (L > WAVE) return false;
+  uint8_t* own = (uint8_t*)e.scr;
+  int d = -1;
+  if (e.lane < L) { d = dev[e.lane]; if (d < 0 || d >= e.M) d = -1; }
+  if (d >= 0) own[d] = (uint8_t)e.lane;
+  wsync();
+  bool clash = d >= 0 && own[d] != (uint8_t)e.lane;
+  bool r = !__any(clash);
+  wsync();
+  return r;
+}
+
+// busy += 1 on every busy device (actions 2 / 10), saturating at 255
+__device__ __forceinline__ void bump_busy(Env& e) {
+  uint32_t* B = (uint32_t*)e.busy;
+  for (int w = e.lane; w < (e.MS >> 2); w += WAVE) {
+    uint32_t b = B[w];
+    uint32_t full = ~nz01(~b) & ONES;          // bytes equal to 255
+    uint32_t inc = nz01(b) & ~full;
+    if (nz01(b) & full) e.eflags |= CG_E_BUSY_SAT;
+    B[w] = b + inc;
+  }
+}
+
+#endif  // CG_ENV_HPP

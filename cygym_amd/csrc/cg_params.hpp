@@ -1,0 +1,54 @@
+// cg_params.hpp -- Device-side parameter blocks (topology blob layout, kernel parameters) and the diagnostic stamp macros.
+// Part of cygym_hip.hip (included inside its anonymous namespace, in order); not a standalone header.
+#ifndef CG_PARAMS_HPP
+#define CG_PARAMS_HPP
+
+
+constexpr int WAVE = 64;
+
+// The shared topology lives in ONE packed device blob whose layout is also the layout of the
+// workgroup-shared LDS section (copied with 16-byte loads): byte offsets o_* into the blob.
+//   [optr u16 M+1][ocol u16 E][os f32 M][ver f32 M][ano f32 M][dst u8 M][vul u8 M][nap u8 M] | [iptr u16 M+1][icol u16 E][ieid u16 E][oeid u16 E]
+//   (ieid: out-slot of an in-entry; oeid: in-entry of an out-slot)
+// The first `lds_bytes` bytes are staged in LDS: everything when it fits (in_lds), else all but the in-CSR.
+struct DevTopo {
+  int M, X, E, EW, MC, Mp;
+  const uint8_t* blob;
+  int o_optr, o_ocol, o_os, o_ver, o_ano, o_dst, o_vul, o_nap, o_iptr, o_icol, o_ieid, o_oeid;
+  int blob_bytes, lds_bytes, in_lds, multi;
+  int K, KW, x_bytes;   // extra-edge list: capacity, blocked-bit words, bytes of its per-wave LDS section
+  // global views (host-side convenience; kernels outside the tick use them)
+  const uint8_t *dstatic, *vuln, *napps;
+  const float *os_val, *version, *anomaly;
+  const uint16_t *out_ptr, *out_col;   // u16: E <= 65535, M <= 2048
+  const uint16_t *in_ptr, *in_col, *in_eid;
+};
+
+struct KParams {
+  const KParams* self;  // device copy of this struct (fused kernel re-reads it every tick instead of pinning SGPRs)
+  DevTopo t;
+  cygym_config c;
+  cygym_buffers b;
+  cygym_buffers snap;   // snap.flags == nullptr when absent
+  cygym_actions a;
+  cygym_outputs o;
+  int n_envs;
+  int n_ticks;          // ticks per launch (cygym_rollout); actions / outputs are [n_ticks][N] arrays
+  int wave_lds;         // bytes of LDS per wave
+  int shared_lds;       // bytes of the workgroup-shared LDS section
+  unsigned long long* dbg;   // diagnostic builds (-DCG_STAMPS): [N][16] s_memtime stamps per env
+};
+
+#ifdef CG_STAMPS
+#define SUBSTAMP(k) do { if (P.dbg && e.lane == 0) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); P.dbg[(size_t)e.env * 16 + (k)] = _t; } } while (0)
+#define SUBVAL(k, v) do { if (P.dbg && e.lane == 0) P.dbg[(size_t)e.env * 16 + (k)] = (unsigned long long)(v); } while (0)
+#define STAMP(k) do { if (P.dbg && lane == 0) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); P.dbg[(size_t)env * 16 + (k)] = _t; } } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#define SUBSTAMP(k) do {} while (0)
+#define SUBVAL(k, v) do {} while (0)
+#endif
+
+#define COLD(c) __builtin_expect(!!(c), 0)   // rarely-taken extra-edge paths: keep them out of the hot layout
+
+#endif  // CG_PARAMS_HPP

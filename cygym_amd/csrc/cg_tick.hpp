@@ -1,0 +1,456 @@
+// cg_tick.hpp -- The tick kernel: step_kernel<WPB, MT, FUSED, XE> (volt_typhoon_env.py:818-1333, 612-779).
+// Part of cygym_hip.hip (included inside its anonymous namespace, in order); not a standalone header.
+#ifndef CG_TICK_HPP
+#define CG_TICK_HPP
+
+// ---------------- the tick ----------------
+// MT: devices per env when known at compile time (64, 256: chunk loops unroll and their LDS latencies
+// overlap), 0 = any M at run time.
+// Per-wave LDS carve + pointer table of one env (must match wave_lds_bytes on the host).
+struct WaveAux { uint64_t* srcb; int32_t* park; };
+__device__ __forceinline__ WaveAux env_setup(Env& e, uint8_t* smem, const KParams& P, int M, int MC, int Mp, int MS,
+                                             int wave, int lane, int env) {
+  uint8_t* wb = smem + P.shared_lds + (size_t)wave * P.wave_lds;
+  e.flags = wb; e.busy = wb + MS; e.wl = wb + 2 * MS; e.cby = wb + 3 * MS;
+  e.scr = (uint32_t*)(wb + ((4 * MS + 15) & ~15));
+  e.blk = e.scr + 2 * Mp;
+  e.bin = e.blk + ((P.t.EW + 3) & ~3);
+  e.ring = (uint16_t*)(e.bin + ((P.t.EW + 3) & ~3));
+  e.marks = (uint32_t*)(e.ring + 2 * CG_LOG_RING);
+  WaveAux x;
+  x.srcb = (uint64_t*)(e.marks + ((Mp / 32 + 2) & ~1));
+  e.lsrc = (uint16_t*)(x.srcb + MC);
+  e.devl = (int16_t*)(e.lsrc + Mp);
+  x.park = (int32_t*)(wb + P.wave_lds - 128);   // [16 i32 + 3 f64] per-env scalars between fused ticks
+  e.xk = (uint32_t*)(wb + P.wave_lds - 128 - P.t.x_bytes);
+  e.xb = e.xk + P.t.K;
+  e.xmo = (uint64_t*)(e.xb + ((P.t.KW + 1) & ~1));
+  e.xmi = e.xmo + MC;
+  e.K = P.t.K;
+  e.optr = (const uint16_t*)(smem + P.t.o_optr); e.ocol = (const uint16_t*)(smem + P.t.o_ocol);
+  e.osv = (const float*)(smem + P.t.o_os); e.ver = (const float*)(smem + P.t.o_ver); e.ano = (const float*)(smem + P.t.o_ano);
+  e.dst = smem + P.t.o_dst; e.vul = smem + P.t.o_vul; e.nap = smem + P.t.o_nap;
+  e.iptr_g = (const uint16_t*)(P.t.blob + P.t.o_iptr); e.icol_g = (const uint16_t*)(P.t.blob + P.t.o_icol);
+  e.ieid_g = (const uint16_t*)(P.t.blob + P.t.o_ieid); e.oeid_g = (const uint16_t*)(P.t.blob + P.t.o_oeid);
+  e.M = M; e.MC = MC; e.MS = MS; e.lane = lane; e.env = env;
+  e.cbits = 32 - __builtin_clz((unsigned)(4 * ((MS / 4 + WAVE - 1) / WAVE)));
+  e.env_id = (uint32_t)(P.c.env_id_base + env);
+  e.seed = P.c.seed;
+  e.multi = P.t.multi != 0;
+  e.stash = P.b.stash + (size_t)env * 4 * M;
+  return x;
+}
+
+// FUSED: cygym_rollout (n_ticks > 1).  The per-env scalars are parked in LDS between ticks so that they are
+// not loop-carried registers; the single-tick instantiation has a compile-time trip count of 1.
+template <int WPB, int MT, bool FUSED, bool XE>
+__global__ __launch_bounds__(WPB * WAVE, FUSED ? 4 : (XE ? CG_LB : 1)) void step_kernel(const KParams P0) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  // every use below goes through `P`: the kernarg copy for the single-tick kernel, the device copy for the
+  // fused one (so that it can be re-read, opaquely, at the top of every tick)
+  const KParams* pk;
+  if constexpr (FUSED) pk = P0.self; else pk = &P0;
+#define P (*pk)
+  const int M = MT ? MT : P.t.M, MC = MT ? (MT + WAVE - 1) / WAVE : P.t.MC, Mp = MC * WAVE, MS = (M + 3) & ~3;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int env = uni(blockIdx.x * WPB + wave);
+  const bool live = env < P.n_envs;
+  const int G = P.a.max_groups, L = P.a.max_devs;
+
+  Env e;
+  WaveAux aux = env_setup(e, smem, P, M, MC, Mp, MS, wave, lane, live ? env : 0);
+  uint64_t* srcb = aux.srcb;
+  int32_t* park = aux.park;
+  e.env = env;
+  e.blk_dirty = e.ring_dirty = e.x_dirty = false;
+
+  STAMP(0);
+  // ---- issue every global load of this tick up front (one memory latency, not a chain) ----
+  const size_t so = (size_t)(live ? env : 0) * 4 * M;
+  const uint8_t* g_live = P.b.live + so;
+  int32_t ie[CG_I_COUNT];
+  double fe[CG_D_COUNT];
+  int mode = 0, ng = 0, at0 = 8, cnt0 = 0, nexp0 = 0, app0 = -1;
+  uint4 r0 = make_uint4(0, 0, 0, 0);
+  uint32_t ringw = 0;
+  constexpr int PF_BLK = 2, PF_DEV = 1;   // words / list entries per lane prefetched into registers
+  uint32_t bw[PF_BLK], bwi[PF_BLK];
+  int16_t dv[PF_DEV];
+  const bool vec = (M & 3) == 0;
+  const int items = M >> 2;   // uint4 items of the [4][M] live block when M % 4 == 0
+  if (live) {
+    const int32_t* g = P.b.ienv + (size_t)env * CG_I_COUNT;
+#pragma unroll
+    for (int i = 0; i < CG_I_COUNT; ++i) ie[i] = g[i];
+    const double* gf = P.b.fenv + (size_t)env * CG_D_COUNT;
+#pragma unroll
+    for (int i = 0; i < CG_D_COUNT; ++i) fe[i] = gf[i];
+    mode = P.a.mode[env];
+    ng = P.a.n_groups[env];
+    at0 = P.a.atype[(size_t)env * G];
+    cnt0 = P.a.dev_cnt[(size_t)env * G];
+    nexp0 = P.a.n_exploit[(size_t)env * G];
+    app0 = P.a.app[(size_t)env * G];
+    if (vec && lane < items) r0 = ((const uint4*)g_live)[lane];
+    if (lane < CG_LOG_RING) ringw = ((const uint32_t*)(P.b.ring + (size_t)env * CG_LOG_RING * 2))[lane];
+#pragma unroll
+    for (int j = 0; j < PF_BLK; ++j) {
+      int w = lane + j * WAVE;
+      bw[j] = w < P.t.EW ? P.b.blocked[(size_t)env * P.t.EW + w] : 0u;
+      bwi[j] = w < P.t.EW ? P.b.blocked_in[(size_t)env * P.t.EW + w] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < PF_DEV; ++j) { int q = lane + j * WAVE; dv[j] = q < L ? P.a.dev_idx[(size_t)env * L + q] : (int16_t)0; }
+  }
+  // ---- workgroup-shared topology blob -> LDS: every 16-byte load is issued before the first store ----
+  {
+    const uint4* src = (const uint4*)P.t.blob;
+    uint4* dstp = (uint4*)smem;
+    const int n16 = P.t.lds_bytes >> 4, stride = WPB * WAVE;
+    constexpr int PF_BLOB = 4;
+    uint4 br[PF_BLOB];
+#pragma unroll
+    for (int j = 0; j < PF_BLOB; ++j) { const int i = threadIdx.x + j * stride; br[j] = src[i < n16 ? i : n16 - 1]; }   // unconditional: stays in registers
+#pragma unroll
+    for (int j = 0; j < PF_BLOB; ++j) { const int i = threadIdx.x + j * stride; if (i < n16) dstp[i] = br[j]; }
+    for (int i = threadIdx.x + PF_BLOB * stride; i < n16; i += stride) dstp[i] = src[i];
+  }
+  if (live) {
+    if (vec) {
+      if (lane < items) ((uint4*)e.flags)[lane] = r0;
+      for (int i = lane + WAVE; i < items; i += WAVE) ((uint4*)e.flags)[i] = ((const uint4*)g_live)[i];
+    } else {
+      for (int pl = 0; pl < 4; ++pl)
+        for (int i = lane; i < MS; i += WAVE) e.flags[pl * MS + i] = i < M ? g_live[pl * M + i] : (pl == 0 ? (uint8_t)CG_F_NYA : (uint8_t)0);
+    }
+    if (lane < CG_LOG_RING) ((uint32_t*)e.ring)[lane] = ringw;
+    const uint32_t* gb = P.b.blocked + (size_t)env * P.t.EW;
+#pragma unroll
+    for (int j = 0; j < PF_BLK; ++j) { int w = lane + j * WAVE; if (w < P.t.EW) { e.blk[w] = bw[j]; e.bin[w] = bwi[j]; } }
+    for (int w = lane + PF_BLK * WAVE; w < P.t.EW; w += WAVE) { e.blk[w] = gb[w]; e.bin[w] = P.b.blocked_in[(size_t)env * P.t.EW + w]; }
+    const int16_t* gd = P.a.dev_idx + (size_t)env * L;
+#pragma unroll
+    for (int j = 0; j < PF_DEV; ++j) { int q = lane + j * WAVE; if (q < L) e.devl[q] = dv[j]; }
+    for (int q = lane + PF_DEV * WAVE; q < L; q += WAVE) e.devl[q] = gd[q];
+  }
+  __syncthreads();   // the only workgroup barrier: waves diverge per env from here on
+  if (!live) return;
+  STAMP(1);
+
+  const int NW = MS >> 2;
+
+  // ---- ticks of this launch: 1 for cygym_step, T for cygym_rollout (state stays in LDS / registers;
+  // no cross-env synchronisation between ticks) ----
+  const int n_ticks = FUSED ? P.n_ticks : 1;
+  for (int tk = 0; tk < n_ticks; ++tk) {
+  const size_t te = (size_t)tk * P.n_envs + env;   // row of this (tick, env) in the action / output arrays
+  if (FUSED && tk > 0) {   // tick 0's header and list were prefetched with the state
+    // Re-derive everything uniform from the device copy of the parameters: keeping ~200 loop-invariant
+    // scalars alive across the tick body would spill SGPRs into VGPRs and halve the occupancy.
+    {
+      const uint64_t pv = (uint64_t)P0.self;
+      uint32_t plo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pv);
+      uint32_t phi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(pv >> 32));
+      asm volatile("" : "+s"(plo), "+s"(phi));   // opaque: nothing derived from it is hoisted out of the tick loop
+      pk = (const KParams*)(((uint64_t)phi << 32) | plo);
+    }
+    aux = env_setup(e, smem, P, M, MC, Mp, MS, wave, lane, env);
+    srcb = aux.srcb; park = aux.park;
+    // parked in LDS: an LDS load lands in a VGPR; readfirstlane tells the compiler the value is uniform, so the
+    // 22 per-env scalars live in SGPRs across the tick body instead of 22 of the 128 VGPRs
+#pragma unroll
+    for (int i = 0; i < CG_I_COUNT; ++i) ie[i] = __builtin_amdgcn_readfirstlane(park[i]);
+#pragma unroll
+    for (int i = 0; i < CG_D_COUNT; ++i)
+      fe[i] = __hiloint2double(__builtin_amdgcn_readfirstlane(park[CG_I_COUNT + 2 * i + 1]),
+                               __builtin_amdgcn_readfirstlane(park[CG_I_COUNT + 2 * i]));
+    mode = P.a.mode[te];
+    ng = P.a.n_groups[te];
+    at0 = P.a.atype[te * G];
+    cnt0 = P.a.dev_cnt[te * G];
+    nexp0 = P.a.n_exploit[te * G];
+    app0 = P.a.app[te * G];
+    const int16_t* gd = P.a.dev_idx + te * L;
+    for (int q = lane; q < L; q += WAVE) e.devl[q] = gd[q];
+    wsync();
+  }
+  if (ng < 0) {   // n_groups < 0: this env does not tick (per-env stepping inside a batch)
+    if (FUSED && tk == 0 && lane == 0) {
+#pragma unroll
+      for (int i = 0; i < CG_I_COUNT; ++i) park[i] = ie[i];
+#pragma unroll
+      for (int i = 0; i < CG_D_COUNT; ++i) ((double*)(park + CG_I_COUNT))[i] = fe[i];
+    }
+    continue;
+  }
+  const int16_t* devs = e.devl;
+  uint32_t* const F = (uint32_t*)e.flags;
+  uint32_t* const Bz = (uint32_t*)e.busy;
+  uint32_t* const Wl = (uint32_t*)e.wl;
+  const uint32_t* const Ds = (const uint32_t*)e.dst;
+  const bool partial = (mode & CG_MODE_PARTIAL) && ng == 0;   // step(action, agent_cnt != len(net)) :1207
+  mode &= 0xFF;
+  e.tick = (uint32_t)ie[CG_I_RNG_TICK];
+  e.eflags = ie[CG_I_FLAGS];
+  e.log_total = ie[CG_I_LOG_TOTAL];
+  if (COLD(XE && (!FUSED || tk == 0) && x_cnt(e) > 0)) {   // this env carries edges evolve_network added: stage its list
+    const uint32_t* xg = P.b.extra + (size_t)env * (P.t.K + P.t.KW);
+    const int nx = x_cnt(e) < P.t.K ? x_cnt(e) : P.t.K;
+    for (int j = lane; j < nx; j += WAVE) e.xk[j] = xg[j];
+    for (int w = lane; w < P.t.KW; w += WAVE) e.xb[w] = xg[P.t.K + w];
+    wsync();
+    x_masks(e);
+  }
+  double cost = 0.0;
+  bool dirty = false;
+  int last_atype = -1;
+
+  if (ng == 0) {   // ---- step(action) volt_typhoon_env.py:818-1333 ----
+    int at = at0;
+    int Ld = cnt0;
+    if (Ld > L) Ld = L;
+    if (Ld < 0) Ld = 0;
+    if (mode == CG_MODE_DEFENDER) { if (!(at >= 0 && at < P.c.n_def_actions)) at = 8; }
+    else                          { if (!(at >= 0 && at < P.c.n_att_actions)) at = 3; }
+    for (int w = lane; w < NW; w += WAVE) {   // :904-908 decay of the cached busy set
+      uint32_t b = Bz[w];
+      Bz[w] = b - (((F[w] >> 6) & ONES) & nz01(b));
+    }
+    wsync();
+    if (mode == CG_MODE_DEFENDER) {
+      if (P.c.baseline != 0) at = 8;   // :913-914
+      def_global(e, P, at, devs, Ld, cost, dirty, false, ie, fe);
+      if (at == 1 || at == 4 || at == 5 || at == 6 || at == 7 || at == 9 || at == 12 || at == 13)
+        if (Ld > 0) def_per_device<XE>(e, P, at, devs, Ld, app0, cost, dirty, ie, fe);
+    } else if (P.c.baseline != 3 && (at == 1 || at == 2)) {
+#pragma unroll
+      for (int c = 0; c < MC; ++c) {   // :1127 snapshot of the sources
+        int d = c * WAVE + lane;
+        uint64_t m = ballot(d < M && (e.flags[d] & (CG_F_COMP | CG_F_OWNED)));
+        if (lane == 0) srcb[c] = m;
+      }
+      wsync();
+      if (at == 1) {
+        int ne = nexp0;
+        if (ne > CG_MAX_EXPLOITS) ne = CG_MAX_EXPLOITS;
+        __builtin_amdgcn_s_setprio(3);   // the spread bounds the launch: win issue arbitration over short envs
+        attacker_spread<XE>(e, P, P.a.exploit + te * G * CG_MAX_EXPLOITS, ne, srcb);
+        __builtin_amdgcn_s_setprio(0);
+      } else {
+        attacker_probe<XE>(e, srcb, cost);
+      }
+    }
+    last_atype = at;
+  } else {   // ---- step_grouped(groups) :694-779 via _step_apply_only :612-692 ----
+    uint8_t* occ = (uint8_t*)(e.scr + Mp);   // second scratch half: clean-stall occurrence numbers
+    for (int i = lane; i < Mp / 4; i += WAVE) ((uint32_t*)occ)[i] = 0;
+    wsync();
+    const int16_t* dp = devs;
+    int used = 0;
+    for (int g = 0; g < ng && g < G; ++g) {
+      int at = P.a.atype[te * G + g];
+      int Ld = P.a.dev_cnt[te * G + g];
+      if (Ld < 0) Ld = 0;
+      if (used + Ld > L) Ld = L - used;
+      if (mode == CG_MODE_DEFENDER && at == 0) at = 8;
+      else if (mode == CG_MODE_ATTACKER && at == 0) at = 3;
+      if (mode == CG_MODE_DEFENDER) {
+        if (P.c.baseline != 0) at = 8;
+        def_global(e, P, at, dp, Ld, cost, dirty, true, ie, fe);
+        if (at == 1 && Ld > 0) def_clean(e, P, dp, Ld, cost, ie, fe, occ);
+      }
+      dp += Ld; used += Ld;
+    }
+    for (int w = lane; w < NW; w += WAVE) { uint32_t b = Bz[w]; Bz[w] = b - nz01(b); }   // _tick_busy_time_once :607
+    wsync();
+  }
+
+  STAMP(2);
+  // ---- fused word pass: workload advance (:1242-1261 / :705-725) + every per-tick count ----
+  int c_fin = 0, c_act = 0, c_idle = 0, c_fsrv = 0, c_comp = 0, c_cdc = 0;
+  for (int w = lane; w < NW; w += WAVE) {
+    uint32_t f = F[w], b = Bz[w], l = Wl[w], st = Ds[w];
+    const uint32_t nya = (f >> 4) & ONES;
+    const uint32_t step = partial ? 0u : (~nz01(b) & ~nya & nz01(l) & ONES);   // idle-of-stall, active, has a job
+    l -= step;
+    const uint32_t fin = step & ~nz01(l);
+    const uint32_t adv = (f >> 7) & ONES;
+    f &= ~((fin & adv) << 7);
+    Wl[w] = l; F[w] = f;
+    const uint32_t act = ~nya & ONES;
+    const uint32_t idl = act & ~nz01(b) & ~nz01(l);
+    const uint32_t cmp = f & ~nya & ~(f >> 1) & ONES;          // compromised, active, not attacker-owned
+    c_fin += __popc(fin & ~adv);
+    c_act += __popc(act);
+    c_idle += __popc(idl);
+    c_fsrv += __popc(idl & (st >> 1));
+    c_comp += __popc(cmp);
+    c_cdc += __popc(cmp & st);
+  }
+  const int current_work = wave_sum_bits(c_fin, e.cbits);
+  const int n_active = wave_sum_bits(c_act, e.cbits);
+  const int n_idle = wave_sum_bits(c_idle, e.cbits);
+  const int n_fsrv = wave_sum_bits(c_fsrv, e.cbits);
+  const int n_comp = wave_sum_bits(c_comp, e.cbits);
+  const int n_comp_dc = wave_sum_bits(c_cdc, e.cbits);
+  ie[CG_I_WORK_DONE] += current_work;
+  wsync();
+  if (!partial) arrivals(e, P, ie[CG_I_STEP_NUM], n_active, n_idle, n_fsrv);   // changes wl only: the counts above stand
+
+  STAMP(3);
+  // ---- rewards (:1267-1304 / :732-748) ----
+  if (ng == 0) ie[CG_I_COMP_CNT] += n_comp;
+  ie[CG_I_LAST_NCOMP] = n_comp;
+  double raw, shaped;
+  {
+    double def_work = P.c.work_scale * current_work;
+    if (mode == CG_MODE_DEFENDER) {
+      raw = cost + def_work - n_comp * P.c.comp_scale;
+      shaped = raw;
+    } else {
+      double r = cost + P.c.comp_scale * (n_comp + 10 * n_comp_dc);
+      double phi = (double)n_comp / (double)M;
+      if (!(e.eflags & CG_E_PREV_SET)) { fe[CG_D_PREV_ATT_POT] = phi; e.eflags |= CG_E_PREV_SET; }
+      double inc = P.c.gamma * phi - fe[CG_D_PREV_ATT_POT];
+      double bonus = 0.1 * inc + 0.0;
+      fe[CG_D_PREV_ATT_POT] = P.c.gamma * phi;
+      raw = r;
+      shaped = r + bonus;
+    }
+  }
+
+  STAMP(4);
+  // ---- observation (_get_state CyberDefenseEnv.py:146-191), before evolve.
+  // One lane per device PAIR: 12 floats = three 16-byte stores; static columns read as float2.
+  if (!(M & 1)) {
+    float4* out4 = (float4*)(P.o.obs + te * M * 6);
+    const int npairs = M >> 1;
+    const uint16_t* F2 = (const uint16_t*)e.flags;
+    const float2* os2 = (const float2*)e.osv;
+    const float2* ve2 = (const float2*)e.ver;
+    const float2* an2 = (const float2*)e.ano;
+    for (int p = lane; p < npairs; p += WAVE) {
+      const uint32_t f2 = F2[p];
+      const float2 o = os2[p], v = ve2[p], a = an2[p];
+      const uint32_t fa = f2 & 0xFFu, fb = f2 >> 8;
+      out4[3 * p + 0] = make_float4(o.x, v.x, (float)(fa & 1u), a.x);
+      out4[3 * p + 1] = make_float4((float)((fa >> 2) & 1u), (float)((fa >> 4) & 1u), o.y, v.y);
+      out4[3 * p + 2] = make_float4((float)(fb & 1u), a.y, (float)((fb >> 2) & 1u), (float)((fb >> 4) & 1u));
+    }
+  } else {   // odd M: rows are not 16-byte aligned across envs
+    float* o = P.o.obs + te * M * 6;
+    for (int d = lane; d < M; d += WAVE) {
+      const uint32_t f = e.flags[d];
+      o[6 * d + 0] = e.osv[d]; o[6 * d + 1] = e.ver[d]; o[6 * d + 2] = (float)(f & 1u); o[6 * d + 3] = e.ano[d];
+      o[6 * d + 4] = (float)((f >> 2) & 1u); o[6 * d + 5] = (float)((f >> 4) & 1u);
+    }
+  }
+
+  STAMP(5);
+  if (!partial) {   // :1307-1312
+    ie[CG_I_STEP_NUM] += 1;
+    if (mode == CG_MODE_ATTACKER) ie[CG_I_ATT_STEP] += 1; else ie[CG_I_DEF_STEP] += 1;
+  }
+  const bool done = ie[CG_I_STEP_NUM] > P.c.episode_limit;
+  if (dirty || (ie[CG_I_STEP_NUM] % P.c.evolve_period) == 0) evolve<XE>(e, P);
+  if (ng == 0) {   // :1330 rebuild of the cached busy set
+    for (int w = lane; w < NW; w += WAVE) F[w] = (F[w] & ~(ONES * CG_F_BUSYC)) | (nz01(Bz[w]) << 6);
+  }
+  wsync();
+  ie[CG_I_RNG_TICK] += 1;
+  ie[CG_I_LAST_ATYPE] = last_atype;
+  ie[CG_I_LOG_TOTAL] = e.log_total;
+  ie[CG_I_FLAGS] = e.eflags | (__any(e.eflags & CG_E_BUSY_SAT) ? CG_E_BUSY_SAT : 0);
+
+  if (lane == 0) {
+    P.o.raw[te] = raw;
+    P.o.shaped[te] = shaped;
+    P.o.done[te] = done ? 1 : 0;
+  }
+
+  if (done && P.c.auto_reset && P.snap.live) {   // reload the initial snapshot; the RNG tick stays monotone
+    const int si = P.snap.n_envs == 1 ? 0 : env;
+    const size_t ss = (size_t)si * 4 * M;
+    wsync();
+    if (vec) {
+      for (int i = lane; i < items; i += WAVE) ((uint4*)e.flags)[i] = ((const uint4*)(P.snap.live + ss))[i];
+    } else {
+      for (int pl = 0; pl < 4; ++pl)
+        for (int i = lane; i < M; i += WAVE) e.flags[pl * MS + i] = P.snap.live[ss + pl * M + i];
+    }
+    for (int i = lane; i < 4 * M; i += WAVE) P.b.stash[so + i] = P.snap.stash[ss + i];
+    for (int w = lane; w < P.t.EW; w += WAVE) {
+      e.blk[w] = P.snap.blocked[(size_t)si * P.t.EW + w];
+      e.bin[w] = P.snap.blocked_in[(size_t)si * P.t.EW + w];
+    }
+    if (lane < CG_LOG_RING) ((uint32_t*)e.ring)[lane] = ((const uint32_t*)(P.snap.ring + (size_t)si * CG_LOG_RING * 2))[lane];
+    e.blk_dirty = e.ring_dirty = true;
+    if (COLD(XE && P.t.K > 0)) {   // the snapshot's extra-edge list (normally empty) replaces the episode's
+      const int ns = P.snap.extra ? (int)((uint32_t)P.snap.ienv[(size_t)si * CG_I_COUNT + CG_I_FLAGS] >> CG_E_NX_SHIFT) : 0;
+      const uint32_t* xs = P.snap.extra + (size_t)si * (P.t.K + P.t.KW);
+      for (int j = lane; j < ns; j += WAVE) e.xk[j] = xs[j];
+      for (int w = lane; w < P.t.KW; w += WAVE) e.xb[w] = ns > 0 ? xs[P.t.K + w] : 0u;
+      e.eflags = (e.eflags & 0xFFFF) | (ns << CG_E_NX_SHIFT);
+      wsync();
+      x_masks(e);
+      e.x_dirty = true;
+    }
+    const int32_t keep_tick = ie[CG_I_RNG_TICK];
+    const int32_t* g = P.snap.ienv + (size_t)si * CG_I_COUNT;
+#pragma unroll
+    for (int i = 0; i < CG_I_COUNT; ++i) ie[i] = g[i];
+    ie[CG_I_RNG_TICK] = keep_tick;
+    if (!(P.t.K > 0 && P.snap.extra)) ie[CG_I_FLAGS] &= 0xFFFF;
+    const double* gf = P.snap.fenv + (size_t)si * CG_D_COUNT;
+#pragma unroll
+    for (int i = 0; i < CG_D_COUNT; ++i) fe[i] = gf[i];
+    wsync();
+  }
+  if (FUSED && tk + 1 < n_ticks) {   // park the scalars for the next tick
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < CG_I_COUNT; ++i) park[i] = ie[i];
+#pragma unroll
+      for (int i = 0; i < CG_D_COUNT; ++i) ((double*)(park + CG_I_COUNT))[i] = fe[i];
+    }
+    wsync();
+  }
+  }   // for tk
+
+  STAMP(6);
+  // ---- write back: the whole [4][M] live block with 16-byte stores ----
+  if (vec) {
+    for (int i = lane; i < items; i += WAVE) ((uint4*)(P.b.live + so))[i] = ((const uint4*)e.flags)[i];
+  } else {
+    for (int pl = 0; pl < 4; ++pl)
+      for (int i = lane; i < M; i += WAVE) P.b.live[so + pl * M + i] = e.flags[pl * MS + i];
+  }
+  if (e.blk_dirty)
+    for (int w = lane; w < P.t.EW; w += WAVE) {
+      P.b.blocked[(size_t)env * P.t.EW + w] = e.blk[w];
+      P.b.blocked_in[(size_t)env * P.t.EW + w] = e.bin[w];
+    }
+  if (e.ring_dirty && lane < CG_LOG_RING)
+    ((uint32_t*)(P.b.ring + (size_t)env * CG_LOG_RING * 2))[lane] = ((const uint32_t*)e.ring)[lane];
+  if (COLD(XE && e.x_dirty)) {
+    uint32_t* xg = P.b.extra + (size_t)env * (P.t.K + P.t.KW);
+    const int nx = (int)((uint32_t)ie[CG_I_FLAGS] >> CG_E_NX_SHIFT);
+    for (int j = lane; j < nx; j += WAVE) xg[j] = e.xk[j];
+    for (int w = lane; w < P.t.KW; w += WAVE) xg[P.t.K + w] = e.xb[w];
+  }
+  if (lane == 0) {
+    int32_t* g = P.b.ienv + (size_t)env * CG_I_COUNT;
+#pragma unroll
+    for (int i = 0; i < CG_I_COUNT; ++i) g[i] = ie[i];
+    double* gf = P.b.fenv + (size_t)env * CG_D_COUNT;
+#pragma unroll
+    for (int i = 0; i < CG_D_COUNT; ++i) gf[i] = fe[i];
+  }
+  STAMP(7);
+#ifdef CG_STAMPS
+  if (P.dbg && lane == 0) { P.dbg[(size_t)env * 16 + 8] = (unsigned long long)(long long)ie[CG_I_LAST_ATYPE]; P.dbg[(size_t)env * 16 + 9] = (unsigned long long)mode; }
+#endif
+#undef P
+}
+
+#endif  // CG_TICK_HPP
