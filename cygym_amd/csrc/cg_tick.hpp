@@ -144,6 +144,7 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? 4 : (XE ? CG_LB : 1)) void step
   const int n_ticks = FUSED ? P.n_ticks : 1;
   for (int tk = 0; tk < n_ticks; ++tk) {
   const size_t te = (size_t)tk * P.n_envs + env;   // row of this (tick, env) in the action / output arrays
+  if (FUSED && tk > 0) STAMP(0);   // diagnostic builds: the stamps then describe the LAST tick of the rollout
   if (FUSED && tk > 0) {   // tick 0's header and list were prefetched with the state
     // Re-derive everything uniform from the device copy of the parameters: keeping ~200 loop-invariant
     // scalars alive across the tick body would spill SGPRs into VGPRs and halve the occupancy.
@@ -174,6 +175,7 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? 4 : (XE ? CG_LB : 1)) void step
     for (int q = lane; q < L; q += WAVE) e.devl[q] = gd[q];
     wsync();
   }
+  if (FUSED && tk > 0) STAMP(1);
   if (ng < 0) {   // n_groups < 0: this env does not tick (per-env stepping inside a batch)
     if (FUSED && tk == 0 && lane == 0) {
 #pragma unroll
@@ -415,6 +417,7 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? 4 : (XE ? CG_LB : 1)) void step
     }
     wsync();
   }
+  if (FUSED) STAMP(6);
   }   // for tk
 
   STAMP(6);

@@ -20,6 +20,25 @@ env.lib.cygym_set_debug.argtypes = [C.c_void_p, C.c_void_p]
 dbg = torch.zeros((N, 16), dtype=torch.int64, device="cuda:0")
 env.lib.cygym_set_debug(env._h, C.c_void_p(dbg.data_ptr()))
 names = ["stage", "action", "work+arrivals", "counts", "obs", "evolve+busyc", "writeback"]
+if os.environ.get("CYGYM_STAMP_ROLLOUT"):   # phases of the LAST tick of a T-tick cygym_rollout, per action type
+    T = int(os.environ["CYGYM_STAMP_ROLLOUT"])
+    for T_run in (T, T + 1):   # last tick defender / attacker
+        env.load_state(init)
+        act, out = env.alloc_rollout(T_run)
+        env.gen_actions_rollout(0, act)
+        env.rollout(act, out)
+        torch.cuda.synchronize()
+        d = dbg.cpu().numpy()
+        st = d[:, :8]
+        seg = np.diff(st[:, :7], axis=1)
+        tot = st[:, 6] - st[:, 0]
+        at = d[:, 8]
+        print(f"rollout T={T_run} last tick mode {int(d[0, 9])}: tick cycles mean {tot.mean():.0f} p50 {np.median(tot):.0f} p99 {np.percentile(tot, 99):.0f} max {tot.max()}")
+        print("   mean per phase:", {n: int(seg[:, i].mean()) for i, n in enumerate(names[:6])})
+        for a in sorted(set(at.tolist())):
+            m = at == a
+            print(f"   atype {int(a):3d}: n={int(m.sum()):5d} tick mean {tot[m].mean():8.0f} max {tot[m].max():8d}  top {seg[m, 0].mean():7.0f} action {seg[m, 1].mean():8.0f} work {seg[m, 2].mean():6.0f} counts {seg[m, 3].mean():6.0f} obs {seg[m, 4].mean():6.0f} evolve {seg[m, 5].mean():6.0f}")
+    sys.exit(0)
 for t in range(40):
     env.gen_actions(t)
     env.step()
