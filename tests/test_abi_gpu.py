@@ -1,0 +1,60 @@
+"""Error behaviour of the C ABI on the GPU (include/cygym_abi.h): every misuse comes back as a negative
+CYGYM_E* code with a message; nothing aborts, nothing silently falls back."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from cygym_amd import abi
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+EINVAL, EHIP, EUNSUP, ENOTBOUND = -1, -2, -3, -4
+
+
+def test_misuse_returns_error_codes():
+    from cygym_amd import _lib
+    from cygym_amd.batched_env import BatchedCyberDefenseEnv
+    from cygym_amd.topology import make_topology
+    lib = _lib.load()
+    topo, init, ck = make_topology(16, 2, seed=2)
+    cfg = abi.EnvConfig(seed=2, **ck)
+    t, c = topo.to_c(), cfg.to_c()
+    h = C.c_void_p()
+    assert lib.cygym_create(C.byref(t), C.byref(c), 8, 0, C.byref(h)) == 0
+    a, o = abi.Actions(), abi.Outputs()
+    assert lib.cygym_step(h, C.byref(a), C.byref(o), None) == ENOTBOUND      # no cygym_bind yet
+    assert b"not bound" in lib.cygym_last_error(h)
+    b = abi.Buffers()
+    assert lib.cygym_bind(h, C.byref(b)) == EINVAL                            # null planes
+    lib.cygym_destroy(h)
+
+    env = BatchedCyberDefenseEnv(topo, cfg, 8, init, device="cuda:0", max_groups=1, max_devs=4)
+    assert env.lib.cygym_step(env._h, C.byref(abi.Actions()), C.byref(env._out), None) == EINVAL   # null action arrays
+    assert env.lib.cygym_observe(env._h, 7, C.c_void_p(env.obs.data_ptr()), None) == EINVAL          # unknown role
+    assert env.lib.cygym_rollout(env._h, 0, C.byref(abi.Actions()), C.byref(env._out), None) == EINVAL
+    # the env still works after the rejected calls
+    env.gen_actions(0)
+    obs, raw, shaped, done = env.step()
+    assert np.isfinite(raw.cpu().numpy()).all()
+    env.close()
+
+    # auto_reset needs a snapshot: BatchedCyberDefenseEnv always sets one, the raw ABI must insist on it
+    cfg2 = abi.EnvConfig(seed=2, auto_reset=1, **ck)
+    c2 = cfg2.to_c()
+    h2 = C.c_void_p()
+    assert lib.cygym_create(C.byref(t), C.byref(c2), 8, 0, C.byref(h2)) == 0
+    st = {k: torch.zeros_like(v) for k, v in env.state.items() if k in abi.BUFFER_FIELDS}
+    bb = abi.Buffers()
+    for k in abi.BUFFER_FIELDS:
+        setattr(bb, k, st[k].data_ptr() if st[k].numel() else None)
+    bb.n_envs = 8
+    assert lib.cygym_bind(h2, C.byref(bb)) == 0
+    aa = abi.Actions()
+    for k, v in env.act.items():
+        setattr(aa, k, v.data_ptr())
+    aa.max_groups, aa.max_devs = 1, 4
+    assert lib.cygym_step(h2, C.byref(aa), C.byref(env._out), None) == EINVAL
+    assert b"snapshot" in lib.cygym_last_error(h2)
+    lib.cygym_destroy(h2)

@@ -155,3 +155,69 @@ def test_tick_kernels_do_not_spill():
             assert r["scratch"] == 0 and r.get("vgpr_spill", 0) == 0, (name, r)
             assert r["vgprs"] <= 128, (name, r)
     assert seen == {(False, False), (False, True), (True, False), (True, True)}
+
+
+def _create(topo, cfg, n=4):
+    from cygym_amd import _lib
+    lib = _lib.load()
+    h = C.c_void_p()
+    t, c = topo.to_c(), cfg.to_c()
+    rc = lib.cygym_create(C.byref(t), C.byref(c), n, 0, C.byref(h))
+    msg = lib.cygym_last_error(None).decode()
+    if rc == 0:
+        lib.cygym_destroy(h)
+    return rc, msg
+
+
+def test_create_rejects_malformed_input_before_touching_the_gpu():
+    """cygym_create validates the topology / config on the host first, so a malformed CSR can never reach a
+    kernel; every rejection is an error code + message (error behaviour of the boundary, include/cygym_abi.h)."""
+    import copy
+    from cygym_amd.topology import make_topology
+    EINVAL, EHIP, EUNSUP = -1, -2, -3
+    topo, init, ck = make_topology(16, 2, seed=1)
+    cfg = abi.EnvConfig(seed=1, **ck)
+
+    def variant(**kw):
+        t = copy.deepcopy(topo)
+        for k, v in kw.items():
+            setattr(t, k, v)
+        return t
+
+    bad_ptr = topo.out_ptr.copy(); bad_ptr[-1] -= 1
+    rc, msg = _create(variant(out_ptr=bad_ptr), cfg)
+    assert rc == EINVAL and "CSR" in msg
+    bad_col = topo.out_col.copy(); bad_col[0] = 99
+    rc, msg = _create(variant(out_col=bad_col), cfg)
+    assert rc == EINVAL and "out of range" in msg
+    bad_eid = topo.in_eid.copy(); bad_eid[[0, 1]] = bad_eid[[1, 0]]
+    rc, msg = _create(variant(in_eid=bad_eid), cfg)
+    assert rc == EINVAL and "in_eid" in msg
+    rc, msg = _create(variant(max_extra=-1), cfg)
+    assert rc == EINVAL and "max_extra_edges" in msg
+    # rows must be sorted by neighbour id once evolve_network may add edges (merged rows, cygym_spec.h)
+    row = slice(int(topo.out_ptr[5]), int(topo.out_ptr[6]))
+    u = next(d for d in range(topo.M) if topo.out_ptr[d + 1] - topo.out_ptr[d] >= 2)
+    lo = int(topo.out_ptr[u])
+    t2 = copy.deepcopy(topo)
+    t2.out_col = topo.out_col.copy()
+    t2.out_col[[lo, lo + 1]] = t2.out_col[[lo + 1, lo]]
+    t2.in_ptr, t2.in_col, t2.in_eid = abi.build_in_csr(t2.M, t2.out_ptr, t2.out_col)
+    t2.max_extra = 8
+    rc, msg = _create(t2, cfg)
+    assert rc == EINVAL and "sorted" in msg
+    t2.max_extra = 0          # the same unsorted rows are fine when no edge can be added
+    rc0, _ = _create(t2, cfg)
+    assert rc0 in (0, EHIP)
+    # configurations outside the implemented path are refused, not approximated
+    rc, msg = _create(topo, abi.EnvConfig(seed=1, **{**ck, "fast_scan": 0}))
+    assert rc == EUNSUP and "fast_scan" in msg
+    rc, msg = _create(topo, abi.EnvConfig(seed=1, **{**ck, "num_of_device": 6000}))
+    assert rc == EUNSUP and "numOfDevice" in msg
+    rc, msg = _create(topo, cfg, n=0)
+    assert rc == EINVAL
+    # a valid request on a host without a GPU fails with CYGYM_EHIP: there is no CPU fallback behind the ABI
+    import torch
+    if not torch.cuda.is_available():
+        rc, msg = _create(topo, cfg)
+        assert rc == EHIP and msg
