@@ -7,6 +7,33 @@
 // MT: devices per env when known at compile time (64, 256: chunk loops unroll and their LDS latencies
 // overlap), 0 = any M at run time.
 // Per-wave LDS carve + pointer table of one env (must match wave_lds_bytes on the host).
+// One lane per device PAIR: 12 floats = three 16-byte stores; static columns read as float2.
+__device__ __forceinline__ void write_obs(const uint8_t* flags, const float* osv, const float* ver, const float* ano,
+                                          float* obs, int M, int lane) {
+  if (!(M & 1)) {
+    float4* out4 = (float4*)obs;
+    const int npairs = M >> 1;
+    const uint16_t* F2 = (const uint16_t*)flags;
+    const float2* os2 = (const float2*)osv;
+    const float2* ve2 = (const float2*)ver;
+    const float2* an2 = (const float2*)ano;
+    for (int p = lane; p < npairs; p += WAVE) {
+      const uint32_t f2 = F2[p];
+      const float2 o = os2[p], v = ve2[p], a = an2[p];
+      const uint32_t fa = f2 & 0xFFu, fb = f2 >> 8;
+      out4[3 * p + 0] = make_float4(o.x, v.x, (float)(fa & 1u), a.x);
+      out4[3 * p + 1] = make_float4((float)((fa >> 2) & 1u), (float)((fa >> 4) & 1u), o.y, v.y);
+      out4[3 * p + 2] = make_float4((float)(fb & 1u), a.y, (float)((fb >> 2) & 1u), (float)((fb >> 4) & 1u));
+    }
+  } else {   // odd M: rows are not 16-byte aligned across envs
+    for (int d = lane; d < M; d += WAVE) {
+      const uint32_t f = flags[d];
+      obs[6 * d + 0] = osv[d]; obs[6 * d + 1] = ver[d]; obs[6 * d + 2] = (float)(f & 1u); obs[6 * d + 3] = ano[d];
+      obs[6 * d + 4] = (float)((f >> 2) & 1u); obs[6 * d + 5] = (float)((f >> 4) & 1u);
+    }
+  }
+}
+
 struct WaveAux { uint64_t* srcb; int32_t* park; };
 __device__ __forceinline__ WaveAux env_setup(Env& e, uint8_t* smem, const KParams& P, int M, int MC, int Mp, int MS,
                                              int wave, int lane, int env) {
@@ -28,7 +55,7 @@ __device__ __forceinline__ WaveAux env_setup(Env& e, uint8_t* smem, const KParam
   e.xmi = e.xmo + MC;
   e.K = P.t.K;
   e.optr = (const uint16_t*)(smem + P.t.o_optr); e.ocol = (const uint16_t*)(smem + P.t.o_ocol);
-  e.osv = (const float*)(smem + P.t.o_os); e.ver = (const float*)(smem + P.t.o_ver); e.ano = (const float*)(smem + P.t.o_ano);
+  e.osv = (const float*)(smem + P.t.o_os); e.ver = (const float*)(smem + P.t.o_ver); e.ano = (const float*)(smem + P.t.o_ano);   // valid when P.t.in_lds
   e.dst = smem + P.t.o_dst; e.vul = smem + P.t.o_vul; e.nap = smem + P.t.o_nap;
   e.iptr_g = (const uint16_t*)(P.t.blob + P.t.o_iptr); e.icol_g = (const uint16_t*)(P.t.blob + P.t.o_icol);
   e.ieid_g = (const uint16_t*)(P.t.blob + P.t.o_ieid); e.oeid_g = (const uint16_t*)(P.t.blob + P.t.o_oeid);
@@ -322,31 +349,11 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? 4 : (XE ? CG_LB : 1)) void step
   }
 
   STAMP(4);
-  // ---- observation (_get_state CyberDefenseEnv.py:146-191), before evolve.
-  // One lane per device PAIR: 12 floats = three 16-byte stores; static columns read as float2.
-  if (!(M & 1)) {
-    float4* out4 = (float4*)(P.o.obs + te * M * 6);
-    const int npairs = M >> 1;
-    const uint16_t* F2 = (const uint16_t*)e.flags;
-    const float2* os2 = (const float2*)e.osv;
-    const float2* ve2 = (const float2*)e.ver;
-    const float2* an2 = (const float2*)e.ano;
-    for (int p = lane; p < npairs; p += WAVE) {
-      const uint32_t f2 = F2[p];
-      const float2 o = os2[p], v = ve2[p], a = an2[p];
-      const uint32_t fa = f2 & 0xFFu, fb = f2 >> 8;
-      out4[3 * p + 0] = make_float4(o.x, v.x, (float)(fa & 1u), a.x);
-      out4[3 * p + 1] = make_float4((float)((fa >> 2) & 1u), (float)((fa >> 4) & 1u), o.y, v.y);
-      out4[3 * p + 2] = make_float4((float)(fb & 1u), a.y, (float)((fb >> 2) & 1u), (float)((fb >> 4) & 1u));
-    }
-  } else {   // odd M: rows are not 16-byte aligned across envs
-    float* o = P.o.obs + te * M * 6;
-    for (int d = lane; d < M; d += WAVE) {
-      const uint32_t f = e.flags[d];
-      o[6 * d + 0] = e.osv[d]; o[6 * d + 1] = e.ver[d]; o[6 * d + 2] = (float)(f & 1u); o[6 * d + 3] = e.ano[d];
-      o[6 * d + 4] = (float)((f >> 2) & 1u); o[6 * d + 5] = (float)((f >> 4) & 1u);
-    }
-  }
+  // ---- observation (_get_state CyberDefenseEnv.py:146-191), before evolve.  The static float columns come from
+  // LDS, or (large M, where leaving them out of LDS buys resident waves) from the L2-resident blob.
+  if (P.t.in_lds) write_obs(e.flags, e.osv, e.ver, e.ano, P.o.obs + te * M * 6, M, lane);
+  else write_obs(e.flags, (const float*)(P.t.blob + P.t.o_os), (const float*)(P.t.blob + P.t.o_ver),
+                 (const float*)(P.t.blob + P.t.o_ano), P.o.obs + te * M * 6, M, lane);
 
   STAMP(5);
   if (!partial) {   // :1307-1312

@@ -138,22 +138,28 @@ static int choose_launch(cygym_handle* h, int max_devs) {
   DevTopo& t = h->t;
   const size_t lds_cap = 160 * 1024;
   const size_t wave = wave_lds_bytes(t, max_devs);
-  const size_t shared = (size_t)t.o_iptr;
-  int best = 0, best_waves = 0;
   const char* force = getenv("CYGYM_WPB");   // tuning aid: force the waves-per-workgroup choice
   const int forced = force ? atoi(force) : 0;
-  for (int wpb = 16; wpb >= 1; wpb >>= 1) {
-    if (forced && wpb != forced) continue;
-    const size_t per_wg = shared + wave * wpb;
-    if (per_wg > lds_cap) continue;
-    int waves = (int)(lds_cap / per_wg) * wpb;
-    if (waves > 32) waves = 32;
-    // ties: two 8-wave workgroups per CU beat one 16-wave workgroup (their phases interleave)
-    if (waves > best_waves || (waves == best_waves && wpb == 8)) { best_waves = waves; best = wpb; }
+  int best = 0, best_waves = 0, best_floats = 1;
+  // The three static float columns (os / version / anomaly, 12 bytes per device) feed only the observation
+  // writer: they ride in LDS unless leaving them in the L2-resident blob buys more resident waves (M >= 1024).
+  for (int floats = 1; floats >= 0; --floats) {
+    const size_t shared = (size_t)(floats ? t.o_iptr : t.o_os);
+    for (int wpb = 16; wpb >= 1; wpb >>= 1) {
+      if (forced && wpb != forced) continue;
+      const size_t per_wg = shared + wave * wpb;
+      if (per_wg > lds_cap) continue;
+      int waves = (int)(lds_cap / per_wg) * wpb;
+      if (waves > 32) waves = 32;
+      // ties: two 8-wave workgroups per CU beat one 16-wave workgroup (their phases interleave)
+      const bool better = waves > best_waves || (waves == best_waves && floats == best_floats && wpb == 8);
+      if (better) { best_waves = waves; best = wpb; best_floats = floats; }
+    }
   }
   if (!best) return -1;
+  const size_t shared = (size_t)(best_floats ? t.o_iptr : t.o_os);
   h->wpb = best; h->wave_lds = (int)wave; h->shared_lds = (int)shared;
-  t.lds_bytes = (int)shared; t.in_lds = 0;
+  t.lds_bytes = (int)shared; t.in_lds = best_floats;   // in_lds: the float columns are staged too
   h->max_devs = max_devs;
   return 0;
 }
@@ -218,8 +224,8 @@ int cygym_create(const cygym_topology* topo, const cygym_config* cfg, int32_t n_
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 16); return (int)o; };
   t.o_optr = take((size_t)(M + 1) * 2); t.o_ocol = take((size_t)(E > 0 ? E : 1) * 2);
-  t.o_os = take((size_t)M * 4); t.o_ver = take((size_t)M * 4); t.o_ano = take((size_t)M * 4);
   t.o_dst = take(M); t.o_vul = take(M); t.o_nap = take(M);
+  t.o_os = take((size_t)M * 4); t.o_ver = take((size_t)M * 4); t.o_ano = take((size_t)M * 4);   // LDS only when that is free
   t.o_iptr = take((size_t)(M + 1) * 2); t.o_icol = take((size_t)(E > 0 ? E : 1) * 2); t.o_ieid = take((size_t)(E > 0 ? E : 1) * 2);
   t.o_oeid = take((size_t)(E > 0 ? E : 1) * 2);
   t.blob_bytes = (int)off;
