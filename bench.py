@@ -190,6 +190,9 @@ def main():
         bw = measured_copy_gbs(dev)
         out["roofline"]["measured_copy_peak"] = bw
         out["roofline"]["frac_of_measured_copy"] = out["roofline"]["achieved"] / bw if bw else None
+    # the fixed-topology run must never have wanted an edge it could not add (CG_E_TOPO_OVF, cygym_spec.h)
+    from cygym_amd import spec as S
+    out["check"]["envs_that_needed_an_unavailable_edge"] = int(((env.state["ienv"][:, S.I_FLAGS] & S.E_TOPO_OVF) != 0).sum())
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(topo, init, cfg, M, L, scripts, W, args.cpu_seconds)
     if rank == 0:

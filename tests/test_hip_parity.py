@@ -239,8 +239,8 @@ def test_full_size_properties(M, blocks, N):
         np.testing.assert_array_equal(full[k][base:], part[k], err_msg=k)
     part["ienv"][:, S.I_FLAGS] &= ~0x80
     assert not gio.compare_state(part, ob.state, "tail vs oracle")
-    f = full["flags"]
-    assert not ((f & S.F_NYA) != 0)[(full["wl"] > 0) & False].any()
+    # a device that is not part of the network holds no workload (evolve removal / action 7 clear it)
+    assert not (((full["flags"] & S.F_NYA) != 0) & (full["wl"] > 0)).any()
     assert (full["ienv"][:, S.I_STEP_NUM] == ticks).all()
     assert (full["ienv"][:, S.I_DEF_STEP] + full["ienv"][:, S.I_ATT_STEP] == ticks).all()
     assert np.isfinite(ret.cpu().numpy()).all()
