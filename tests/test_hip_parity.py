@@ -315,3 +315,15 @@ def test_rollout_with_added_edges(M, blocks, N, T, max_extra):
     assert not gio.compare_state(a, ob.state, "fused vs oracle")
     assert seen > 0 and out["done"].any()
     env.close(); fused.close()
+
+
+def test_differential_fuzz_sample(monkeypatch):
+    """A slice of tools_fuzz.py (random sizes, evolve parameters, extra-edge capacities incl. too small ones,
+    reshuffled ownership, episode caps; per-tick vs oracle and fused vs per-tick).  The full campaign
+    (1500 cases x 300 ticks, all agreeing) is run by hand on the GPU box; see DESIGN.md section 5."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import tools_fuzz
+    monkeypatch.setattr(sys, "argv", ["tools_fuzz.py", "--cases", "16", "--seed0", "5000", "--ticks", "150"])
+    tools_fuzz.main()   # exits non-zero (SystemExit) on the first mismatch

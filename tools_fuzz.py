@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""tools_fuzz.py -- differential fuzzing of the HIP tick against the CPU oracle (GPU box only).
+
+    python tools_fuzz.py [--cases 40] [--seed0 0] [--ticks 300]
+
+Each case draws a topology size, activity level, evolve parameters (events, additions, attacker-owned
+activations), extra-edge capacity (including too small ones), list capacity, an optional ownership reshuffle and
+episode cap, then steps both sides with the synthetic script -- every third tick with a hand-aimed block /
+unblock / clean on attacker-owned devices -- and compares the whole state bit for bit every few ticks, plus a
+fused rollout of the same script at the end.  Prints one line per case; exits non-zero on the first mismatch.
+TEST INFRASTRUCTURE (uses oracle/): not part of the product path.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=40)
+    ap.add_argument("--seed0", type=int, default=0)
+    ap.add_argument("--ticks", type=int, default=300)
+    a = ap.parse_args()
+    import torch
+    import golden_io as gio
+    from cygym_amd import abi, spec as S
+    from cygym_amd.actions import gen_actions_numpy
+    from cygym_amd.batched_env import BatchedCyberDefenseEnv
+    from cygym_amd.topology import make_topology
+    from oracle import driver as od
+
+    t_start = time.time()
+    for case in range(a.seed0, a.seed0 + a.cases):
+        rs = np.random.RandomState(1000 + case)
+        M = int(rs.choice([13, 16, 24, 37, 64, 100, 130, 200, 256, 300, 520]))
+        blocks = int(rs.choice([1, 1, 2, 4])) if M >= 16 else 1
+        n_active = int(rs.randint(max(3, M // 3), M + 1))
+        K = int(rs.choice([0, 4, 16, 64, 128, 256]))
+        N = int(rs.choice([33, 64, 96]))
+        L = int(rs.choice([1, 2, max(1, M // 8), max(2, M // 4) & ~1, 7]))
+        ticks = min(a.ticks, 120 if M > 256 else a.ticks)
+        topo, init, ck = make_topology(M, blocks, seed=case, n_active=n_active, max_extra=K)
+        ck.update(dict(lambda_events=float(rs.choice([0.0, 0.7, 1.5, 3.0])), p_add=float(rs.choice([0.1, 0.4, 0.8])),
+                       p_attacker=float(rs.choice([0.0, 0.05, 0.3])),
+                       num_of_device=int(rs.randint(2, max(3, n_active))), min_network_size=2,
+                       episode_limit=int(rs.choice([1000, 37])), auto_reset=int(rs.rand() < 0.5),
+                       zero_day=int(rs.rand() < 0.2), zero_day_owned_mask=int(rs.randint(0, 4))))
+        cfg = abi.EnvConfig(seed=int(rs.randint(1 << 30)), env_id_base=int(rs.randint(1 << 20)), **ck)
+        env = BatchedCyberDefenseEnv(topo, cfg, N, init, device="cuda:0", max_groups=1, max_devs=L)
+        fused = BatchedCyberDefenseEnv(topo, cfg, N, init, device="cuda:0", max_groups=1, max_devs=L)
+        ob = od.OracleBatch(topo, cfg, N)
+        ob.load_state(init)
+        shuffle = rs.rand() < 0.6
+        if shuffle:
+            for b in (env, fused, ob):
+                b.randomize()
+        script = []
+        for t in range(ticks):
+            act = gen_actions_numpy(cfg.seed, cfg.env_id_base, N, M, topo.X, t, L)
+            if t % 3 == 0:
+                fl = ob.state["flags"]
+                for e in range(0, N, 2):
+                    if act["mode"][e] != S.MODE_DEFENDER:
+                        continue
+                    owned = np.flatnonzero(fl[e] & S.F_OWNED)
+                    if owned.size:
+                        k = min(L, owned.size)
+                        pick = owned[rs.permutation(owned.size)[:k]]
+                        if rs.rand() < 0.3 and k > 1:
+                            pick[1] = pick[0]           # a repeated device
+                        act["atype"][e, 0] = int(rs.choice([6, 6, 9, 9, 1, 7, 13]))
+                        act["dev_cnt"][e, 0] = k
+                        act["dev_idx"][e, :k] = pick
+            script.append({k: v.copy() for k, v in act.items()})
+            env.set_actions_numpy(act)
+            obs, raw, shaped, done = env.step()
+            o_obs, o_raw, o_shaped, o_done = ob.step(act)
+            bad = []
+            if not np.allclose(raw.cpu().numpy(), o_raw, rtol=0, atol=1e-9):
+                bad.append("raw reward")
+            if t % 5 == 0 or t == ticks - 1:
+                got = env.state_numpy()
+                got["ienv"] = got["ienv"].copy()
+                got["ienv"][:, S.I_FLAGS] &= ~0x80
+                bad += gio.compare_state(got, ob.state, f"t={t}")
+                if not np.array_equal(got["ienv"][:, S.I_FLAGS] & S.E_TOPO_OVF, ob.state["ienv"][:, S.I_FLAGS] & S.E_TOPO_OVF):
+                    bad.append("TOPO_OVF flags")
+                if not np.array_equal(obs.cpu().numpy(), o_obs):
+                    bad.append("obs")
+            if bad:
+                print(f"case {case}: MISMATCH at tick {t}: M={M} blocks={blocks} n_active={n_active} K={K} N={N} L={L} "
+                      f"shuffle={shuffle} cfg={ck}\n  " + "\n  ".join(bad[:6]))
+                sys.exit(1)
+        # the same script as ONE fused rollout must land in the same state
+        r_act, r_out = fused.alloc_rollout(ticks)
+        for k in r_act:
+            r_act[k].copy_(torch.from_numpy(np.stack([s[k] for s in script]).astype(r_act[k].cpu().numpy().dtype)).reshape(r_act[k].shape))
+        fused.rollout(r_act, r_out)
+        fa, fb = fused.state_numpy(), env.state_numpy()
+        for k in ("live", "stash", "blocked", "blocked_in", "ring", "ienv", "fenv"):
+            if not np.array_equal(fa[k], fb[k]):
+                print(f"case {case}: fused rollout differs from stepping in {k}: M={M} K={K} L={L} cfg={ck}")
+                sys.exit(1)
+        if K > 0:
+            nx = (fb["ienv"][:, S.I_FLAGS].astype(np.int64) >> S.E_NX_SHIFT)
+            for e in range(N):
+                if not np.array_equal(fa["extra"][e, :nx[e]], fb["extra"][e, :nx[e]]):
+                    print(f"case {case}: fused rollout extra-edge list differs (env {e})")
+                    sys.exit(1)
+        nxmax = int((ob.state["ienv"][:, S.I_FLAGS].astype(np.int64) >> S.E_NX_SHIFT).max())
+        ovf = int(((ob.state["ienv"][:, S.I_FLAGS] & S.E_TOPO_OVF) != 0).sum())
+        print(f"case {case}: ok  M={M} b={blocks} act={n_active} K={K} N={N} L={L} shuffle={int(shuffle)} lam={ck['lambda_events']} "
+              f"p_att={ck['p_attacker']} cap={ck['episode_limit']}/{ck['auto_reset']} ticks={ticks} max_extra_edges={nxmax} ovf_envs={ovf} "
+              f"[{time.time() - t_start:.0f}s]", flush=True)
+        env.close(); fused.close()
+    print("fuzz: all cases agree")
+
+
+if __name__ == "__main__":
+    main()
