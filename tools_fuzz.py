@@ -5,9 +5,10 @@
 
 Each case draws a topology size, activity level, evolve parameters (events, additions, attacker-owned
 activations), extra-edge capacity (including too small ones), list capacity, an optional ownership reshuffle and
-episode cap, then steps both sides with the synthetic script -- every third tick with a hand-aimed block /
-unblock / clean on attacker-owned devices -- and compares the whole state bit for bit every few ticks, plus a
-fused rollout of the same script at the end.  Prints one line per case; exits non-zero on the first mismatch.
+episode cap, baseline mode and group capacity, then steps both sides with the synthetic script -- every third
+tick with a hand-aimed block / unblock / clean on attacker-owned devices, some ticks as step_grouped() calls,
+some envs sitting a tick out or taking a partial tick -- and compares the whole state bit for bit every few
+ticks, plus a fused rollout of the same script at the end.  Prints one line per case; exits non-zero on the first mismatch.
 TEST INFRASTRUCTURE (uses oracle/): not part of the product path.
 """
 from __future__ import annotations
@@ -47,6 +48,8 @@ def main():
         K = int(rs.choice([0, 4, 16, 64, 128, 256]))
         N = int(rs.choice([33, 64, 96]))
         L = int(rs.choice([1, 2, max(1, M // 8), max(2, M // 4) & ~1, 7]))
+        G = int(rs.choice([1, 1, 3]))                      # > 1: some ticks are step_grouped() calls
+        baseline = str(rs.choice(["Nash", "Nash", "Nash", "No Defense", "Preset", "No Attack"]))
         ticks = min(a.ticks, 120 if M > 256 else a.ticks)
         topo, init, ck = make_topology(M, blocks, seed=case, n_active=n_active, max_extra=K)
         ck.update(dict(lambda_events=float(rs.choice([0.0, 0.7, 1.5, 3.0])), p_add=float(rs.choice([0.1, 0.4, 0.8])),
@@ -54,9 +57,9 @@ def main():
                        num_of_device=int(rs.randint(2, max(3, n_active))), min_network_size=2,
                        episode_limit=int(rs.choice([1000, 37])), auto_reset=int(rs.rand() < 0.5),
                        zero_day=int(rs.rand() < 0.2), zero_day_owned_mask=int(rs.randint(0, 4))))
-        cfg = abi.EnvConfig(seed=int(rs.randint(1 << 30)), env_id_base=int(rs.randint(1 << 20)), **ck)
-        env = BatchedCyberDefenseEnv(topo, cfg, N, init, device="cuda:0", max_groups=1, max_devs=L)
-        fused = BatchedCyberDefenseEnv(topo, cfg, N, init, device="cuda:0", max_groups=1, max_devs=L)
+        cfg = abi.EnvConfig(seed=int(rs.randint(1 << 30)), env_id_base=int(rs.randint(1 << 20)), baseline=baseline, **ck)
+        env = BatchedCyberDefenseEnv(topo, cfg, N, init, device="cuda:0", max_groups=G, max_devs=L)
+        fused = BatchedCyberDefenseEnv(topo, cfg, N, init, device="cuda:0", max_groups=G, max_devs=L)
         ob = od.OracleBatch(topo, cfg, N)
         ob.load_state(init)
         shuffle = rs.rand() < 0.6
@@ -80,6 +83,32 @@ def main():
                         act["atype"][e, 0] = int(rs.choice([6, 6, 9, 9, 1, 7, 13]))
                         act["dev_cnt"][e, 0] = k
                         act["dev_idx"][e, :k] = pick
+            if G > 1:   # widen the single-action script to G groups; every 4th tick some defenders call step_grouped
+                wide = od.alloc_actions(N, G, L)
+                for k in ("mode", "n_groups", "dev_idx"):
+                    wide[k][...] = act[k]
+                for k in ("atype", "n_exploit", "app", "dev_cnt"):
+                    wide[k][:, 0] = act[k][:, 0]
+                wide["exploit"][:, 0] = act["exploit"][:, 0]
+                if t % 4 == 1:
+                    for e in range(1, N, 3):
+                        if wide["mode"][e] != S.MODE_DEFENDER:
+                            continue
+                        g = int(rs.randint(1, G + 1))
+                        wide["n_groups"][e] = g
+                        used = 0
+                        for j in range(g):
+                            wide["atype"][e, j] = int(rs.choice([1, 2, 3, 10, 11, 8, 0, 1]))
+                            c = int(rs.randint(0, max(1, (L - used)) + 1)) if used < L else 0
+                            wide["dev_cnt"][e, j] = c
+                            wide["dev_idx"][e, used:used + c] = rs.randint(0, M, size=c)
+                            used += c
+                act = wide
+            if t % 7 == 3:      # some envs sit this tick out, some take a partial tick (step(action, agent_cnt))
+                idle = rs.rand(N) < 0.15
+                act["n_groups"][idle] = -1
+                part = (rs.rand(N) < 0.1) & (act["n_groups"] == 0)
+                act["mode"][part] |= S.MODE_PARTIAL
             script.append({k: v.copy() for k, v in act.items()})
             env.set_actions_numpy(act)
             obs, raw, shaped, done = env.step()
@@ -119,7 +148,7 @@ def main():
         nxmax = int((ob.state["ienv"][:, S.I_FLAGS].astype(np.int64) >> S.E_NX_SHIFT).max())
         ovf = int(((ob.state["ienv"][:, S.I_FLAGS] & S.E_TOPO_OVF) != 0).sum())
         print(f"case {case}: ok  M={M} b={blocks} act={n_active} K={K} N={N} L={L} shuffle={int(shuffle)} lam={ck['lambda_events']} "
-              f"p_att={ck['p_attacker']} cap={ck['episode_limit']}/{ck['auto_reset']} ticks={ticks} max_extra_edges={nxmax} ovf_envs={ovf} "
+              f"p_att={ck['p_attacker']} G={G} bl={baseline!r} cap={ck['episode_limit']}/{ck['auto_reset']} ticks={ticks} max_extra_edges={nxmax} ovf_envs={ovf} "
               f"[{time.time() - t_start:.0f}s]", flush=True)
         env.close(); fused.close()
     print("fuzz: all cases agree")
