@@ -1,0 +1,75 @@
+"""Differential fuzzing of the CPU oracle against the reference itself (build container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/harness/fuzz_reference.py [--cases 30] [--seed0 0]
+
+Each case builds a reference environment with random size / activity / evolve parameters (events, additions,
+attacker-owned activations, extra-edge capacity), optionally reshuffles ownership, drives it with random
+reference-style actions (single, grouped, None, repeated devices) under the injected Philox draws, and replays the
+recording through oracle/cygym_oracle.c with the same tick-by-tick comparison the golden tests use
+(tests/golden_io.check_oracle_against_fixture).  Nothing is written into the repository.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_harness as H          # noqa: E402
+import make_golden as G          # noqa: E402
+sys.path.insert(0, os.path.join(H.REPO, "tests"))
+import golden_io as gio          # noqa: E402
+from cygym_amd import spec as S  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=30)
+    ap.add_argument("--seed0", type=int, default=0)
+    a = ap.parse_args()
+    t0 = time.time()
+    for case in range(a.seed0, a.seed0 + a.cases):
+        rs = np.random.RandomState(50000 + case)
+        M = int(rs.choice([10, 12, 16, 20, 24, 32, 48]))
+        n_active = int(rs.randint(max(4, M // 2), M + 1))
+        over = dict(lambda_events=float(rs.choice([0.0, 0.7, 1.5, 2.5])), p_add=float(rs.choice([0.1, 0.45, 0.8])),
+                    p_attacker=float(rs.choice([0.0, 0.1, 0.4])), Min_network_size=int(rs.choice([2, 4])),
+                    sv_attacker_fraction=float(rs.choice([0.05, 0.25])))
+        if rs.rand() < 0.2:
+            over.update(zero_day=True, k_known=1, j_private=1)
+        env0 = H.build_env(M, n_active, init_seed=int(rs.randint(1, 10000)), strip_vuln_frac=float(rs.choice([0.2, 0.5])),
+                           extra_reachable=int(rs.randint(0, 3)), overrides=over)
+        X = 3 if over.get("zero_day") else 2
+        kind = rs.choice(["mixed", "edges", "dups"])
+        if kind == "edges":
+            fn = G.edge_heavy_actions(M, max(2, M // 5), X=X)
+        else:
+            fn = G.mixed_actions(M, G.ALL_DEF, G.ALL_ATT, max(2, M // 4), X=X, unique=(kind != "dups"))
+        shuffle = rs.rand() < 0.5
+
+        def pre(e, env, rs2, shuffle=shuffle):
+            if shuffle:
+                env.randomize_compromise_and_ownership()
+                return True
+            return False
+        T = int(rs.choice([80, 160]))
+        res = H.run_scenario(env0, 2, T, fn, seed=int(rs.randint(1 << 16)), env_id_base=int(rs.randint(1 << 16)),
+                             pre_fn=pre, max_extra=256)
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, "case.npz")
+            H.save_fixture(path, res, 1)
+            fx = gio.Fixture(f"fuzz{case}", path=path)
+            n = gio.check_oracle_against_fixture(fx)
+        nx = int((fx.exp["ienv"][:, :, S.I_FLAGS].astype(np.int64) >> S.E_NX_SHIFT).max())
+        print(f"case {case}: ok  M={M} active={n_active} {kind} shuffle={int(shuffle)} {over} ticks={n} max_extra_edges={nx} "
+              f"[{time.time() - t0:.0f}s]", flush=True)
+    print("reference fuzz: the oracle agrees with the reference on every case")
+
+
+if __name__ == "__main__":
+    main()

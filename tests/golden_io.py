@@ -21,8 +21,8 @@ def fixture_names():
 
 
 class Fixture:
-    def __init__(self, name):
-        z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    def __init__(self, name, path=None):
+        z = np.load(path if path is not None else os.path.join(GOLDEN, name + ".npz"))
         self.name = name
         self.z = z
         st = {k[len("static_"):]: z[k] for k in z.files if k.startswith("static_")}
@@ -191,3 +191,43 @@ def compare_state(got: dict, exp: dict, label: str, ring_total=None):
         idx = np.argwhere(~np.isclose(gf, xf, rtol=0, atol=1e-9))[0]
         bad.append(f"{label}: fenv differs at {tuple(idx)}: got {gf[tuple(idx)]} exp {xf[tuple(idx)]}")
     return bad
+
+
+def check_oracle_against_fixture(fx: "Fixture") -> int:
+    """Step the CPU oracle through a fixture (outputs of the reference itself) and compare every tick:
+    integer planes / counters / ring / extra edges bit-exact, rewards within 1e-9, the three observation
+    views exact.  Returns the number of ticks compared.  Used by tests/test_oracle_golden.py and by
+    oracle/harness/fuzz_reference.py."""
+    from oracle import driver as od
+    name = fx.name
+    ob = od.OracleBatch(fx.topo, fx.cfg, fx.N)
+    ob.load_state(fx.init)
+    act = od.alloc_actions(fx.N, fx.G, fx.L)
+    alive = np.ones(fx.N, bool)   # without an extra-edge list parity is defined while the topology is unchanged
+    checked = 0
+    for t in range(fx.T):
+        fx.actions(t, act, flags=ob.state["flags"])
+        obs, raw, shaped, done = ob.step(act)
+        same = fx.exp["topo_same"][:, t].astype(bool)
+        # where the reference ADDED edges (evolve star / PA), the build must have flagged it
+        ovf = (ob.state["ienv"][:, S.I_FLAGS] & S.E_TOPO_OVF) != 0
+        if fx.follows_topology():   # the added edges are part of the compared state: parity never ends
+            assert not ovf.any(), f"{name} t={t}: extra-edge list overflowed"
+        else:
+            assert np.array_equal(ovf[alive], ~same[alive]), f"{name} t={t}: TOPO_OVF {ovf} vs topo_same {same}"
+            alive &= same
+        if not alive.any():
+            break
+        exp = fx.expected_state(t)
+        sel = np.where(alive)[0]
+        got = {k: v[sel] for k, v in ob.state.items()}
+        bad = compare_state(got, {k: v[sel] for k, v in exp.items()}, f"{name} t={t}")
+        assert not bad, "\n".join(bad[:8])
+        np.testing.assert_array_equal(obs[sel], fx.exp["obs"][sel, t], err_msg=f"{name} obs t={t}")
+        np.testing.assert_allclose(raw[sel], fx.exp["raw"][sel, t], rtol=0, atol=1e-9, err_msg=f"{name} raw t={t}")
+        np.testing.assert_allclose(shaped[sel], fx.exp["shaped"][sel, t], rtol=0, atol=1e-9, err_msg=f"{name} shaped t={t}")
+        np.testing.assert_array_equal(done[sel], fx.exp["done"][sel, t], err_msg=f"{name} done t={t}")
+        np.testing.assert_array_equal(ob.observe(1)[sel], fx.exp["obs_def"][sel, t], err_msg=f"{name} obs_def t={t}")
+        np.testing.assert_array_equal(ob.observe(2)[sel], fx.exp["obs_att"][sel, t], err_msg=f"{name} obs_att t={t}")
+        checked += 1
+    return checked
