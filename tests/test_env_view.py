@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 NAMES = [n for n in gio.fixture_names()
-         if n.startswith(("s16_none", "s16_baselines", "s32_grouped", "s16_dups", "s16_mixed", "s16_zeroday", "s16_partial"))]
+         if n.startswith(("s16_none", "s16_baselines", "s32_grouped", "s16_dups", "s16_mixed", "s16_zeroday", "s16_partial",
+                          "s24_star", "s20_pa"))]
 
 
 @pytest.mark.parametrize("name", NAMES)
