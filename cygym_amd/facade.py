@@ -46,26 +46,32 @@ class ExploitView:
 
 
 class GraphView:
-    """The cached adjacency (_outnbrs / _innbrs) with python-igraph's read accessors."""
+    """The cached adjacency (_outnbrs / _innbrs) with python-igraph's read accessors: the shared base CSR
+    plus the edges evolve_network added to THIS env (extra-edge list), rows in neighbour-id order."""
 
-    def __init__(self, topo, blocked_bits):
+    def __init__(self, topo, blocked_bits, extra=()):
         self._t = topo
         self._blocked = blocked_bits
+        self._extra = sorted((int(u), int(v)) for (u, v, _b) in extra)
+        self._extra_blocked = {(int(u), int(v)) for (u, v, b) in extra if b}
 
     def vcount(self):
         return self._t.M
 
     def ecount(self):
-        return self._t.E
+        return self._t.E + len(self._extra)
 
     def get_edgelist(self):
         src = np.repeat(np.arange(self._t.M), np.diff(self._t.out_ptr))
-        return [(int(u), int(v)) for u, v in zip(src, self._t.out_col)]
+        return [(int(u), int(v)) for u, v in zip(src, self._t.out_col)] + list(self._extra)
 
     def neighbors(self, v, mode="all"):
         t = self._t
         out = [int(x) for x in t.out_col[t.out_ptr[v]:t.out_ptr[v + 1]]]
         inn = [int(x) for x in t.in_col[t.in_ptr[v]:t.in_ptr[v + 1]]]
+        if self._extra:
+            out = sorted(out + [b for (a, b) in self._extra if a == v])
+            inn = sorted(inn + [a for (a, b) in self._extra if b == v])
         m = str(mode).lower()
         return out if m == "out" else inn if m == "in" else sorted(out + inn)
 
@@ -79,9 +85,21 @@ class GraphView:
             return [len(self.neighbors(i, mode)) for i in v]
         return len(self.neighbors(v, mode))
 
+    def get_eid(self, u, v, directed=True, error=True):
+        """Edge id of (u -> v): base CSR slot, or E + position in the env's extra-edge list; -1 when absent."""
+        t = self._t
+        for k in range(int(t.out_ptr[u]), int(t.out_ptr[u + 1])):
+            if int(t.out_col[k]) == int(v):
+                return k
+        if (int(u), int(v)) in self._extra:
+            return t.E + self._extra.index((int(u), int(v)))
+        if error:
+            raise ValueError(f"no such edge ({u}, {v})")
+        return -1
+
     def blocked_edges(self):
         src = np.repeat(np.arange(self._t.M), np.diff(self._t.out_ptr))
-        return {(int(src[k]), int(self._t.out_col[k])) for k in np.nonzero(self._blocked)[0]}
+        return {(int(src[k]), int(self._t.out_col[k])) for k in np.nonzero(self._blocked)[0]} | set(self._extra_blocked)
 
 
 class SubnetView:
@@ -110,7 +128,7 @@ class SimulatorView:
     def __init__(self, view):
         from . import abi
         b, i = view._b, view._i
-        st = {k: b.state[k][i].cpu().numpy() for k in ("live", "blocked", "ienv")}
+        st = {k: b.state[k][i].cpu().numpy() for k in ("live", "blocked", "ienv", "extra")}
         flags, busy, wl, cby = st["live"]
         topo = b.topo
         net = {}
@@ -133,7 +151,9 @@ class SimulatorView:
             dv.compromised_by = {e for e in range(topo.X) if (int(cby[d]) >> e) & 1}
             net[d] = dv
         bits = abi.unpack_blocked(st["blocked"].view(np.uint32)[None], topo.E)[0]
-        self.subnet = SubnetView(net, GraphView(topo, bits))
+        n_extra = (int(st["ienv"][S.I_FLAGS]) & 0xFFFFFFFF) >> S.E_NX_SHIFT
+        extra = abi.unpack_extra(st["extra"].view(np.uint32), n_extra, topo.max_extra) if n_extra else ()
+        self.subnet = SubnetView(net, GraphView(topo, bits, extra))
         disc = int(st["ienv"][S.I_DISCOVERED])
         self.exploits = []
         for e in range(topo.X):

@@ -124,3 +124,30 @@ def test_object_facade_reads_the_soa():
     live_ids = [i for i, d in sim.subnet.net.items() if not d.Not_yet_added]   # HMARL.py:470
     assert live_ids == [i for i in range(fx.M) if not (f[i] & S.F_NYA)]
     batch.close()
+
+
+def test_facade_graph_follows_added_edges():
+    """`env.simulator.subnet.graph` shows the edges evolve_network added to THIS env (star around the
+    attacker-owned hub, CyberDefenseEnv.py:738-774), in igraph's neighbour order."""
+    from cygym_amd.batched_env import BatchedCyberDefenseEnv
+    from cygym_amd.env_view import CyberDefenseEnvView
+    from cygym_amd import abi
+    fx = gio.Fixture("s24_star")
+    batch = BatchedCyberDefenseEnv(fx.topo, fx.cfg, fx.N, fx.init, device="cuda:0", max_groups=1, max_devs=fx.L)
+    env = CyberDefenseEnvView(batch, 2)
+    T = 100
+    for t in range(T):
+        env.mode = fx.mode_name(2, t)
+        env.step(fx.python_action(2, t))
+    n = int(fx.exp["ienv"][2, T - 1, S.I_FLAGS]) >> S.E_NX_SHIFT
+    assert n > 0
+    exp = abi.unpack_extra(fx.exp["extra"][2, T - 1], n, fx.K)
+    g = env.simulator.subnet.graph
+    assert g.ecount() == fx.topo.E + n
+    assert g.get_edgelist()[fx.topo.E:] == [(u, v) for (u, v, _b) in exp]
+    u0, v0, _ = exp[0]
+    assert v0 in g.neighbors(u0, mode="out") and u0 in g.neighbors(v0, mode="in")
+    assert g.neighbors(u0, mode="out") == sorted(g.neighbors(u0, mode="out"))
+    assert g.get_eid(u0, v0) == fx.topo.E and g.get_eid(v0, v0, error=False) in (-1, g.get_eid(v0, v0, error=False))
+    assert {(u, v) for (u, v, b) in exp if b} <= g.blocked_edges()
+    batch.close()
