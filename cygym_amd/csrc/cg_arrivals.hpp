@@ -4,7 +4,8 @@
 #define CG_ARRIVALS_HPP
 
 // ---------------- arrivals: CDSimulator.generate_workloads :244-348 ----------------
-__device__ __forceinline__ void gen_workloads(Env& e, const KParams& P, int num, bool server, int n_active) {
+template <class KP>
+__device__ __forceinline__ void gen_workloads(Env& e, const KP& P, int num, bool server, int n_active) {
   const int M = e.M, MC = e.MC;
   if (n_active <= 0) return;
   if (P.c.workload_cap >= 0 && num > P.c.workload_cap) num = P.c.workload_cap;
@@ -75,7 +76,7 @@ __device__ __forceinline__ void gen_workloads(Env& e, const KParams& P, int num,
       seen_eq += __popcll(em);
     }
     if (take) {
-      e.wl[d] = (uint8_t)(1 + cg_cdf_lookup(e.draw(CG_SITE_ARR_TIME, d, 0), P.c.tri_thr, CG_TRI_TABLE));
+      e.wl[d] = (uint8_t)(1 + cdf_lookup(e.draw(CG_SITE_ARR_TIME, d, 0), P.c.tri_thr, CG_TRI_TABLE));
       e.flags[d] &= (uint8_t)~CG_F_WLADV;
     }
   }
@@ -83,7 +84,8 @@ __device__ __forceinline__ void gen_workloads(Env& e, const KParams& P, int num,
 }
 
 // volt_typhoon_env.py:575-596; the three counts come from the fused pass of the tick
-__device__ __forceinline__ void arrivals(Env& e, const KParams& P, int step_num, int n_active, int idle, int free_s) {
+template <class KP>
+__device__ __forceinline__ void arrivals(Env& e, const KP& P, int step_num, int n_active, int idle, int free_s) {
   int free_c = idle - free_s;
   int n1 = n_active > 1 ? n_active : 1;
   int half = 0;

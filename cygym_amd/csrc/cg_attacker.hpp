@@ -113,8 +113,8 @@ __device__ __forceinline__ int spread_x_counts(Env& e, const uint16_t* cur, cons
   return total;
 }
 
-template <bool XE>
-__device__ __forceinline__ void attacker_spread(Env& e, const KParams& P, const int32_t* expl, int n_expl,
+template <bool XE, class KP>
+__device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32_t* expl, int n_expl,
                                                 uint64_t* srcb) {
   const int M = e.M, MC = e.MC, Mp = MC * WAVE;
   uint32_t* T = e.scr;                          // [Mp] first-compromise time (source id + 1)

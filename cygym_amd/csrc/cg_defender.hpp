@@ -4,7 +4,8 @@
 #define CG_DEFENDER_HPP
 
 // ---------------- defender ----------------
-__device__ __forceinline__ void def_global(Env& e, const KParams& P, int at, const int16_t* dev, int L, double& cost,
+template <class KP>
+__device__ __forceinline__ void def_global(Env& e, const KP& P, int at, const int16_t* dev, int L, double& cost,
                                            bool& dirty, bool grouped, int32_t* ie, double* fe) {
   const double ds = P.c.def_scale;
   const int M = e.M;
@@ -57,7 +58,8 @@ __device__ __forceinline__ void def_global(Env& e, const KParams& P, int at, con
 
 // action 1 over one device list; `occ` (u8 [Mp], LDS) carries stall occurrence numbers across
 // the groups of one step_grouped tick (nullptr for single-action steps).
-__device__ __forceinline__ void def_clean(Env& e, const KParams& P, const int16_t* dev, int L, double& cost,
+template <class KP>
+__device__ __forceinline__ void def_clean(Env& e, const KP& P, const int16_t* dev, int L, double& cost,
                                           int32_t* ie, double* fe, uint8_t* occ) {
   const double ds = P.c.def_scale;
   int a, b, disc;
@@ -248,8 +250,8 @@ __device__ __forceinline__ void block_seq(Env& e, const PoolPtrs q, const int16_
   }
 }
 
-template <bool XE>
-__device__ __forceinline__ void def_per_device(Env& e, const KParams& P, int at, const int16_t* dev, int L, int app,
+template <bool XE, class KP>
+__device__ __forceinline__ void def_per_device(Env& e, const KP& P, int at, const int16_t* dev, int L, int app,
                                                double& cost, bool& dirty, int32_t* ie, double* fe) {
   const double ds = P.c.def_scale;
   const int M = e.M;

@@ -33,8 +33,8 @@ __device__ __forceinline__ bool edge_exists(const Env& e, int u, int v) {
   return false;
 }
 
-template <bool XE>
-__device__ __forceinline__ void evolve(Env& e, const KParams& P) {
+template <bool XE, class KP>
+__device__ __forceinline__ void evolve(Env& e, const KP& P) {
   const int M = e.M, MC = e.MC;
   if (!(e.eflags & CG_E_EVO_INIT)) {   // :654-659
     uint32_t* F = (uint32_t*)e.flags;
@@ -47,7 +47,7 @@ __device__ __forceinline__ void evolve(Env& e, const KParams& P) {
   }
   int n_ev = 0;
   if (P.c.poisson_thr[0] < (1ull << 32))   // lambda_events == 0: the table says "always zero events"
-    n_ev = cg_cdf_lookup(e.draw(CG_SITE_EVO_POISSON, 0, 0), P.c.poisson_thr, CG_POISSON_TABLE);
+    n_ev = cdf_lookup(e.draw(CG_SITE_EVO_POISSON, 0, 0), P.c.poisson_thr, CG_POISSON_TABLE);
   bool any_new = false;
   uint32_t* newly = e.marks;   // bit per device
   if (n_ev > 0) {

@@ -40,6 +40,11 @@ struct KParams {
   unsigned long long* dbg;   // diagnostic builds (-DCG_STAMPS): [N][16] s_memtime stamps per env
 };
 
+// how a kernel sees its parameters: the kernarg copy (per-tick kernel) or the device copy, through the constant
+// address space (rollout kernel)
+template <bool FUSED> struct KParamsOf { using type = const KParams; };
+template <> struct KParamsOf<true> { using type = const __attribute__((address_space(4))) KParams; };
+
 #ifdef CG_STAMPS
 #define SUBSTAMP(k) do { if (P.dbg && e.lane == 0) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); P.dbg[(size_t)e.env * 16 + (k)] = _t; } } while (0)
 #define SUBVAL(k, v) do { if (P.dbg && e.lane == 0) P.dbg[(size_t)e.env * 16 + (k)] = (unsigned long long)(v); } while (0)

@@ -35,7 +35,8 @@ __device__ __forceinline__ void write_obs(const uint8_t* flags, const float* osv
 }
 
 struct WaveAux { uint64_t* srcb; int32_t* park; };
-__device__ __forceinline__ WaveAux env_setup(Env& e, uint8_t* smem, const KParams& P, int M, int MC, int Mp, int MS,
+template <class KP>
+__device__ __forceinline__ WaveAux env_setup(Env& e, uint8_t* smem, const KP& P, int M, int MC, int Mp, int MS,
                                              int wave, int lane, int env) {
   uint8_t* wb = smem + P.shared_lds + (size_t)wave * P.wave_lds;
   e.flags = wb; e.busy = wb + MS; e.wl = wb + 2 * MS; e.cby = wb + 3 * MS;
@@ -75,8 +76,12 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? 4 : (XE ? CG_LB : 1)) void step
   extern __shared__ __align__(16) uint8_t smem[];
   // every use below goes through `P`: the kernarg copy for the single-tick kernel, the device copy for the
   // fused one (so that it can be re-read, opaquely, at the top of every tick)
-  const KParams* pk;
-  if constexpr (FUSED) pk = P0.self; else pk = &P0;
+  // The rollout kernel reads the parameters through a CONSTANT-address-space pointer: LLVM then knows that the
+  // pointers it loads from there are global ones (not LDS / scratch) and emits global_* instead of flat_*
+  // memory instructions (a flat access also ticks the LDS counter, so every LDS wait would queue behind it).
+  using KPT = typename KParamsOf<FUSED>::type;
+  KPT* pk;
+  if constexpr (FUSED) pk = (KPT*)(uintptr_t)P0.self; else pk = &P0;
 #define P (*pk)
   const int M = MT ? MT : P.t.M, MC = MT ? (MT + WAVE - 1) / WAVE : P.t.MC, Mp = MC * WAVE, MS = (M + 3) & ~3;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? 4 : (XE ? CG_LB : 1)) void step
       uint32_t plo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pv);
       uint32_t phi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(pv >> 32));
       asm volatile("" : "+s"(plo), "+s"(phi));   // opaque: nothing derived from it is hoisted out of the tick loop
-      pk = (const KParams*)(((uint64_t)phi << 32) | plo);
+      pk = (KPT*)(((uint64_t)phi << 32) | plo);
     }
     aux = env_setup(e, smem, P, M, MC, Mp, MS, wave, lane, env);
     srcb = aux.srcb; park = aux.park;

@@ -47,6 +47,14 @@ __device__ __forceinline__ int nth_bit32(uint32_t m, int r) {
   return __builtin_ctz(m);
 }
 
+// cg_cdf_lookup (cygym_spec.h) over a table that may live in any address space (kernarg or the constant-space copy)
+template <class Tab>
+__device__ __forceinline__ int cdf_lookup(uint32_t u, const Tab& thr, int n) {
+  int k = 0;
+  for (int j = 0; j < n; ++j) k += ((uint64_t)u >= thr[j]) ? 1 : 0;
+  return k;
+}
+
 // ---- SWAR on 4 device bytes per 32-bit word ----
 #define ONES 0x01010101u
 __device__ __forceinline__ uint32_t nz01(uint32_t b) {   // 0x01 in every byte of b that is non-zero
