@@ -145,12 +145,14 @@ def test_tick_kernels_do_not_spill():
     import re
     seen = set()
     for name, r in ticks.items():
-        m = re.search(r"ELb([01])ELb([01])E", name)   # step_kernel<WPB, MT, FUSED, XE>
+        m = re.search(r"ELi(\d+)ELb([01])ELb([01])E", name)   # step_kernel<WPB, MT, FUSED, XE>
         assert m, name
-        fused, xe = m.group(1) == "1", m.group(2) == "1"
+        mt, fused, xe = int(m.group(1)), m.group(2) == "1", m.group(3) == "1"
         seen.add((fused, xe))
-        if fused or xe:   # register-capped variants (128 / 80 VGPRs): a few cold spills are tolerated
-            assert r["scratch"] <= 256, (name, r)
+        if fused and not xe and mt:   # the rollout kernel at a compile-time size: spills here meant flat
+            assert r["scratch"] == 0 and r.get("vgpr_spill", 0) == 0, (name, r)   # addressing (generic pointers), -25 %
+        elif fused or xe:   # register-capped variants (run-time size, cold extra-edge code): a few spills are tolerated
+            assert r["scratch"] <= 160, (name, r)
         else:             # the lean per-tick kernel: no scratch at all
             assert r["scratch"] == 0 and r.get("vgpr_spill", 0) == 0, (name, r)
             assert r["vgprs"] <= 128, (name, r)
