@@ -38,6 +38,17 @@ if os.environ.get("CYGYM_STAMP_ROLLOUT"):   # phases of the LAST tick of a T-tic
         for a in sorted(set(at.tolist())):
             m = at == a
             print(f"   atype {int(a):3d}: n={int(m.sum()):5d} tick mean {tot[m].mean():8.0f} max {tot[m].max():8d}  top {seg[m, 0].mean():7.0f} action {seg[m, 1].mean():8.0f} work {seg[m, 2].mean():6.0f} counts {seg[m, 3].mean():6.0f} obs {seg[m, 4].mean():6.0f} evolve {seg[m, 5].mean():6.0f}")
+        if int(d[0, 9]) == 1 and (at == 1).any():
+            sub = d[at == 1]
+            print("   spread sub-phases (mean cycles): setup", int((sub[:, 10] - sub[:, 1]).mean()), "rounds", int((sub[:, 11] - sub[:, 10]).mean()),
+                  "logcnt", int((sub[:, 12] - sub[:, 11]).mean()), "ring", int((sub[:, 13] - sub[:, 12]).mean()),
+                  "apply", int((sub[:, 14] - sub[:, 13]).mean()), " n_rounds mean", sub[:, 15].mean(), "max", sub[:, 15].max())
+        if int(d[0, 9]) == 0:
+            for aa in (6, 9):
+                if (at == aa).any():
+                    sub = d[at == aa]
+                    print(f"   action {aa}: pre {int((sub[:, 10] - sub[:, 1]).mean())} loop {int((sub[:, 11] - sub[:, 10]).mean())} (max {int((sub[:, 11] - sub[:, 10]).max())}) rest {int((sub[:, 2] - sub[:, 11]).mean())}"
+                          f" passes mean {sub[:, 15].mean():.2f} max {sub[:, 15].max()} entries mean {sub[:, 14].mean():.1f}")
     sys.exit(0)
 for t in range(40):
     env.gen_actions(t)
