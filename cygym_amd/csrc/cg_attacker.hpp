@@ -190,8 +190,8 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
         while (nm) {
           const int src_lane = __builtin_ctzll(nm);
           nm &= nm - 1;
-          const int ls = __shfl(s, src_lane), lo1 = __shfl(o1, src_lane), lk0 = __shfl(k0, src_lane);
-          const int lst = __shfl((int)st, src_lane);
+          const int ls = __builtin_amdgcn_readlane(s, src_lane), lo1 = __builtin_amdgcn_readlane(o1, src_lane), lk0 = __builtin_amdgcn_readlane(k0, src_lane);
+          const int lst = __builtin_amdgcn_readlane((int)st, src_lane);
           int k = spread_scan_coop(e, T, ls, lst & CG_D_DC, round == 0 ? lk0 : lk0 + 1, lo1);
           if (k != lk0) changed = true;
           if (e.lane == 0) {
@@ -236,7 +236,7 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
         const int i = b0 + e.lane;
         int n = i < n_src ? cntv[i] : 0;
         int incl = wave_incl_scan(n, e.lane);
-        int blk_total = __shfl(incl, 63);
+        int blk_total = __builtin_amdgcn_readlane(incl, 63);
         uint32_t cbase = after - (uint32_t)blk_total;
         uint32_t off = cbase + (uint32_t)(incl - n);
         bool mine = n > 0 && off + (uint32_t)n > lo;
@@ -271,8 +271,8 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
         while (lm) {
           int ll = __builtin_ctzll(lm);
           lm &= lm - 1;
-          int ls = __shfl(s, ll);
-          uint32_t idx0 = __shfl(off, ll);
+          int ls = __builtin_amdgcn_readlane(s, ll);
+          uint32_t idx0 = (uint32_t)__builtin_amdgcn_readlane((int)off, ll);
           int o0 = e.optr[ls], o1 = e.optr[ls + 1];
           int last = cur[ls] < o1 ? (int)cur[ls] : o1 - 1;
           for (int k0 = o0; k0 <= last; k0 += WAVE) {

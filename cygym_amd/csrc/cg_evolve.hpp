@@ -148,7 +148,7 @@ __device__ __forceinline__ void evolve(Env& e, const KP& P) {
         }
         const int incl = wave_incl_scan(w, e.lane);
         cdf[d] = (uint32_t)(total + incl);
-        total += __shfl(incl, 63);
+        total += __builtin_amdgcn_readlane(incl, 63);
       }
       wsync();
 #pragma nounroll

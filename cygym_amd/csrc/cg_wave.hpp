@@ -14,30 +14,29 @@ __device__ __forceinline__ int below(uint64_t m) {  // set bits of m below this 
   return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ int wave_or(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o);
+// Wave-wide inclusive scans on the VALU's DPP path (no LDS permutes): prefix within each row of 16 lanes with
+// row_shr 1/2/4/8, then lane 15 of rows 0/2 into rows 1/3 (row_bcast15) and lane 31 into rows 2/3 (row_bcast31).
+// Every lane must be active (all call sites are in wave-uniform control flow).
+#define CG_DPP(v, ctrl, rmask) __builtin_amdgcn_update_dpp(0, (v), (ctrl), (rmask), 0xf, false)
+__device__ __forceinline__ int dpp_scan_add(int v) {
+  v += CG_DPP(v, 0x111, 0xf); v += CG_DPP(v, 0x112, 0xf); v += CG_DPP(v, 0x114, 0xf); v += CG_DPP(v, 0x118, 0xf);
+  v += CG_DPP(v, 0x142, 0xa); v += CG_DPP(v, 0x143, 0xc);
   return v;
 }
+__device__ __forceinline__ int dpp_scan_or(int v) {
+  v |= CG_DPP(v, 0x111, 0xf); v |= CG_DPP(v, 0x112, 0xf); v |= CG_DPP(v, 0x114, 0xf); v |= CG_DPP(v, 0x118, 0xf);
+  v |= CG_DPP(v, 0x142, 0xa); v |= CG_DPP(v, 0x143, 0xc);
+  return v;
+}
+__device__ __forceinline__ int wave_or(int v) { return __builtin_amdgcn_readlane(dpp_scan_or(v), 63); }
 // sum of a small per-lane count (< 2^bits) with `bits` ballots (SALU popcounts; no LDS permutes)
 __device__ __forceinline__ int wave_sum_bits(int v, int bits) {
   int t = 0;
   for (int b = 0; b < bits; ++b) t += __popcll(ballot((v >> b) & 1)) << b;
   return t;
 }
-__device__ __forceinline__ int wave_sum(int v) {   // general (permute-based); rare paths only
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    int n = __shfl_up(v, o);
-    if (lane >= o) v += n;
-  }
-  return v;
-}
+__device__ __forceinline__ int wave_sum(int v) { return __builtin_amdgcn_readlane(dpp_scan_add(v), 63); }
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) { (void)lane; return dpp_scan_add(v); }
 __device__ __forceinline__ int nth_bit(uint64_t m, int r) {  // position of the r-th set bit (uniform)
   for (int i = 0; i < r; ++i) m &= m - 1;
   return __builtin_ctzll(m);
