@@ -72,7 +72,7 @@ __device__ __forceinline__ WaveAux env_setup(Env& e, uint8_t* smem, const KP& P,
 // FUSED: cygym_rollout (n_ticks > 1).  The per-env scalars are parked in LDS between ticks so that they are
 // not loop-carried registers; the single-tick instantiation has a compile-time trip count of 1.
 template <int WPB, int MT, bool FUSED, bool XE>
-__global__ __launch_bounds__(WPB * WAVE, FUSED ? 4 : (XE ? CG_LB : 1)) void step_kernel(const KParams P0) {
+__global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? CG_LB : 1)) void step_kernel(const KParams P0) {
   extern __shared__ __align__(16) uint8_t smem[];
   // every use below goes through `P`: the kernarg copy for the single-tick kernel, the device copy for the
   // fused one (so that it can be re-read, opaquely, at the top of every tick)

@@ -35,6 +35,9 @@
 #include <new>
 #include "cygym_abi.h"
 
+#ifndef CG_FUSED_LB
+#define CG_FUSED_LB 4
+#endif
 #ifndef CG_LB
 #define CG_LB 6
 #endif
