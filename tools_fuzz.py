@@ -30,7 +30,9 @@ def main():
     ap.add_argument("--cases", type=int, default=40)
     ap.add_argument("--seed0", type=int, default=0)
     ap.add_argument("--ticks", type=int, default=300)
+    ap.add_argument("--sizes", default="13,16,24,37,64,100,130,200,256,300,520", help="device counts to draw from")
     a = ap.parse_args()
+    sizes = [int(x) for x in a.sizes.split(",")]
     import torch
     import golden_io as gio
     from cygym_amd import abi, spec as S
@@ -42,11 +44,11 @@ def main():
     t_start = time.time()
     for case in range(a.seed0, a.seed0 + a.cases):
         rs = np.random.RandomState(1000 + case)
-        M = int(rs.choice([13, 16, 24, 37, 64, 100, 130, 200, 256, 300, 520]))
-        blocks = int(rs.choice([1, 1, 2, 4])) if M >= 16 else 1
+        M = int(rs.choice(sizes))
+        blocks = (int(rs.choice([1, 1, 2, 4])) if M >= 16 else 1) * (8 if M >= 1024 else 1)
         n_active = int(rs.randint(max(3, M // 3), M + 1))
         K = int(rs.choice([0, 4, 16, 64, 128, 256]))
-        N = int(rs.choice([33, 64, 96]))
+        N = int(rs.choice([33, 64, 96])) if M <= 520 else int(rs.choice([9, 17]))
         L = int(rs.choice([1, 2, max(1, M // 8), max(2, M // 4) & ~1, 7]))
         G = int(rs.choice([1, 1, 3]))                      # > 1: some ticks are step_grouped() calls
         baseline = str(rs.choice(["Nash", "Nash", "Nash", "No Defense", "Preset", "No Attack"]))
