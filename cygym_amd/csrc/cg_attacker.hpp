@@ -21,8 +21,14 @@ __device__ __forceinline__ void spread_take(uint32_t* T, int v, int s) {
 // first slot k in [from, o1) that source s can take, or o1
 __device__ __forceinline__ int spread_scan_lane(const Env& e, const uint32_t* T, int s, bool dc,
                                                 int from, int o1) {
-  for (int k = from; k < o1; ++k) {
-    if (e.blocked(k)) continue;
+  if (from >= o1) return o1;
+  // the row (<= LONG_ROW slots) spans at most two words of the blocked bitmask: read them once, not per slot
+  const int w0 = from >> 5;
+  uint64_t bits = e.blk[w0];
+  if (((o1 - 1) >> 5) != w0) bits |= (uint64_t)e.blk[w0 + 1] << 32;
+  bits >>= (from & 31);   // bit i <-> slot from + i
+  for (int k = from; k < o1; ++k, bits >>= 1) {
+    if (bits & 1ull) continue;
     if (dc || spread_ok(T, e.ocol[k], s)) return k;
   }
   return o1;
