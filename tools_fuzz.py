@@ -7,8 +7,9 @@ Each case draws a topology size, activity level, evolve parameters (events, addi
 activations), extra-edge capacity (including too small ones), list capacity, an optional ownership reshuffle and
 episode cap, baseline mode and group capacity, then steps both sides with the synthetic script -- every third
 tick with a hand-aimed block / unblock / clean on attacker-owned devices, some ticks as step_grouped() calls,
-some envs sitting a tick out or taking a partial tick -- and compares the whole state bit for bit every few
-ticks, plus a fused rollout of the same script at the end.  Prints one line per case; exits non-zero on the first mismatch.
+some envs sitting a tick out or taking a partial tick, in 40 % of the cases with host-side calls between ticks
+(reset / reshuffle of a random subset, baseline and reward-scale changes, role observations) -- and compares the
+whole state bit for bit every few ticks, plus a fused rollout of the same script at the end.  Prints one line per case; exits non-zero on the first mismatch.
 TEST INFRASTRUCTURE (uses oracle/): not part of the product path.
 """
 from __future__ import annotations
@@ -69,7 +70,25 @@ def main():
             for b in (env, fused, ob):
                 b.randomize()
         script = []
+        meddle = rs.rand() < 0.4      # host-side calls between ticks (then no fused replay of the script)
         for t in range(ticks):
+            if meddle and t and t % 23 == 0:   # reset / reshuffle a random subset, flip the baseline, like do_agent.py:189-196
+                ids = np.flatnonzero(rs.rand(N) < 0.3).astype(np.int32)
+                if ids.size:
+                    what = int(rs.randint(3))
+                    if what == 0:
+                        env.reset(ids); ob.reset(ids)
+                    elif what == 1:
+                        env.randomize(ids); ob.randomize(ids)
+                    else:
+                        import dataclasses
+                        cfg = dataclasses.replace(cfg, baseline=str(rs.choice(["Nash", "No Defense", "Preset", "No Attack"])),
+                                                  comp_scale=float(rs.choice([50.0, 10.0])))
+                        env.set_config(cfg); ob.cfg = cfg
+                for role in (1, 2):
+                    if not np.array_equal(env.observe(role).cpu().numpy(), ob.observe(role)):
+                        print(f"case {case}: role-{role} observation differs at tick {t}")
+                        sys.exit(1)
             act = gen_actions_numpy(cfg.seed, cfg.env_id_base, N, M, topo.X, t, L)
             if t % 3 == 0:
                 fl = ob.state["flags"]
@@ -131,6 +150,12 @@ def main():
                 print(f"case {case}: MISMATCH at tick {t}: M={M} blocks={blocks} n_active={n_active} K={K} N={N} L={L} "
                       f"shuffle={shuffle} cfg={ck}\n  " + "\n  ".join(bad[:6]))
                 sys.exit(1)
+        if meddle:
+            nxmax = int((ob.state["ienv"][:, S.I_FLAGS].astype(np.int64) >> S.E_NX_SHIFT).max())
+            print(f"case {case}: ok  M={M} K={K} N={N} L={L} G={G} with host-side resets / reshuffles / config changes "
+                  f"ticks={ticks} max_extra_edges={nxmax} [{time.time() - t_start:.0f}s]", flush=True)
+            env.close(); fused.close()
+            continue
         # the same script as ONE fused rollout must land in the same state
         r_act, r_out = fused.alloc_rollout(ticks)
         for k in r_act:
