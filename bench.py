@@ -40,7 +40,7 @@ WORKLOADS = {
 }
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PMC_SUMMARY = "r01_v9_target_pmc_summary.json"
+PMC_SUMMARY = "r01_v10_target_pmc_summary.json"
 
 
 def algorithmic_bytes(M: int, E: int) -> float:
@@ -64,10 +64,11 @@ def main():
     ap.add_argument("--envs", type=int, default=0, help="override envs per GPU")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--max-extra", type=int, default=-1,
-                    help="capacity of the per-env list of edges evolve_network may add; -1 (default): the topology "
-                         "generator's default (room for two attacker stars), i.e. the kernels that implement the whole "
-                         "tick; 0: no list (lambda_events = 0 never adds an edge anyway), lean kernels")
+    ap.add_argument("--max-extra", type=int, default=0,
+                    help="capacity of the per-env list of edges evolve_network may add.  0 (default): no list -- this is the "
+                         "fixed-topology run of SURVEY.md 8d (lambda_events = 0 can never add an edge; bench.py checks that "
+                         "no env wanted one), lean kernels; -1: the topology generator's default (room for two attacker "
+                         "stars), i.e. the kernels that also follow added edges (about 1 %% slower at 4096 x 256)")
     ap.add_argument("--cpu-seconds", type=float, default=16.0)
     ap.add_argument("--fused", type=int, default=-1,
                     help="ticks per cygym_rollout launch (-1 = all K steps in one launch, 0 = skip the rollout leg)")
