@@ -164,7 +164,7 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
     }
     wsync();
     SUBSTAMP(10);
-    int n_rounds = 0;
+    [[maybe_unused]] int n_rounds = 0;   // read by the stamps of diagnostic builds
     // fix-point rounds: a source re-examines its pick and, if an earlier source took it, resumes the scan
     for (int round = 0; round <= M + 1; ++round) {
       ++n_rounds;

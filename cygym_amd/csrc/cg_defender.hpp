@@ -293,7 +293,7 @@ __device__ __forceinline__ void def_per_device(Env& e, const KP& P, int at, cons
       uint64_t am = ballot(d >= 0);
       n_act += __popcll(am);
       SUBSTAMP(10);
-      int n_pass = 0;
+      [[maybe_unused]] int n_pass = 0;   // read by the stamps of diagnostic builds
       // Speculate: every remaining entry picks on the bitmasks as they stand.  An entry is exact unless an
       // EARLIER remaining entry flips an edge ending at its device (or is the same device); apply the exact
       // prefix in parallel and repeat from the first inexact entry (at least one entry retires per pass).
