@@ -207,7 +207,7 @@ int cygym_gen_actions(cygym_handle* h, int32_t tick, int32_t* mode, int32_t* n_g
 int cygym_timer_start(cygym_handle* h, void* stream);
 int cygym_timer_stop(cygym_handle* h, void* stream, float* ms);
 
-/* Diagnostic builds only (-DCG_STAMPS, tools_stamps.py): `stamps` = DEVICE int64 [N][16] receiving per-phase
+/* Diagnostic builds only (-DCG_STAMPS, tools/stamps.py): `stamps` = DEVICE int64 [N][16] receiving per-phase
  * s_memtime stamps of every env's last tick, or NULL to switch them off.  Ignored by the product build. */
 int cygym_set_debug(cygym_handle* h, void* stamps);
 

@@ -318,12 +318,12 @@ def test_rollout_with_added_edges(M, blocks, N, T, max_extra):
 
 
 def test_differential_fuzz_sample(monkeypatch):
-    """A slice of tools_fuzz.py (random sizes, evolve parameters, extra-edge capacities incl. too small ones,
+    """A slice of tools/fuzz.py (random sizes, evolve parameters, extra-edge capacities incl. too small ones,
     reshuffled ownership, episode caps; per-tick vs oracle and fused vs per-tick).  The full campaign
     (1500 cases x 300 ticks, all agreeing) is run by hand on the GPU box; see DESIGN.md section 5."""
     import sys
     import os
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-    import tools_fuzz
-    monkeypatch.setattr(sys, "argv", ["tools_fuzz.py", "--cases", "16", "--seed0", "5000", "--ticks", "150"])
-    tools_fuzz.main()   # exits non-zero (SystemExit) on the first mismatch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import fuzz
+    monkeypatch.setattr(sys, "argv", ["tools/fuzz.py", "--cases", "16", "--seed0", "5000", "--ticks", "150"])
+    fuzz.main()   # exits non-zero (SystemExit) on the first mismatch

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""tools_fuzz.py -- differential fuzzing of the HIP tick against the CPU oracle (GPU box only).
+"""tools/fuzz.py -- differential fuzzing of the HIP tick against the CPU oracle (GPU box only).
 
-    python tools_fuzz.py [--cases 40] [--seed0 0] [--ticks 300]
+    python tools/fuzz.py [--cases 40] [--seed0 0] [--ticks 300]
 
 Each case draws a topology size, activity level, evolve parameters (events, additions, attacker-owned
 activations), extra-edge capacity (including too small ones), list capacity, an optional ownership reshuffle and
@@ -21,7 +21,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

@@ -1,8 +1,8 @@
 """Diagnostic: per-phase cycle shares of the tick kernel (build with -DCG_STAMPS).
-Usage on the GPU box: python tools_stamps.py [envs] [M]"""
+Usage on the GPU box: python tools/stamps.py [envs] [M]"""
 import ctypes as C, os, subprocess, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.abspath(__file__)); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from cygym_amd import abi, build as B
 so = os.path.join(ROOT, "cygym_amd", "libcygym_hip_stamps.so")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DCG_STAMPS",
