@@ -223,3 +223,26 @@ def test_create_rejects_malformed_input_before_touching_the_gpu():
     if not torch.cuda.is_available():
         rc, msg = _create(topo, cfg)
         assert rc == EHIP and msg
+
+
+def test_profile_summary_parser(tmp_path):
+    """tools/profile.py: per-kernel-class means from rocprofv3 counter CSVs (per_tick vs rollout kernel, counters
+    summed over a dispatch's rows)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("cg_tools_profile", os.path.join(ROOT, "tools", "profile.py"))
+    tp = importlib.util.module_from_spec(spec)   # loaded by path: a bare `import profile` would be the stdlib module
+    spec.loader.exec_module(tp)
+    d = tmp_path / "pmc" / "run"
+    d.mkdir(parents=True)
+    rows = ['"Correlation_Id","Dispatch_Id","Kernel_Name","Counter_Name","Counter_Value"']
+    tick = "void (anonymous namespace)::step_kernel<8, 256, false, false>((anonymous namespace)::KParams)"
+    roll = "void (anonymous namespace)::step_kernel<8, 256, true, false>((anonymous namespace)::KParams)"
+    for disp, name, vals in ((1, tick, (10.0, 30.0)), (2, tick, (20.0, 20.0)), (3, roll, (1000.0, 1000.0)), (4, "other_kernel", (5.0, 5.0))):
+        for v in vals:   # two rows per dispatch (e.g. per XCD): summed
+            rows.append(f'{disp},{disp},"{name}","WRITE_SIZE",{v}')
+    (d / "1_counter_collection.csv").write_text("\n".join(rows) + "\n")
+    s = tp.summarize_pmc([str(tmp_path / "pmc")], steps=200)
+    assert s["per_tick"]["WRITE_SIZE"] == {"launches": 2, "mean_per_launch": 40.0} and s["per_tick"]["ticks_per_launch"] == 1
+    assert s["fused"]["WRITE_SIZE"] == {"launches": 1, "mean_per_launch": 2000.0} and s["fused"]["ticks_per_launch"] == 200
+    assert tp.kernel_class("_ZN12_GLOBAL__N_111step_kernelILi8ELi256ELb1ELb0EEEvNS_7KParamsE") == "fused"
+    assert tp.kernel_class("gen_actions_kernel") is None
