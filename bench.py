@@ -184,7 +184,7 @@ def main():
                 r = leg["roofline"]
                 r["traffic"] = kb * 1024.0 / ticks_pmc * r["ticks_per_launch"]
                 r["traffic_unit"] = "bytes per launch"
-                r["traffic_source"] = f"profiles/{PMC_SUMMARY} (rocprofv3 --pmc passes of this command, tools/profile.py)"
+                r["traffic_source"] = f"profiles/{PMC_SUMMARY} (rocprofv3 --pmc passes of this command, tools/rocprof_summary.py)"
         except Exception:
             pass
     if rank == 0:

@@ -323,7 +323,10 @@ def test_differential_fuzz_sample(monkeypatch):
     (1500 cases x 300 ticks, all agreeing) is run by hand on the GPU box; see DESIGN.md section 5."""
     import sys
     import os
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
-    import fuzz
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools", "fuzz.py")
+    spec = importlib.util.spec_from_file_location("cg_tools_fuzz", path)
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
     monkeypatch.setattr(sys, "argv", ["tools/fuzz.py", "--cases", "16", "--seed0", "5000", "--ticks", "150"])
     fuzz.main()   # exits non-zero (SystemExit) on the first mismatch

@@ -226,11 +226,11 @@ def test_create_rejects_malformed_input_before_touching_the_gpu():
 
 
 def test_profile_summary_parser(tmp_path):
-    """tools/profile.py: per-kernel-class means from rocprofv3 counter CSVs (per_tick vs rollout kernel, counters
+    """tools/rocprof_summary.py: per-kernel-class means from rocprofv3 counter CSVs (per_tick vs rollout kernel, counters
     summed over a dispatch's rows)."""
     import importlib.util
-    spec = importlib.util.spec_from_file_location("cg_tools_profile", os.path.join(ROOT, "tools", "profile.py"))
-    tp = importlib.util.module_from_spec(spec)   # loaded by path: a bare `import profile` would be the stdlib module
+    spec = importlib.util.spec_from_file_location("cg_tools_profile", os.path.join(ROOT, "tools", "rocprof_summary.py"))
+    tp = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(tp)
     d = tmp_path / "pmc" / "run"
     d.mkdir(parents=True)

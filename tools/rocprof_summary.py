@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/profile.py -- turn rocprofv3 output of `python3 bench.py ...` into the summaries kept under profiles/.
+"""tools/rocprof_summary.py -- turn rocprofv3 output of `python3 bench.py ...` into the summaries kept under profiles/.
 
 Recipe (on the GPU box; counters in their own passes, never together with a trace):
 
@@ -7,7 +7,7 @@ Recipe (on the GPU box; counters in their own passes, never together with a trac
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt  -- python3 bench.py --no-cpu-baseline
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --no-cpu-baseline
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --no-cpu-baseline
-  python3 tools/profile.py --steps 200 --kernel-stats $OUT/kt --pmc $OUT/pmc_fetch $OUT/pmc_write \
+  python3 tools/rocprof_summary.py --steps 200 --kernel-stats $OUT/kt --pmc $OUT/pmc_fetch $OUT/pmc_write \
           --out-stats profiles/rNN_target_kernel_stats.csv --out-pmc profiles/rNN_target_pmc_summary.json
 
 The PMC summary holds, per kernel class (`per_tick` = step_kernel<.., FUSED=0>, `fused` = step_kernel<.., FUSED=1>),
