@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--cases", type=int, default=40)
     ap.add_argument("--seed0", type=int, default=0)
     ap.add_argument("--ticks", type=int, default=300)
+    ap.add_argument("--envs", type=int, default=0, help="fix the batch size (default: 33..96, or 9..17 above 520 devices)")
     ap.add_argument("--sizes", default="13,16,24,37,64,100,130,200,256,300,520", help="device counts to draw from")
     a = ap.parse_args()
     sizes = [int(x) for x in a.sizes.split(",")]
@@ -50,6 +51,8 @@ def main():
         n_active = int(rs.randint(max(3, M // 3), M + 1))
         K = int(rs.choice([0, 4, 16, 64, 128, 256]))
         N = int(rs.choice([33, 64, 96])) if M <= 520 else int(rs.choice([9, 17]))
+        if a.envs:
+            N = a.envs
         L = int(rs.choice([1, 2, max(1, M // 8), max(2, M // 4) & ~1, 7]))
         G = int(rs.choice([1, 1, 3]))                      # > 1: some ticks are step_grouped() calls
         baseline = str(rs.choice(["Nash", "Nash", "Nash", "No Defense", "Preset", "No Attack"]))
