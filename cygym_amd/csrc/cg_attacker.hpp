@@ -179,11 +179,22 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
           o0 = e.optr[s]; o1 = e.optr[s + 1]; k0 = cur[s]; st = e.dst[s];
           const bool dc = st & CG_D_DC;
           int k = k0;
+          const bool shortrow = o1 - o0 <= LONG_ROW;
+          const bool full = !shortrow && (st & CG_D_FULLROW) && !dc;
           if (COLD(xany && x_isout(e, s))) {   // row with added edges: handled by spread_x_round below
-          } else if (o1 - o0 <= LONG_ROW) k = spread_scan_lane(e, T, s, dc, k0, o1);
-          else if ((st & CG_D_FULLROW) && !dc) {
-            if (!(k0 < o1 && !e.blocked(k0) && spread_ok(T, e.ocol[k0], s)))
-              k = spread_scan_full(e, T, cand, s, round == 0 ? k0 : k0 + 1, o0, o1);
+          } else if (shortrow || full) {
+            // Short rows and full rows share ONE re-examination of the current pick (rounds > 0): under divergence a
+            // wave runs both arms one after the other, so only the lanes that lost their pick may enter a scan.
+            bool keep = false;
+            if (round > 0 && k0 < o1) {
+              const int vc = full ? (k0 - o0) + ((k0 - o0) >= s ? 1 : 0) : (int)e.ocol[k0];
+              keep = !e.blocked(k0) && (dc || spread_ok(T, vc, s));
+            }
+            if (!keep) {
+              const int from = round == 0 ? k0 : k0 + 1;
+              if (shortrow) k = spread_scan_lane(e, T, s, dc, from, o1);
+              else          k = spread_scan_full(e, T, cand, s, from, o0, o1);
+            }
           } else {
             coop = round == 0 || (k0 < o1 && !(dc || spread_ok(T, e.ocol[k0], s)));
           }

@@ -5,7 +5,7 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from cygym_amd import abi, build as B
 so = os.path.join(ROOT, "cygym_amd", "libcygym_hip_stamps.so")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DCG_STAMPS",
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DCG_STAMPS", *os.environ.get("CYGYM_EXTRA_FLAGS", "").split(),
                        "-I" + B.INC, "-o", so, os.environ.get("CYGYM_SRC", B.SRC)])
 from cygym_amd import _lib
 _lib.SO = so
