@@ -132,9 +132,11 @@ struct PoolPtrs {
   const uint16_t *optr, *ocol;           // LDS
   const uint16_t *icol, *ieid, *oeid;    // global
 };
+template <bool WIDE>
 __device__ __forceinline__ Pick pool_pick(const PoolPtrs q, bool want, uint32_t u, int o0, int o1, int i0, int i1) {
   Pick p; p.slot = -1; p.j = -1; p.x = -1;
-  const int nbo = range_popc(q.blk, o0, o1), nbi = range_popc(q.bin, i0, i1);
+  const int nbo = WIDE ? range_popc_wide(q.blk, o0, o1) : range_popc(q.blk, o0, o1);
+  const int nbi = WIDE ? range_popc_wide(q.bin, i0, i1) : range_popc(q.bin, i0, i1);
   const int n_out = want ? nbo : (o1 - o0) - nbo;
   const int n_in = want ? nbi : (i1 - i0) - nbi;
   const int n = n_out + n_in;
@@ -250,7 +252,7 @@ __device__ __forceinline__ void block_seq(Env& e, const PoolPtrs q, const int16_
   }
 }
 
-template <bool XE, class KP>
+template <bool XE, bool WIDE, class KP>
 __device__ __forceinline__ void def_per_device(Env& e, const KP& P, int at, const int16_t* dev, int L, int app,
                                                double& cost, bool& dirty, int32_t* ie, double* fe) {
   const double ds = P.c.def_scale;
@@ -305,7 +307,7 @@ __device__ __forceinline__ void def_per_device(Env& e, const KP& P, int at, cons
         if (mine) {
           uint32_t uu = u;
           if (!simple) { const int b = occ[d]; if (b > 0) uu = e.draw(site, d, b); }
-          pk = pool_pick(q, want, uu, o0, o1, i0, i1);
+          pk = pool_pick<WIDE>(q, want, uu, o0, o1, i0, i1);
           if (pk.slot >= 0) atomicMin(&fh[pk.x], (uint32_t)e.lane);
           if (!simple) atomicMin(&fh[d], (uint32_t)e.lane);   // a repeated device must wait for its first occurrence
         }

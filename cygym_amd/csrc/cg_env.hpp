@@ -66,6 +66,25 @@ __device__ __forceinline__ int range_popc(const uint32_t* blk, int a, int b) {
   }
   return n;
 }
+// The same count with up to nine words read at once (any row of <= 256 slots): nine independent reads, one LDS
+// latency.  For per-lane callers whose rows differ a lot in length (block / unblock pools: a full row next to a
+// two-entry row) the rolled loop above makes every lane wait out the longest row, one word per trip.  It costs
+// registers, so only the per-tick kernel -- whose launch lasts as long as its slowest env -- uses it.
+__device__ __forceinline__ int range_popc_wide(const uint32_t* blk, int a, int b) {
+  if (a >= b) return 0;
+  const int w0 = a >> 5, w1 = (b - 1) >> 5;
+  if (w1 - w0 >= 9) return range_popc(blk, a, b);
+  int n = 0;
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    const int w = w0 + j;
+    uint32_t x = blk[w <= w1 ? w : w1];
+    if (j == 0) x &= 0xFFFFFFFFu << (a & 31);
+    if (w == w1 && ((b & 31) != 0)) x &= 0xFFFFFFFFu >> (32 - (b & 31));
+    n += w <= w1 ? __popc(x) : 0;
+  }
+  return n;
+}
 // slot of the r-th entry in [a, b) whose blocked bit == want (uniform); r must be in range
 __device__ __forceinline__ int range_select(const uint32_t* blk, int a, int b, bool want, int r) {
   const int w0 = a >> 5, w1 = (b - 1) >> 5;

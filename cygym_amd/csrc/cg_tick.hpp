@@ -71,7 +71,7 @@ __device__ __forceinline__ WaveAux env_setup(Env& e, uint8_t* smem, const KP& P,
 
 // FUSED: cygym_rollout (n_ticks > 1).  The per-env scalars are parked in LDS between ticks so that they are
 // not loop-carried registers; the single-tick instantiation has a compile-time trip count of 1.
-template <int WPB, int MT, bool FUSED, bool XE>
+template <int WPB, int MT, bool FUSED, bool XE, bool WIDE>
 __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? CG_LB : 1)) void step_kernel(const KParams P0) {
   extern __shared__ __align__(16) uint8_t smem[];
   // every use below goes through `P`: the kernarg copy for the single-tick kernel, the device copy for the
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? CG_LB : 1))
       if (P.c.baseline != 0) at = 8;   // :913-914
       def_global(e, P, at, devs, Ld, cost, dirty, false, ie, fe);
       if (at == 1 || at == 4 || at == 5 || at == 6 || at == 7 || at == 9 || at == 12 || at == 13)
-        if (Ld > 0) def_per_device<XE>(e, P, at, devs, Ld, app0, cost, dirty, ie, fe);
+        if (Ld > 0) def_per_device<XE, WIDE>(e, P, at, devs, Ld, app0, cost, dirty, ie, fe);
     } else if (P.c.baseline != 3 && (at == 1 || at == 2)) {
 #pragma unroll
       for (int c = 0; c < MC; ++c) {   // :1127 snapshot of the sources

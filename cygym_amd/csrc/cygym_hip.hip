@@ -70,6 +70,7 @@ struct cygym_handle {
   void* dev_blob;       // one allocation holding the topology copies
   uint32_t* keybuf;     // randomize scratch [n_envs][Mp]
   int wpb, max_devs;
+  bool few_waves;       // n_envs <= 16 per CU: one wave per env cannot use more than 4 waves per SIMD
   int wave_lds, shared_lds;
   hipEvent_t ev0, ev1;
   KParams* dparams;     // device copy of the launch parameters (read by the fused kernel)
@@ -91,28 +92,32 @@ static int fail(cygym_handle* h, int code, const char* fmt, const char* detail) 
     if (_e != hipSuccess) return fail(h, CYGYM_EHIP, #call ": %s", hipGetErrorString(_e)); \
   } while (0)
 
-template <int MT, bool FUSED, bool XE>
+template <int MT, bool FUSED, bool XE, bool WIDE>
 static const void* kernel_for(int wpb) {
   switch (wpb) {
-    case 16: return (const void*)step_kernel<16, MT, FUSED, XE>;
-    case 8: return (const void*)step_kernel<8, MT, FUSED, XE>;
-    case 4: return (const void*)step_kernel<4, MT, FUSED, XE>;
-    case 2: return (const void*)step_kernel<2, MT, FUSED, XE>;
-    default: return (const void*)step_kernel<1, MT, FUSED, XE>;
+    case 16: return (const void*)step_kernel<16, MT, FUSED, XE, WIDE>;
+    case 8: return (const void*)step_kernel<8, MT, FUSED, XE, WIDE>;
+    case 4: return (const void*)step_kernel<4, MT, FUSED, XE, WIDE>;
+    case 2: return (const void*)step_kernel<2, MT, FUSED, XE, WIDE>;
+    default: return (const void*)step_kernel<1, MT, FUSED, XE, WIDE>;
   }
 }
-template <bool FUSED, bool XE>
+template <bool FUSED, bool XE, bool WIDE>
 static const void* kernel_for_m(const cygym_handle* h) {
-  if (h->t.M == 256) return kernel_for<256, FUSED, XE>(h->wpb);
-  if (h->t.M == 64) return kernel_for<64, FUSED, XE>(h->wpb);
-  return kernel_for<0, FUSED, XE>(h->wpb);
+  if (h->t.M == 256) return kernel_for<256, FUSED, XE, WIDE>(h->wpb);
+  if (h->t.M == 64) return kernel_for<64, FUSED, XE, false>(h->wpb);   // rows of <= 3 words: nothing to gain (measured: -9 %)
+  return kernel_for<0, FUSED, XE, false>(h->wpb);   // run-time M: the wide variant would spill
 }
 // XE: the kernel that follows the edges evolve_network adds (max_extra_edges > 0).  With no extra-edge list
 // the lean instantiation runs: none of that code is in it.
+// WIDE (lean per-tick kernel only): the block / unblock pools count their bits nine words at a time.  That costs
+// registers (108 VGPRs: 4 waves per SIMD), so it is used when the batch cannot fill more than that anyway
+// (envs <= 16 per CU) -- there a launch lasts as long as its slowest env, and block / unblock is that env.
 static const void* pick_kernel(const cygym_handle* h, bool fused) {
   const bool xe = h->t.K > 0;
-  if (fused) return xe ? kernel_for_m<true, true>(h) : kernel_for_m<true, false>(h);
-  return xe ? kernel_for_m<false, true>(h) : kernel_for_m<false, false>(h);
+  if (fused) return xe ? kernel_for_m<true, true, false>(h) : kernel_for_m<true, false, false>(h);
+  if (xe) return kernel_for_m<false, true, false>(h);
+  return h->few_waves ? kernel_for_m<false, false, true>(h) : kernel_for_m<false, false, false>(h);
 }
 static hipError_t set_lds_attr(cygym_handle* h) {
   const int lds = h->shared_lds + h->wave_lds * h->wpb;
@@ -218,6 +223,11 @@ int cygym_create(const cygym_topology* topo, const cygym_config* cfg, int32_t n_
   h->device_id = device_id; h->n_envs = n_envs; h->c = *cfg;
   hipError_t e0 = hipSetDevice(device_id);
   if (e0 != hipSuccess) { fail(nullptr, CYGYM_EHIP, "hipSetDevice: %s", hipGetErrorString(e0)); delete h; return CYGYM_EHIP; }
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || cus <= 0) cus = 256;
+    h->few_waves = (long long)n_envs <= 16LL * cus && !getenv("CYGYM_NO_WIDE");
+  }
   DevTopo& t = h->t;
   t.M = M; t.X = X; t.E = E; t.EW = (E + 31) / 32 > 0 ? (E + 31) / 32 : 1;
   t.MC = (M + WAVE - 1) / WAVE; t.Mp = t.MC * WAVE;

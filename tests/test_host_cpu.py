@@ -145,7 +145,7 @@ def test_tick_kernels_do_not_spill():
     import re
     seen = set()
     for name, r in ticks.items():
-        m = re.search(r"ELi(\d+)ELb([01])ELb([01])E", name)   # step_kernel<WPB, MT, FUSED, XE>
+        m = re.search(r"ELi(\d+)ELb([01])ELb([01])ELb([01])E", name)   # step_kernel<WPB, MT, FUSED, XE, WIDE>
         assert m, name
         mt, fused, xe = int(m.group(1)), m.group(2) == "1", m.group(3) == "1"
         seen.add((fused, xe))
@@ -235,8 +235,8 @@ def test_profile_summary_parser(tmp_path):
     d = tmp_path / "pmc" / "run"
     d.mkdir(parents=True)
     rows = ['"Correlation_Id","Dispatch_Id","Kernel_Name","Counter_Name","Counter_Value"']
-    tick = "void (anonymous namespace)::step_kernel<8, 256, false, false>((anonymous namespace)::KParams)"
-    roll = "void (anonymous namespace)::step_kernel<8, 256, true, false>((anonymous namespace)::KParams)"
+    tick = "void (anonymous namespace)::step_kernel<8, 256, false, false, true>((anonymous namespace)::KParams)"
+    roll = "void (anonymous namespace)::step_kernel<8, 256, true, false, false>((anonymous namespace)::KParams)"
     for disp, name, vals in ((1, tick, (10.0, 30.0)), (2, tick, (20.0, 20.0)), (3, roll, (1000.0, 1000.0)), (4, "other_kernel", (5.0, 5.0))):
         for v in vals:   # two rows per dispatch (e.g. per XCD): summed
             rows.append(f'{disp},{disp},"{name}","WRITE_SIZE",{v}')
@@ -244,5 +244,5 @@ def test_profile_summary_parser(tmp_path):
     s = tp.summarize_pmc([str(tmp_path / "pmc")], steps=200)
     assert s["per_tick"]["WRITE_SIZE"] == {"launches": 2, "mean_per_launch": 40.0} and s["per_tick"]["ticks_per_launch"] == 1
     assert s["fused"]["WRITE_SIZE"] == {"launches": 1, "mean_per_launch": 2000.0} and s["fused"]["ticks_per_launch"] == 200
-    assert tp.kernel_class("_ZN12_GLOBAL__N_111step_kernelILi8ELi256ELb1ELb0EEEvNS_7KParamsE") == "fused"
+    assert tp.kernel_class("_ZN12_GLOBAL__N_111step_kernelILi8ELi256ELb1ELb0ELb0EEEvNS_7KParamsE") == "fused"
     assert tp.kernel_class("gen_actions_kernel") is None

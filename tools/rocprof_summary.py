@@ -11,7 +11,7 @@ Recipe (on the GPU box; counters in their own passes, never together with a trac
           --out-stats profiles/rNN_target_kernel_stats.csv --out-pmc profiles/rNN_target_pmc_summary.json
 
 The PMC summary holds, per kernel class (`per_tick` = step_kernel<.., FUSED=0>, `fused` = step_kernel<.., FUSED=1>),
-the mean counter value per launch; FETCH_SIZE / WRITE_SIZE are in KiB (rocprofv3's unit); bench.py applies the
+the mean counter value per launch (template arguments: <waves per workgroup, compile-time M, FUSED, XE, WIDE>); FETCH_SIZE / WRITE_SIZE are in KiB (rocprofv3's unit); bench.py applies the
 gfx950 correction (FETCH_SIZE x2, MI355X_MICROARCH.md) when it turns them into `roofline.traffic`.
 """
 from __future__ import annotations
@@ -29,10 +29,10 @@ from collections import defaultdict
 def kernel_class(name: str):
     if "step_kernel" not in name:
         return None
-    m = re.search(r"step_kernelILi\d+ELi\d+ELb([01])ELb([01])E", name)
+    m = re.search(r"step_kernelILi\d+ELi\d+ELb([01])", name)           # mangled: <WPB, MT, FUSED, ...>
     if m:
         return "fused" if m.group(1) == "1" else "per_tick"
-    m = re.search(r"step_kernel<[^>]*?(true|false)\s*,\s*(true|false)\s*>", name)
+    m = re.search(r"step_kernel<\s*\d+\s*,\s*\d+\s*,\s*(true|false)", name)   # demangled
     if m:
         return "fused" if m.group(1) == "true" else "per_tick"
     return "per_tick"
