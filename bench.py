@@ -40,7 +40,7 @@ WORKLOADS = {
 }
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PMC_SUMMARY = "r01_v10_target_pmc_summary.json"
+PMC_SUMMARY = "r01_v11_target_pmc_summary.json"
 
 
 def algorithmic_bytes(M: int, E: int) -> float:
