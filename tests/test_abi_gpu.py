@@ -58,3 +58,33 @@ def test_misuse_returns_error_codes():
     assert lib.cygym_step(h2, C.byref(aa), C.byref(env._out), None) == EINVAL
     assert b"snapshot" in lib.cygym_last_error(h2)
     lib.cygym_destroy(h2)
+
+
+def test_launches_follow_the_callers_stream():
+    """Calls are stream-ordered on torch's CURRENT stream (include/cygym_abi.h conventions): the same ticks issued
+    inside a side stream, interleaved with other work on it, give the same state as on the default stream."""
+    from cygym_amd.batched_env import BatchedCyberDefenseEnv
+    from cygym_amd.topology import make_topology
+    topo, init, ck = make_topology(64, 4, seed=4)
+    cfg = abi.EnvConfig(seed=4, **ck)
+    a = BatchedCyberDefenseEnv(topo, cfg, 256, init, device="cuda:0", max_groups=1, max_devs=8)
+    b = BatchedCyberDefenseEnv(topo, cfg, 256, init, device="cuda:0", max_groups=1, max_devs=8)
+    side = torch.cuda.Stream(device="cuda:0")
+    junk = torch.zeros(1 << 22, device="cuda:0")
+    for t in range(40):
+        a.gen_actions(t)
+        a.step()
+    act, out = b.alloc_rollout(10)
+    with torch.cuda.stream(side):
+        for t in range(30):
+            junk.add_(1.0)          # unrelated work queued on the same side stream
+            b.gen_actions(t)
+            b.step()
+        b.gen_actions_rollout(30, act)
+        b.rollout(act, out)         # the last 10 ticks as one launch, still on the side stream
+    side.synchronize()
+    sa, sb = a.state_numpy(), b.state_numpy()
+    for k in ("live", "stash", "blocked", "ring", "ienv", "fenv"):
+        np.testing.assert_array_equal(sa[k], sb[k], err_msg=k)
+    np.testing.assert_array_equal(a.raw.cpu().numpy(), out["raw"][-1].cpu().numpy())
+    a.close(); b.close()
