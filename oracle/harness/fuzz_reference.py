@@ -4,7 +4,8 @@
 
 Each case builds a reference environment with random size / activity / evolve parameters (events, additions,
 attacker-owned activations, extra-edge capacity), optionally reshuffles ownership, drives it with random
-reference-style actions (single, grouped, None, repeated devices) under the injected Philox draws, and replays the
+reference-style actions (four mixes: plain, edge-heavy, repeated devices, and "wild": step_grouped calls,
+action=None under a random base_line, partial ticks, out-of-range action types) under the injected Philox draws, and replays the
 recording through oracle/cygym_oracle.c with the same tick-by-tick comparison the golden tests use
 (tests/golden_io.check_oracle_against_fixture).  Nothing is written into the repository.
 """
@@ -45,11 +46,32 @@ def main():
         env0 = H.build_env(M, n_active, init_seed=int(rs.randint(1, 10000)), strip_vuln_frac=float(rs.choice([0.2, 0.5])),
                            extra_reachable=int(rs.randint(0, 3)), overrides=over)
         X = 3 if over.get("zero_day") else 2
-        kind = rs.choice(["mixed", "edges", "dups"])
+        kind = rs.choice(["mixed", "edges", "dups", "wild"])
         if kind == "edges":
             fn = G.edge_heavy_actions(M, max(2, M // 5), X=X)
         else:
-            fn = G.mixed_actions(M, G.ALL_DEF, G.ALL_ATT, max(2, M // 4), X=X, unique=(kind != "dups"))
+            fn = G.mixed_actions(M, G.ALL_DEF, G.ALL_ATT, max(2, M // 4), X=X, unique=(kind not in ("dups", "wild")))
+        groups_cap = 1
+        if kind == "wild":   # step_grouped calls, action=None, partial ticks, out-of-range action types
+            base, groups_cap = fn, 4
+
+            def fn(e, t, env, rs2, base=base):
+                mode, a = base(e, t, env, rs2)
+                u = rs2.rand()
+                if u < 0.2:
+                    ng = int(rs2.randint(1, 5))
+                    return mode, [(int(rs2.choice([0, 1, 1, 2, 3, 8, 10, 11])) if mode == G.DEF else int(rs2.choice([0, 1, 2, 3])),
+                                   np.array([0]), G.dev_list(rs2, M, 4, unique=(rs2.rand() < 0.6)), 0) for _ in range(ng)]
+                if u < 0.4:
+                    return mode, None
+                if u < 0.5:
+                    return mode | S.MODE_PARTIAL, a
+                if u < 0.56:
+                    at, ex, dv, app = a
+                    return mode, (int(rs2.choice([-1, 14, 99])) if mode == G.DEF else int(rs2.choice([-2, 0, 4, 9])), ex, dv, app)
+                return mode, a
+            over["base_line"] = str(rs.choice(["Nash", "Nash", "No Defense", "No Attack", "Preset"]))
+            env0.base_line = over["base_line"]
         shuffle = rs.rand() < 0.5
 
         def pre(e, env, rs2, shuffle=shuffle):
@@ -62,7 +84,7 @@ def main():
                              pre_fn=pre, max_extra=256)
         with tempfile.TemporaryDirectory() as tmp:
             path = os.path.join(tmp, "case.npz")
-            H.save_fixture(path, res, 1)
+            H.save_fixture(path, res, groups_cap)
             fx = gio.Fixture(f"fuzz{case}", path=path)
             n = gio.check_oracle_against_fixture(fx)
         nx = int((fx.exp["ienv"][:, :, S.I_FLAGS].astype(np.int64) >> S.E_NX_SHIFT).max())
