@@ -1,21 +1,31 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/sec of the batched CyGym tick on MI355X.
 
-One "step" = one tick of every env of the batch, on synthetic input: the fixed-topology
-generator (cygym_amd/topology.py) and the alternating defender/attacker action script
-(SURVEY.md section 8d), pre-generated on device so that all inputs are resident in HBM
-when the timed region starts.  The script is open loop by construction, so the K timed
-steps are issued the way the library runs an open-loop rollout: cygym_rollout, K ticks in
-one launch, state on chip between ticks, every tick's observation / reward / done written
-to HBM (`value`, `roofline`).  The same K steps issued as K cygym_step launches -- what a
-closed-loop policy would drive -- are timed too and reported under `per_tick_stepping`
-(`--headline per_tick` swaps the two).
+One "step" = one tick of every env of the batch, on synthetic input: the fixed-topology generator
+(cygym_amd/topology.py) and the alternating defender/attacker action script, pre-generated
+on device so that all inputs are resident in HBM when a timed region starts.
 
-Contract (see the task description): `python bench.py --gpus N --steps K --warmup W`;
-for N > 1 the driver launches one rank per GPU with torch.distributed.run.  Envs are
-independent, so ranks shard the batch by env id (weak scaling: per-GPU envs fixed) and
-there is NO collective on the step path; the only collectives are the barrier and the
-MAX-over-ranks of the timing.  Rank 0 prints ONE JSON line.
+Two ways of issuing the same K ticks are timed, from the same state, and must end with the same rewards:
+
+  * `per_tick_stepping` -- K x cygym_step: one launch per tick (per sub-batch), i.e. what `env.step()` drives and
+    what a closed-loop policy can use.  THIS is `value` / `roofline` (the reference's callers are closed-loop:
+    do_agent.py:206-272, IPPO.py:503-620).  By default the batch is stepped as `--sub-batches` S contiguous
+    sub-batches, each on its own HIP stream (cygym_step_range): a sub-batch's next tick starts when ITS slowest env
+    is done, not the whole batch's, which is how a closed-loop driver pipelines policy evaluation and stepping.
+    The plain one-launch-per-tick figure (S = 1) is measured in the same run and reported beside it
+    (`single_launch`); its `launch_us` is the figure rocprofv3's kernel trace reports for the full-batch kernel.
+  * `fused_rollout` -- cygym_rollout: K ticks in ONE launch (open-loop scripts only; state on chip between ticks;
+    every tick's observation / reward / done still written to HBM).  `--headline rollout` swaps the two.
+
+Every timed region times exactly K steps and is repeated `--reps` times from the same state (restored, untimed,
+between repetitions); the MEDIAN repetition is reported (max over ranks first).  HIP events on the launch stream
+give `roofline.launch_us`.
+
+Contract (see the task description): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver
+launches one rank per GPU with torch.distributed.run.  Envs are independent, so ranks shard the batch by env id
+(weak scaling: per-GPU envs fixed) and there is NO collective on the step path; the collectives are the barrier,
+the MAX-over-ranks of the timings and one end-of-run all_gather of per-env returns (checked against a
+single-rank recomputation).  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -36,16 +46,24 @@ WORKLOADS = {
     "target": (4096, 256, 1, "north-star target: 4096 envs x 256 devices, Volt-Typhoon roles"),
     "cfg2": (4096, 64, 4, "BASELINE configs[1]: 4096 envs x 64 devices / 4 subnets"),
     "cfg3": (16384, 256, 1, "BASELINE configs[2]: 16384 envs x 256 devices"),
+    "cfg4": (16384, 256, 1, "BASELINE configs[3], per-GPU shard: 131072 envs x 256 devices over 8 GPUs = 16384 per GPU"),
     "cfg5": (4096, 2048, 32, "BASELINE configs[4]: 4096 envs x 2048 devices / 32 subnets"),
 }
+DEFAULT_SUB = {"target": 4, "cfg2": 4, "cfg3": 4, "cfg4": 4, "cfg5": 2}
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PMC_SUMMARY = "r01_v11_target_pmc_summary.json"
+PMC_SUMMARY = "r02_pmc_summary.json"   # profiles/: per workload and kernel class, bytes per launch from the --pmc passes
 
 
 def algorithmic_bytes(M: int, E: int) -> float:
     """B(M,E) = M*(S_r+S_w) + M*O_w + 2*ceil(E/8) + A, S_r=S_w=8, O_w=24, A=M/8+16."""
     return M * 16.0 + M * 24.0 + 2.0 * ((E + 7) // 8) + (M / 8.0 + 16.0)
+
+
+def state_term_bytes(M: int) -> float:
+    """The M*(S_r+S_w) term of B: per-device state read + written every tick.  The fused rollout keeps the state on
+    chip between ticks and never moves it, so its fraction is also reported without this term."""
+    return M * 16.0
 
 
 def layout_bytes(M: int, E: int) -> float:
@@ -55,214 +73,200 @@ def layout_bytes(M: int, E: int) -> float:
     return M * 3 * 2 + M + M * 24.0 + 2 * (16 * 4 + 3 * 8) + 48 + M / 8.0 + 0.5 * 4 * ((E + 31) // 32)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="target", choices=sorted(WORKLOADS))
-    ap.add_argument("--envs", type=int, default=0, help="override envs per GPU")
-    ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--max-extra", type=int, default=0,
-                    help="capacity of the per-env list of edges evolve_network may add.  0 (default): no list -- this is the "
-                         "fixed-topology run of SURVEY.md 8d (lambda_events = 0 can never add an edge; bench.py checks that "
-                         "no env wanted one), lean kernels; -1: the topology generator's default (room for two attacker "
-                         "stars), i.e. the kernels that also follow added edges (about 1 %% slower at 4096 x 256)")
-    ap.add_argument("--cpu-seconds", type=float, default=16.0)
-    ap.add_argument("--fused", type=int, default=-1,
-                    help="ticks per cygym_rollout launch (-1 = all K steps in one launch, 0 = skip the rollout leg)")
-    ap.add_argument("--headline", default="rollout", choices=["rollout", "per_tick"],
-                    help="which way of issuing the K steps fills value / roofline (the other one is reported beside it)")
-    args = ap.parse_args()
+class Dist:
+    """The few collectives the bench needs (none of them on the step path)."""
 
+    def __init__(self):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        # Rehearsal aid (one-GPU box): CYGYM_BENCH_SAME_GPU=1 runs every rank on cuda:0 (backend nccl = RCCL works
+        # there for <= 6 ranks; CYGYM_BENCH_BACKEND=gloo uses CPU collectives instead).
+        self.backend = os.environ.get("CYGYM_BENCH_BACKEND", "nccl")
+        if os.environ.get("CYGYM_BENCH_SAME_GPU") == "1":
+            self.local_rank = 0
+        self.dev = torch.device(f"cuda:{self.local_rank}")
+        torch.cuda.set_device(self.dev)
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+            else:
+                dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
+
+    def barrier(self):
+        self.torch.cuda.synchronize(self.dev)
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize(self.dev)
+
+    def max_over_ranks(self, values):
+        if self.world == 1:
+            return list(values)
+        t = self.torch.tensor(list(values), dtype=self.torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [float(x) for x in t]
+
+    def close(self):
+        if self.world > 1:
+            self.dist.destroy_process_group()
+
+
+def timed_reps(D: Dist, env, keep, reps, issue):
+    """`reps` repetitions of one timed region: restore the state (untimed), barrier + synchronize, issue, barrier +
+    synchronize.  Returns (median wall seconds, median HIP-event seconds), each the max over ranks per repetition."""
+    torch = D.torch
+    walls, evs = [], []
+    for _ in range(reps):
+        for k, v in keep.items():
+            env.state[k].copy_(v)
+        D.barrier()
+        t0 = time.perf_counter()
+        env.timer_start()          # HIP events on the stream the kernels are launched on (the current stream)
+        issue()
+        ev_ms = env.timer_stop()
+        torch.cuda.synchronize(D.dev)
+        D.barrier()
+        walls.append(time.perf_counter() - t0)
+        evs.append(ev_ms / 1e3)
+    walls = D.max_over_ranks(walls)
+    evs = D.max_over_ranks(evs)
+    return float(np.median(walls)), float(np.median(evs)), walls
+
+
+def run_workload(D: Dist, name, n_per_gpu, K, W, reps, sub, fused_T, seed, max_extra, want_rollout=True):
+    """All legs of one workload on this rank's shard.  Returns (record, env-side objects for the CPU baseline)."""
     import torch
-    import torch.distributed as dist
     from cygym_amd import abi
+    from cygym_amd import spec as S
     from cygym_amd.batched_env import BatchedCyberDefenseEnv
     from cygym_amd.topology import make_topology
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # Rehearsal aid (one-GPU box): CYGYM_BENCH_BACKEND=gloo CYGYM_BENCH_SAME_GPU=1 runs every rank on cuda:0
-    # with CPU collectives, to exercise the multi-rank code path without a second GPU.
-    backend = os.environ.get("CYGYM_BENCH_BACKEND", "nccl")
-    if os.environ.get("CYGYM_BENCH_SAME_GPU") == "1":
-        local_rank = 0
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
-    dev = torch.device(f"cuda:{local_rank}")
-    torch.cuda.set_device(dev)
-
-    n_per_gpu, M, blocks, desc = WORKLOADS[args.workload]
-    if args.envs:
-        n_per_gpu = args.envs
-    topo, init, ck = make_topology(M, blocks, seed=args.seed, max_extra=None if args.max_extra < 0 else args.max_extra)
+    _, M, blocks, desc = WORKLOADS[name]
+    dev = D.dev
+    topo, init, ck = make_topology(M, blocks, seed=seed, max_extra=None if max_extra < 0 else max_extra)
     # fixed-topology roofline run: lambda_events = 0 (SURVEY.md 8d); everything else at reference defaults
-    cfg = abi.EnvConfig(seed=args.seed, env_id_base=rank * n_per_gpu, auto_reset=1, lambda_events=0.0, **ck)
+    cfg = abi.EnvConfig(seed=seed, env_id_base=D.rank * n_per_gpu, auto_reset=1, lambda_events=0.0, **ck)
     L = max(1, M // 8)
     env = BatchedCyberDefenseEnv(topo, cfg, n_per_gpu, init, device=dev, max_groups=1, max_devs=L)
-
-    K, W = args.steps, args.warmup
-    # pre-generate the action script for every tick: inputs resident in HBM before timing
-    scripts = []
+    N = n_per_gpu
+    scripts = []   # the action script of every tick, generated on device: inputs resident in HBM before timing
     for t in range(W + K):
         act = {k: torch.empty_like(v) for k, v in env.act.items()}
         env.gen_actions(t, act)
         scripts.append(act)
-    torch.cuda.synchronize(dev)
-
     for t in range(W):
         env.step(scripts[t])
     torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    env.timer_start()
-    for t in range(W, W + K):
-        env.step(scripts[t])
-    ev_ms = env.timer_stop()          # HIP events on the stream the kernels were launched on
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    wall = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([wall, ev_ms], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall, ev_ms = float(tt[0]), float(tt[1])
-
-    total_envs = n_per_gpu * world
-    launch_s = (ev_ms / 1e3) / K      # average launch duration over the timed region (incl. inter-kernel gaps)
+    keep = {k: env.state[k].clone() for k in abi.BUFFER_FIELDS}   # the state at tick W: every timed region starts here
     B = algorithmic_bytes(M, topo.E)
-    ret_sum = float(env.raw.sum())
-    per_tick = {"what": "K launches of cygym_step (what a closed-loop policy drives)",
-                "value": total_envs * K / wall, "unit": "env-steps/s", "ms_per_step": wall / K * 1e3,
-                "roofline": roofline_block(n_per_gpu * B, launch_s, "step_kernel<.., FUSED=0>", 1),
-                "last_raw_reward_sum": ret_sum}
+    total_envs = N * D.world
+    main = torch.cuda.current_stream(dev)
+
+    def single():
+        for t in range(W, W + K):
+            env.step(scripts[t])
+
+    sub = max(1, min(int(sub), N))
+    streams = [torch.cuda.Stream(device=dev) for _ in range(sub)] if sub > 1 else []
+    per = (N + sub - 1) // sub
+    ev_go = torch.cuda.Event()
+
+    def pipelined():
+        ev_go.record(main)
+        for st in streams:
+            st.wait_event(ev_go)
+        for t in range(W, W + K):
+            for j, st in enumerate(streams):
+                with torch.cuda.stream(st):
+                    env.step_range(j * per, max(0, min(per, N - j * per)), scripts[t])
+        for st in streams:
+            main.wait_stream(st)
+
+    def leg(issue, launches_per_tick, what):
+        wall, ev, walls = timed_reps(D, env, keep, reps, issue)
+        r = roofline_block(N * B, ev / K, "step_kernel<WPB, M, FUSED=0, ..>", 1)
+        r["launches_per_tick"] = launches_per_tick
+        return {"what": what, "value": total_envs * K / wall, "unit": "env-steps/s", "ms_per_step": wall / K * 1e3,
+                "sub_batches": launches_per_tick, "reps": reps, "rep_spread": [min(walls) / K * 1e3, max(walls) / K * 1e3],
+                "roofline": r, "last_raw_reward_sum": float(env.raw.sum())}
+
+    one = leg(single, 1, "K launches of cygym_step, one full-batch launch per tick")
+    if sub > 1:
+        per_tick = leg(pipelined, sub, f"K ticks of cygym_step_range on {sub} sub-batches of {per} envs, one HIP stream each "
+                       "(closed-loop capable: every tick is its own launch)")
+        per_tick["single_launch"] = {k: one[k] for k in ("value", "ms_per_step", "roofline", "rep_spread")}
+        same_sub = per_tick["last_raw_reward_sum"] == one["last_raw_reward_sum"]
+    else:
+        per_tick, same_sub = one, True
+
     rollout = None
-    if args.fused:
-        rollout = fused_leg(env, init, scripts, W, K, args.fused, world, dev, n_per_gpu, B, backend)
-    head = rollout if (rollout is not None and args.headline == "rollout") else per_tick
-    other = per_tick if head is rollout else rollout
+    if want_rollout and fused_T != 0:
+        T = K if fused_T < 0 else min(fused_T, K)
+        chunks = []
+        for c in range((K + T - 1) // T):
+            lo, hi = W + c * T, min(W + K, W + (c + 1) * T)
+            act = {k: torch.stack([scripts[t][k] for t in range(lo, hi)]).contiguous() for k in scripts[0]}
+            _, out = env.alloc_rollout(hi - lo)
+            chunks.append((act, out))
 
-    out = {
-        "metric": "env-steps/sec", "value": head["value"], "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u8", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: {desc}", "envs_per_gpu": n_per_gpu, "devices": M, "edges": topo.E,
-                   "exploits": topo.X, "lambda_events": 0.0, "max_extra_edges": topo.max_extra,
-                   "stepping": head["what"],
-                   "parallelism": f"env-batch split x{world}, no step-path collective"},
-        "roofline": head["roofline"],
-        "check": {"last_raw_reward_sum": head["last_raw_reward_sum"],
-                  "same_trajectory_both_ways": (rollout is None) or (rollout["last_raw_reward_sum"] == ret_sum)},
-    }
-    out["roofline"].update({"bytes_per_env_step": B, "layout_bytes_per_env_step": layout_bytes(M, topo.E)})
-    if other is not None:
-        out["per_tick_stepping" if other is per_tick else "fused_rollout"] = other
+        def fused():
+            for act, out in chunks:
+                env.rollout(act, out)
+        wall, ev, walls = timed_reps(D, env, keep, reps, fused)
+        n_launch = len(chunks)
+        r = roofline_block(N * B * K / n_launch, ev / n_launch, "step_kernel<WPB, M, FUSED=1, ..>", K / n_launch)
+        r["frac_without_state_term"] = (N * (B - state_term_bytes(M)) * K / n_launch) / (ev / n_launch) / 1e9 / HBM_PEAK_GBS
+        rollout = {"what": f"cygym_rollout: {T} ticks per launch (open loop, pre-staged action script; state on chip between "
+                           "ticks; every tick's obs / reward / done written to HBM)",
+                   "value": total_envs * K / wall, "unit": "env-steps/s", "ms_per_step": wall / K * 1e3, "reps": reps,
+                   "rep_spread": [min(walls) / K * 1e3, max(walls) / K * 1e3], "roofline": r,
+                   "last_raw_reward_sum": float(chunks[-1][1]["raw"][-1].sum())}
+        del chunks
 
-    # HBM traffic of each kernel from the committed PMC passes of this same command
-    # (profiles/: separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled per the gfx950 note)
+    rec = {"workload": f"{name}: {desc}", "envs_per_gpu": N, "devices": M, "edges": topo.E, "exploits": topo.X,
+           "bytes_per_env_step": B, "layout_bytes_per_env_step": layout_bytes(M, topo.E),
+           "per_tick_stepping": per_tick, "fused_rollout": rollout,
+           "check": {"last_raw_reward_sum": per_tick["last_raw_reward_sum"],
+                     "same_trajectory_all_ways": same_sub and (rollout is None or rollout["last_raw_reward_sum"] == per_tick["last_raw_reward_sum"]),
+                     # the fixed-topology run must never have wanted an edge it could not add (CG_E_TOPO_OVF)
+                     "envs_that_needed_an_unavailable_edge": int(((env.state["ienv"][:, S.I_FLAGS] & S.E_TOPO_OVF) != 0).sum())}}
+    attach_traffic(rec, name, N)
+    return rec, (env, topo, init, cfg, M, L, scripts)
+
+
+def attach_traffic(rec, name, n_envs):
+    """HBM traffic of each kernel from the committed PMC passes of this same workload (profiles/: separate --pmc
+    FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), scaled to this
+    run's launch shape; `frac_traffic` = those bytes / launch time / peak."""
     pmc = os.path.join(ROOT, "profiles", PMC_SUMMARY)
-    if args.workload == "target" and not args.envs and os.path.exists(pmc):
-        try:
-            c = json.load(open(pmc))
-            for leg, key in ((per_tick, "per_tick"), (rollout, "fused")):
-                if leg is None or key not in c:
-                    continue
-                kb = 2.0 * c[key]["FETCH_SIZE"]["mean_per_launch"] + c[key]["WRITE_SIZE"]["mean_per_launch"]
-                ticks_pmc = float(c[key].get("ticks_per_launch", 1))
-                r = leg["roofline"]
-                r["traffic"] = kb * 1024.0 / ticks_pmc * r["ticks_per_launch"]
-                r["traffic_unit"] = "bytes per launch"
-                r["traffic_source"] = f"profiles/{PMC_SUMMARY} (rocprofv3 --pmc passes of this command, tools/rocprof_summary.py)"
-        except Exception:
-            pass
-    if rank == 0:
-        # also price the kernel against a device-copy bandwidth measured on this box
-        bw = measured_copy_gbs(dev)
-        out["roofline"]["measured_copy_peak"] = bw
-        out["roofline"]["frac_of_measured_copy"] = out["roofline"]["achieved"] / bw if bw else None
-    # the fixed-topology run must never have wanted an edge it could not add (CG_E_TOPO_OVF, cygym_spec.h)
-    from cygym_amd import spec as S
-    out["check"]["envs_that_needed_an_unavailable_edge"] = int(((env.state["ienv"][:, S.I_FLAGS] & S.E_TOPO_OVF) != 0).sum())
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(topo, init, cfg, M, L, scripts, W, args.cpu_seconds)
-    if rank == 0:
-        print(json.dumps(out))
-    env.close()
-    if world > 1:
-        dist.destroy_process_group()
-
-
-def fused_leg(env, init, scripts, W, K, T, world, dev, n_per_gpu, B, backend="nccl"):
-    """cygym_rollout: the same K ticks on the same script, T ticks per launch (open-loop), every tick's
-    observation still written to HBM.  Restarts from the initial state, so its last reward sum must equal
-    the per-tick leg's (same trajectory)."""
-    import torch
-    import torch.distributed as dist
-    T = K if T < 0 else min(T, K)
-    env.load_state(init)
-    for t in range(W):   # the W untimed warm-up steps
-        env.step(scripts[t])
-    n_launch = (K + T - 1) // T
-    chunks = []
-    for c in range(n_launch):
-        lo, hi = W + c * T, min(W + K, W + (c + 1) * T)
-        act = {k: torch.stack([scripts[t][k] for t in range(lo, hi)]).contiguous() for k in scripts[0]}
-        _, out = env.alloc_rollout(hi - lo)
-        chunks.append((act, out))
-    # warm the rollout kernel with a throw-away pass of the same launches, then put the state back at tick W
-    keep = {k: env.state[k].clone() for k in abi_buffer_fields()}
-    for act, out in chunks:
-        env.rollout(act, out)
-    for k, v in keep.items():
-        env.state[k].copy_(v)
-    del keep
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    env.timer_start()
-    for act, out in chunks:
-        env.rollout(act, out)
-    ev_ms = env.timer_stop()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    wall = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([wall, ev_ms], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall, ev_ms = float(tt[0]), float(tt[1])
-    n_launch = len(chunks)
-    return {"what": f"cygym_rollout: {T} ticks per launch (open loop, pre-staged action script; state on chip between "
-                    "ticks; every tick's obs / reward / done written to HBM)",
-            "value": n_per_gpu * world * K / wall, "unit": "env-steps/s", "ms_per_step": wall / K * 1e3,
-            "roofline": roofline_block(n_per_gpu * B * K / n_launch, (ev_ms / 1e3) / n_launch, "step_kernel<.., FUSED=1>", K / n_launch),
-            "last_raw_reward_sum": float(chunks[-1][1]["raw"][-1].sum())}
-
-
-def abi_buffer_fields():
-    from cygym_amd import abi
-    return abi.BUFFER_FIELDS
+    if not os.path.exists(pmc):
+        return
+    try:
+        c = json.load(open(pmc)).get(name)
+        if not c or c.get("envs_per_launch") != n_envs:
+            return
+        for leg, key in ((rec["per_tick_stepping"], "per_tick"), (rec["fused_rollout"], "fused")):
+            if leg is None or key not in c:
+                continue
+            per_tick_bytes = (2.0 * c[key]["FETCH_SIZE_KiB_per_launch"] + c[key]["WRITE_SIZE_KiB_per_launch"]) * 1024.0 \
+                / float(c[key]["ticks_per_launch"])
+            for r in [leg["roofline"]] + ([leg["single_launch"]["roofline"]] if "single_launch" in leg else []):
+                r["traffic"] = per_tick_bytes * r["ticks_per_launch"]
+                r["traffic_unit"] = "bytes per tick of the whole batch" if key == "per_tick" else "bytes per launch"
+                r["frac_traffic"] = r["traffic"] / (r["launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+                r["traffic_source"] = f"profiles/{PMC_SUMMARY} (rocprofv3 --pmc passes, tools/rocprof_summary.py)"
+    except Exception as e:   # a malformed summary must not break the bench line
+        print(f"[bench] warning: could not read {pmc}: {e}", file=sys.stderr)
 
 
 def roofline_block(bytes_per_launch, launch_s, kernel, ticks_per_launch):
     achieved = bytes_per_launch / launch_s / 1e9
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None, "kernel": kernel, "launch_us": launch_s * 1e6, "ticks_per_launch": ticks_per_launch,
-            "algorithmic_bytes_per_launch": bytes_per_launch}
+            "traffic": None, "frac_traffic": None, "kernel": kernel, "launch_us": launch_s * 1e6,
+            "ticks_per_launch": ticks_per_launch, "algorithmic_bytes_per_launch": bytes_per_launch}
 
 
 def measured_copy_gbs(dev, mib=1024, reps=8):
@@ -282,6 +286,30 @@ def measured_copy_gbs(dev, mib=1024, reps=8):
     ms = e0.elapsed_time(e1)
     del a, b
     return 2.0 * n * reps / (ms / 1e3) / 1e9 if ms > 0 else None
+
+
+def gathered_returns_check(D: Dist, env, scripts, topo, init, cfg, L, n_check=64):
+    """The one optional collective: all_gather of the per-env returns into global env order
+    (cygym_amd/sharding.gather_by_env; RCCL with the nccl backend).  Rank 0 recomputes the first `n_check` envs as
+    a single-rank batch (same global env ids, same script) and compares."""
+    import dataclasses
+    import torch
+    from cygym_amd.batched_env import BatchedCyberDefenseEnv
+    from cygym_amd.sharding import gather_by_env
+    local = env.raw.clone()
+    if D.backend != "nccl" and D.world > 1:
+        local = local.cpu()
+    allret = gather_by_env(local, env.N * D.world)
+    ok = None
+    if D.rank == 0:
+        n = min(n_check, env.N)
+        ref = BatchedCyberDefenseEnv(topo, dataclasses.replace(cfg, env_id_base=0), n, init, device=D.dev, max_groups=1, max_devs=L)
+        for act in scripts:
+            ref.step({k: v[:n].contiguous() for k, v in act.items()})
+        torch.cuda.synchronize(D.dev)
+        ok = bool(torch.equal(ref.raw.cpu(), allret[:n].cpu())) and int(allret.shape[0]) == env.N * D.world
+        ref.close()
+    return ok
 
 
 def cpu_baseline(topo, init, cfg, M, L, scripts, W, budget_s):
@@ -335,6 +363,118 @@ def cpu_baseline(topo, init, cfg, M, L, scripts, W, budget_s):
                     "sample": f"oracle/cygym_oracle.c, {threads} threads x {per} envs each: first {nt} envs x "
                               f"{len(scripts)} ticks of the same script, replayed {rt}x ({st} env-steps in {dt:.1f} s)"})
     return out
+
+
+def brief(rec):
+    """The sub-record of a secondary workload in the `configs` block."""
+    out = {"workload": rec["workload"], "envs_per_gpu": rec["envs_per_gpu"], "devices": rec["devices"],
+           "bytes_per_env_step": rec["bytes_per_env_step"], "check": rec["check"]}
+    for key in ("per_tick_stepping", "fused_rollout"):
+        leg = rec[key]
+        if leg is None:
+            continue
+        r = leg["roofline"]
+        out[key] = {"value": leg["value"], "ms_per_step": leg["ms_per_step"], "frac": r["frac"], "frac_traffic": r.get("frac_traffic"),
+                    "traffic": r.get("traffic"), "launch_us": r["launch_us"], "ticks_per_launch": r["ticks_per_launch"]}
+        if key == "per_tick_stepping":
+            out[key]["sub_batches"] = leg["sub_batches"]
+            if "single_launch" in leg:
+                out[key]["single_launch"] = {"value": leg["single_launch"]["value"], "frac": leg["single_launch"]["roofline"]["frac"],
+                                             "launch_us": leg["single_launch"]["roofline"]["launch_us"]}
+        else:
+            out[key]["frac_without_state_term"] = r.get("frac_without_state_term")
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="target", choices=sorted(WORKLOADS))
+    ap.add_argument("--envs", type=int, default=0, help="override envs per GPU")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--reps", type=int, default=11, help="repetitions of every timed K-step region (median reported)")
+    ap.add_argument("--sub-batches", type=int, default=0,
+                    help="per-tick stepping: sub-batches / HIP streams the batch is pipelined over (0 = the workload's default, "
+                         "1 = one full-batch launch per tick only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the short runs of the other single-GPU BASELINE configs")
+    ap.add_argument("--max-extra", type=int, default=0,
+                    help="capacity of the per-env list of edges evolve_network may add.  0 (default): no list -- this is the "
+                         "fixed-topology run of SURVEY.md 8d (lambda_events = 0 can never add an edge; bench.py checks that "
+                         "no env wanted one), lean kernels; -1: the topology generator's default (room for two attacker "
+                         "stars), i.e. the full-feature kernels")
+    ap.add_argument("--cpu-seconds", type=float, default=16.0)
+    ap.add_argument("--fused", type=int, default=-1,
+                    help="ticks per cygym_rollout launch (-1 = all K steps in one launch, 0 = skip the rollout leg)")
+    ap.add_argument("--headline", default="per_tick", choices=["per_tick", "rollout"],
+                    help="which way of issuing the K steps fills value / roofline (the other one is reported beside it)")
+    args = ap.parse_args()
+
+    D = Dist()
+    if args.gpus != D.world and D.rank == 0 and D.world > 1:
+        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={D.world}", file=sys.stderr)
+    K, W = args.steps, args.warmup
+    name = args.workload
+    n_per_gpu = args.envs or WORKLOADS[name][0]
+    sub = args.sub_batches or DEFAULT_SUB[name]
+    rec, (env, topo, init, cfg, M, L, scripts) = run_workload(D, name, n_per_gpu, K, W, args.reps, sub, args.fused, args.seed,
+                                                               args.max_extra)
+    per_tick, rollout = rec["per_tick_stepping"], rec["fused_rollout"]
+    head = rollout if (rollout is not None and args.headline == "rollout") else per_tick
+    other_key, other = ("per_tick_stepping", per_tick) if head is rollout else ("fused_rollout", rollout)
+
+    out = {
+        "metric": "env-steps/sec", "value": head["value"], "unit": "env-steps/s", "n_gpus": D.world, "steps": K, "warmup": W,
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+        "config": {"workload": rec["workload"], "envs_per_gpu": n_per_gpu, "devices": M, "edges": topo.E,
+                   "exploits": topo.X, "lambda_events": 0.0, "max_extra_edges": topo.max_extra,
+                   "stepping": head["what"], "reps": args.reps,
+                   "parallelism": f"env-batch split x{D.world}, no step-path collective"},
+        "roofline": dict(head["roofline"]),
+        "check": rec["check"],
+    }
+    out["roofline"].update({"bytes_per_env_step": rec["bytes_per_env_step"], "layout_bytes_per_env_step": rec["layout_bytes_per_env_step"]})
+    if head is per_tick and "single_launch" in per_tick:
+        out["single_launch_per_tick"] = per_tick["single_launch"]
+    if other is not None:
+        out[other_key] = other
+    if D.rank == 0:
+        # SURVEY.md 8d: also price the kernel against a device-copy bandwidth measured on this box
+        bw = measured_copy_gbs(D.dev)
+        out["roofline"]["measured_copy_peak"] = bw
+        out["roofline"]["frac_of_measured_copy"] = out["roofline"]["achieved"] / bw if bw else None
+    if D.world > 1:
+        # end-of-rollout gather of per-env returns over RCCL, checked against a single-rank recomputation:
+        # restart from the initial state and run the first W + 4 ticks on every rank
+        n_ticks = min(len(scripts), W + 4)
+        env.load_state(init)
+        for t in range(n_ticks):
+            env.step(scripts[t])
+        out["check"]["gathered_returns_match_single_rank"] = gathered_returns_check(D, env, scripts[:n_ticks], topo, init, cfg, L)
+    if D.rank == 0 and D.world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(topo, init, cfg, M, L, scripts, W, args.cpu_seconds)
+    env.close()
+    del env, scripts
+
+    # the other BASELINE configs as short sub-records (parity-test sizes, here timed on the current kernels):
+    # N = 1: cfg2 / cfg3 / cfg5; N > 1: cfg4 = the per-GPU shard of the 131072-env config
+    if not args.no_configs and not args.envs and name == "target":
+        others = ["cfg2", "cfg3", "cfg5"] if D.world == 1 else ["cfg4"]
+        out["configs"] = {}
+        for w in others:
+            kk = min(K, 20 if w != "cfg5" else 10)
+            r, objs = run_workload(D, w, WORKLOADS[w][0], kk, min(W, 5), min(args.reps, 5), DEFAULT_SUB[w], -1, args.seed, args.max_extra)
+            objs[0].close()
+            del objs
+            b = brief(r)
+            b["steps"] = kk
+            out["configs"][w] = b
+    if D.rank == 0:
+        print(json.dumps(out))
+    D.close()
 
 
 if __name__ == "__main__":

@@ -13,7 +13,7 @@ import numpy as np
 from . import rng as R
 from . import spec as S
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 u8p = C.POINTER(C.c_uint8)
 u16p = C.POINTER(C.c_uint16)
@@ -30,7 +30,7 @@ class Topology(C.Structure):
         ("dstatic", C.c_void_p), ("vuln", C.c_void_p), ("napps", C.c_void_p),
         ("os_val", C.c_void_p), ("version", C.c_void_p), ("anomaly", C.c_void_p),
         ("out_ptr", C.c_void_p), ("out_col", C.c_void_p), ("in_ptr", C.c_void_p),
-        ("in_col", C.c_void_p), ("in_eid", C.c_void_p),
+        ("in_col", C.c_void_p), ("in_eid", C.c_void_p), ("det_apl", C.c_void_p),
     ]
 
 
@@ -53,7 +53,8 @@ class Buffers(C.Structure):
     _fields_ = [
         ("live", C.c_void_p), ("stash", C.c_void_p),
         ("blocked", C.c_void_p), ("blocked_in", C.c_void_p), ("ring", C.c_void_p), ("ienv", C.c_void_p),
-        ("fenv", C.c_void_p), ("extra", C.c_void_p), ("n_envs", C.c_int32), ("reserved", C.c_int32),
+        ("fenv", C.c_void_p), ("extra", C.c_void_p), ("forest", C.c_void_p), ("hist", C.c_void_p),
+        ("n_envs", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -74,7 +75,7 @@ BASELINES = {"Nash": 0, "No Defense": 1, "Preset": 2, "No Attack": 3}
 LIVE_PLANES = ("flags", "busy", "wl", "comp_by")          # order inside Buffers.live  [N][4][M]
 STASH_PLANES = ("st_flags", "st_busy", "st_wl", "st_comp_by")  # order inside Buffers.stash [N][4][M]
 STATE_PLANES = LIVE_PLANES + STASH_PLANES
-BUFFER_FIELDS = ("live", "stash", "blocked", "blocked_in", "ring", "ienv", "fenv", "extra")
+BUFFER_FIELDS = ("live", "stash", "blocked", "blocked_in", "ring", "ienv", "fenv", "extra", "forest", "hist")
 
 
 @dataclass
@@ -143,6 +144,7 @@ class TopologyArrays:
     in_col: np.ndarray
     in_eid: np.ndarray
     max_extra: int = 0          # K: capacity of the per-env list of edges evolve_network may add
+    det_apl: np.ndarray | None = None   # f64 [DET_APL_N] leaf-term table of the trained detector (detector.apl_table())
     _keep: list = field(default_factory=list, repr=False)
 
     @property
@@ -165,7 +167,8 @@ class TopologyArrays:
             int(self.M), int(self.X), a(self.dstatic, np.uint8), a(self.vuln, np.uint8), a(self.napps, np.uint8),
             a(self.os_val, np.float32), a(self.version, np.float32), a(self.anomaly, np.float32),
             a(self.out_ptr, np.int32), a(self.out_col, np.int32), a(self.in_ptr, np.int32),
-            a(self.in_col, np.int32), a(self.in_eid, np.int32), int(self.max_extra))
+            a(self.in_col, np.int32), a(self.in_eid, np.int32), int(self.max_extra),
+            None if self.det_apl is None else a(self.det_apl, np.float64))
 
     def validate(self):
         M, E = self.M, self.E
@@ -185,6 +188,8 @@ class TopologyArrays:
             raise ValueError("max_extra must be in [0, 4096]")
         if self.in_eid.shape != (E,):
             raise ValueError("in_eid must have shape (E,)")
+        if self.det_apl is not None and self.det_apl.shape != (S.DET_APL_N,):
+            raise ValueError(f"det_apl must have shape ({S.DET_APL_N},)")
         if E:
             if self.in_eid.min() < 0 or self.in_eid.max() >= E:
                 raise ValueError("in_eid out of range")
@@ -205,6 +210,7 @@ class TopologyArrays:
                 arr = np.zeros(1, arr.dtype)
                 self._keep.append(arr)
             setattr(t, name, arr.ctypes.data)
+        t.det_apl = None if self.det_apl is None else self.det_apl.ctypes.data
         return t
 
 

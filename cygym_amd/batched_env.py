@@ -19,17 +19,21 @@ from . import spec as S
 
 _BUF_DTYPES = {"live": torch.uint8, "stash": torch.uint8, "blocked": torch.int32, "blocked_in": torch.int32,
                "ring": torch.int16,
-               "ienv": torch.int32, "fenv": torch.float64, "extra": torch.int32}
+               "ienv": torch.int32, "fenv": torch.float64, "extra": torch.int32, "forest": torch.int32, "hist": torch.int16}
 _STATE_KEYS = abi.STATE_PLANES + ("blocked", "ring", "ienv", "fenv")
-_NP_VIEW = {"blocked": np.uint32, "ring": np.uint16, "extra": np.uint32}
+_NP_VIEW = {"blocked": np.uint32, "ring": np.uint16, "extra": np.uint32, "forest": np.uint32, "hist": np.uint16}
 
 
-def _alloc_state(n, M, EW, device, K=0):
+def _alloc_state(n, M, EW, device, K=0, detector=False):
     """`live` / `stash` are the [N][4][M] buffers of the ABI; flags/busy/... are VIEWS into them.
-    `extra` is the per-env list of edges evolve_network added (K = topo.max_extra entries)."""
+    `extra` is the per-env list of edges evolve_network added (K = topo.max_extra entries); `forest` / `hist`
+    (trained-detector mode: the env's flattened isolation forest and the comm-log history it is fitted on) have
+    zero width unless asked for."""
     dims = {"live": (4, M), "stash": (4, M), "blocked": (EW,), "blocked_in": (EW,), "ring": (S.LOG_RING, 2),
-            "ienv": (S.I_COUNT,), "fenv": (S.D_COUNT,), "extra": (abi.x_words(K),)}
+            "ienv": (S.I_COUNT,), "fenv": (S.D_COUNT,), "extra": (abi.x_words(K),),
+            "forest": (S.FOREST_WORDS if detector else 0,), "hist": (S.HIST_RING if detector else 0, 2)}
     st = {k: torch.zeros((n,) + dims[k], dtype=dt, device=device) for k, dt in _BUF_DTYPES.items()}
+    st["hist"].fill_(-1)
     for i, k in enumerate(abi.LIVE_PLANES):
         st[k] = st["live"][:, i]
     for i, k in enumerate(abi.STASH_PLANES):
@@ -77,12 +81,18 @@ class BatchedCyberDefenseEnv:
     """
 
     def __init__(self, topo: abi.TopologyArrays, cfg: abi.EnvConfig, n_envs: int, init_state: dict,
-                 device="cuda:0", max_groups: int = 1, max_devs: int | None = None):
+                 device="cuda:0", max_groups: int = 1, max_devs: int | None = None, detector: bool = False):
         self.lib = _lib.load()   # raises when libcygym_hip.so is missing: no fallback
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.CygymError("BatchedCyberDefenseEnv runs on a ROCm GPU only (device must be cuda:N)")
         self.topo = topo.normalised()
+        # detector=True: trained-detector mode is available (defender action 10 -> service_detectors()): binds the
+        # per-env forest (4 KB) and history ring (8 KB) and selects the full-feature kernels
+        self.detector = bool(detector)
+        if self.detector and self.topo.det_apl is None:
+            from . import detector as D
+            self.topo.det_apl = D.apl_table()
         self.topo.validate()
         self.cfg = cfg
         self.N, self.M, self.EW = int(n_envs), self.topo.M, self.topo.EW
@@ -95,11 +105,12 @@ class BatchedCyberDefenseEnv:
             rc = self.lib.cygym_create(C.byref(t), C.byref(c), self.N, self.device.index or 0, C.byref(self._h))
         _lib.check(rc, None, "cygym_create")
         self.K = self.topo.max_extra
-        self.state = _alloc_state(self.N, self.M, self.EW, self.device, self.K)
+        self.state = _alloc_state(self.N, self.M, self.EW, self.device, self.K, self.detector)
+        self._scratch = None   # cygym_randomize's shuffle keys, allocated on first use
         lead = int(np.asarray(init_state["flags"]).shape[0])
         if lead not in (1, self.N):
             raise ValueError("init_state must have leading dimension 1 or n_envs")
-        self.snapshot = _alloc_state(lead, self.M, self.EW, self.device, self.K)
+        self.snapshot = _alloc_state(lead, self.M, self.EW, self.device, self.K, self.detector)
         self._load(self.snapshot, init_state)
         _lib.check(self.lib.cygym_bind(self._h, C.byref(_buffers_struct(self.state))), self._h, "cygym_bind")
         self._snap_struct = _buffers_struct(self.snapshot)
@@ -150,6 +161,12 @@ class BatchedCyberDefenseEnv:
         if "extra" in src and dst["extra"].numel():
             a = np.ascontiguousarray(np.asarray(src["extra"]).astype(np.uint32)).view(np.int32)
             dst["extra"].copy_(torch.from_numpy(a).reshape(dst["extra"].shape))
+        dst["forest"].zero_()
+        dst["hist"].fill_(-1)
+        for k, udt, sdt in (("forest", np.uint32, np.int32), ("hist", np.uint16, np.int16)):
+            if k in src and dst[k].numel():
+                a = np.ascontiguousarray(np.asarray(src[k]).astype(udt)).view(sdt)
+                dst[k].copy_(torch.from_numpy(a).reshape((-1,) + tuple(dst[k].shape[1:])).expand_as(dst[k]))
 
     def _derive(self, st):
         """Fill the library-maintained derived buffers (blocked_in) of a state dict."""
@@ -183,7 +200,7 @@ class BatchedCyberDefenseEnv:
             self._load(self.state, state)
             self._derive(self.state)
         else:
-            tmp = _alloc_state(1, self.M, self.EW, self.device, self.K)
+            tmp = _alloc_state(1, self.M, self.EW, self.device, self.K, self.detector)
             self._load(tmp, state)
             self._derive(tmp)
             for k in abi.BUFFER_FIELDS:
@@ -201,24 +218,48 @@ class BatchedCyberDefenseEnv:
 
     def randomize(self, env_ids=None):
         """randomize_compromise_and_ownership() (volt_typhoon_env.py:330) for the given envs."""
+        if self._scratch is None:   # caller-owned scratch of cygym_randomize: u32 [N][ceil(M/64)*64]
+            self._scratch = torch.empty((self.N, (self.M + 63) // 64 * 64), dtype=torch.int32, device=self.device)
+        sc = C.c_void_p(self._scratch.data_ptr())
         if env_ids is None:
-            rc = self.lib.cygym_randomize(self._h, None, self.N, self._stream())
+            rc = self.lib.cygym_randomize(self._h, None, self.N, sc, self._stream())
         else:
             ids = torch.as_tensor(env_ids, dtype=torch.int32, device=self.device).contiguous()
-            rc = self.lib.cygym_randomize(self._h, C.c_void_p(ids.data_ptr()), int(ids.numel()), self._stream())
+            if ids.numel() > self.N:
+                raise ValueError("more env ids than envs")
+            rc = self.lib.cygym_randomize(self._h, C.c_void_p(ids.data_ptr()), int(ids.numel()), sc, self._stream())
             torch.cuda.current_stream(self.device).synchronize()
         _lib.check(rc, self._h, "cygym_randomize")
 
+    _ACT_DTYPES = {"mode": torch.int32, "n_groups": torch.int32, "atype": torch.int32, "n_exploit": torch.int32,
+                   "exploit": torch.int32, "app": torch.int32, "dev_cnt": torch.int32, "dev_idx": torch.int16}
+
+    def _check_actions(self, act, lead):
+        """The kernel indexes these tensors by raw pointer: dtype, device, contiguity and every dimension are
+        checked here, so a malformed dict is a Python error and never an out-of-bounds access on the GPU.
+        `lead`: leading dimensions, (N,) for step() or (T, N) for rollout().  Returns (G, L)."""
+        nl = len(lead)
+        G = int(act["atype"].shape[nl]) if act["atype"].dim() > nl else 0
+        L = int(act["dev_idx"].shape[nl]) if act["dev_idx"].dim() > nl else 0
+        want = {"mode": (), "n_groups": (), "atype": (G,), "n_exploit": (G,), "exploit": (G, S.MAX_EXPLOITS),
+                "app": (G,), "dev_cnt": (G,), "dev_idx": (L,)}
+        for k, tail in want.items():
+            t = act[k]
+            if t.dtype != self._ACT_DTYPES[k] or t.device != self.device or not t.is_contiguous():
+                raise ValueError(f"action tensor {k} must be a contiguous {self._ACT_DTYPES[k]} tensor on {self.device}")
+            if tuple(t.shape) != tuple(lead) + tail:
+                raise ValueError(f"action tensor {k} has shape {tuple(t.shape)}, expected {tuple(lead) + tail}")
+        if G < 1 or L < 1:
+            raise ValueError("action tensors need max_groups >= 1 and max_devs >= 1")
+        return G, L
+
     def actions_struct(self, act=None) -> abi.Actions:
         act = self.act if act is None else act
+        G, L = self._check_actions(act, (self.N,))
         a = abi.Actions()
-        for k in ("mode", "n_groups", "atype", "n_exploit", "exploit", "app", "dev_cnt", "dev_idx"):
-            t = act[k]
-            if not t.is_contiguous() or t.device != self.device:
-                raise ValueError(f"action tensor {k} must be contiguous on {self.device}")
-            setattr(a, k, t.data_ptr())
-        a.max_groups = int(act["atype"].shape[1]) if act["atype"].dim() > 1 else 1
-        a.max_devs = int(act["dev_idx"].shape[1])
+        for k in self._ACT_DTYPES:
+            setattr(a, k, act[k].data_ptr())
+        a.max_groups, a.max_devs = G, L
         return a
 
     def step(self, act=None):
@@ -227,6 +268,54 @@ class BatchedCyberDefenseEnv:
         a = self.actions_struct(act)
         _lib.check(self.lib.cygym_step(self._h, C.byref(a), C.byref(self._out), self._stream()), self._h, "cygym_step")
         return self.obs, self.raw, self.shaped, self.done
+
+    def step_range(self, begin: int, n: int, act=None):
+        """One tick for the envs [begin, begin + n) only, on the current stream (cygym_step_range).  The action and
+        output tensors keep their [N] leading dimension.  A closed-loop driver pipelines sub-batches this way: each
+        sub-batch on its own stream, so that its policy evaluation and the tail of its slowest env overlap the other
+        sub-batches' ticks (see bench.py, leg `per_tick_stepping`)."""
+        a = self.actions_struct(act)
+        _lib.check(self.lib.cygym_step_range(self._h, int(begin), int(n), C.byref(a), C.byref(self._out), self._stream()),
+                   self._h, "cygym_step_range")
+        return self.obs, self.raw, self.shaped, self.done
+
+    # ---- trained-detector mode: Detector.train is a host callback (cygym_amd/detector.py) ----
+    def install_forest(self, env: int, words):
+        """Write one env's flattened forest (keeping the request the tick recorded in header words 3, 4) and clear
+        CG_E_DET_PENDING.  `words`: u32 [FOREST_WORDS] from detector.fit_forest / flatten_forest."""
+        if not self.detector:
+            raise _lib.CygymError("this batch was created without detector=True")
+        w = torch.from_numpy(np.ascontiguousarray(np.asarray(words, np.uint32)).view(np.int32)).to(self.device)
+        f = self.state["forest"][env]
+        f[0:3] = w[0:3]
+        f[5] = f[3]
+        f[S.FOREST_HDR:] = w[S.FOREST_HDR:]
+        self.state["ienv"][env, S.I_FLAGS] &= ~S.E_DET_PENDING
+
+    def service_detectors(self) -> int:
+        """Answer every pending Detector.train (defender action 10 on a non-empty log, volt_typhoon_env.py:945-962):
+        fit scikit-learn's IsolationForest on the last <= 2000 entries of the env's history ring -- the numpy stream
+        it draws from seeded by the Philox draw addressed (env, request tick, CG_SITE_DET_FIT) -- and install the
+        flattened trees.  Call it after a tick that may have carried action 10 and before the next scan (a scan
+        that finds the request still pending answers all-"D" and raises CG_E_UNPINNED).  Synchronises; returns the
+        number of forests fitted."""
+        if not self.detector:
+            return 0
+        from . import detector as D
+        flags = self.state["ienv"][:, S.I_FLAGS]
+        pend = torch.nonzero(flags & S.E_DET_PENDING).flatten().tolist()
+        for e in pend:
+            hdr = self.state["forest"][e, :S.FOREST_HDR].cpu().numpy().view(np.uint32)
+            req_tick, req_total = int(hdr[3]), int(hdr[4])
+            total = int(self.state["ienv"][e, S.I_LOG_TOTAL])
+            if total - max(0, req_total - S.TRAIN_WINDOW) > S.HIST_RING:
+                raise _lib.CygymError(f"env {e}: the training window of tick {req_tick} has left the history ring "
+                                      "(service_detectors() must run before 48 more log entries arrive)")
+            hist = self.state["hist"][e].cpu().numpy().view(np.uint16)
+            rows = D.training_window(hist, req_total)
+            self.install_forest(e, D.fit_forest(rows, D.fit_seed(self.cfg.seed, self.cfg.env_id_base + e, req_tick),
+                                                n_fits=int(hdr[6])))
+        return len(pend)
 
     def alloc_rollout(self, n_ticks: int):
         """Action and output tensors with a leading tick dimension for rollout()."""
@@ -245,19 +334,17 @@ class BatchedCyberDefenseEnv:
         (see alloc_rollout).  Open-loop: every tick's action is staged beforehand.  Same results as T step()
         calls; an env's state stays on chip between its ticks and envs never wait for each other."""
         T = int(act["mode"].shape[0])
+        G, L = self._check_actions(act, (T, self.N))
         a = abi.Actions()
-        for k in ("mode", "n_groups", "atype", "n_exploit", "exploit", "app", "dev_cnt", "dev_idx"):
-            t = act[k]
-            if not t.is_contiguous() or t.device != self.device or t.shape[0] != T or t.shape[1] != self.N:
-                raise ValueError(f"rollout tensor {k} must be contiguous [T, N, ...] on {self.device}")
-            setattr(a, k, t.data_ptr())
-        a.max_groups = int(act["atype"].shape[2])
-        a.max_devs = int(act["dev_idx"].shape[2])
+        for k in self._ACT_DTYPES:
+            setattr(a, k, act[k].data_ptr())
+        a.max_groups, a.max_devs = G, L
         o = abi.Outputs()
-        for k in ("obs", "raw", "shaped", "done"):
+        odt = {"obs": (torch.float32, (self.M, 6)), "raw": (torch.float64, ()), "shaped": (torch.float64, ()), "done": (torch.uint8, ())}
+        for k, (dt, tail) in odt.items():
             t = out[k]
-            if not t.is_contiguous() or t.shape[0] != T or t.shape[1] != self.N:
-                raise ValueError(f"rollout output {k} must be contiguous [T, N, ...]")
+            if t.dtype != dt or t.device != self.device or not t.is_contiguous() or tuple(t.shape) != (T, self.N) + tail:
+                raise ValueError(f"rollout output {k} must be a contiguous {dt} tensor of shape {(T, self.N) + tail} on {self.device}")
             setattr(o, k, t.data_ptr())
         _lib.check(self.lib.cygym_rollout(self._h, T, C.byref(a), C.byref(o), self._stream()), self._h, "cygym_rollout")
         return out

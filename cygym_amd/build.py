@@ -50,6 +50,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I" + INC, "-o", SO, SRC,
            "-Rpass-analysis=kernel-resource-usage"]
+    cmd += os.environ.get("CYGYM_BUILD_FLAGS", "").split()   # development: e.g. -DCG_DEV_MT=256 -DCG_DEV_WPB=8
     if verbose:
         print(" ".join(cmd))
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

@@ -243,20 +243,30 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
     wsync();
     if constexpr (XE) { if (COLD(xany)) { total_new += spread_x_counts(e, cur, slist, cntv, n_src, ebit); wsync(); } }
     SUBSTAMP(12);
-    // ring: only the last CG_LOG_RING entries (global order: source id, then row order) matter
+    // ring: only the last CG_LOG_RING entries (global order: source id, then row order) matter; the long history
+    // (cygym_buffers.hist, full-feature kernel only) takes the last CG_HIST_RING of them, straight to global memory
     if (total_new > 0) {
       const uint32_t base = (uint32_t)e.log_total;
       const uint32_t end = base + (uint32_t)total_new;
       const uint32_t lo = end > CG_LOG_RING ? end - CG_LOG_RING : 0;
+      uint16_t* hist = nullptr;
+      if constexpr (XE) { if (COLD(P.b.hist != nullptr)) hist = P.b.hist + (size_t)e.env * CG_HIST_RING * 2; }
+      const uint32_t lo_all = hist ? (end > CG_HIST_RING ? end - CG_HIST_RING : 0) : lo;   // lo_all <= lo
+      auto put = [&](uint32_t idx, int from, int to) {
+        if (idx >= lo) { e.ring[2 * (idx % CG_LOG_RING)] = (uint16_t)from; e.ring[2 * (idx % CG_LOG_RING) + 1] = (uint16_t)to; }
+        if constexpr (XE) {
+          if (COLD(hist != nullptr) && idx >= lo_all) { hist[2 * (idx % CG_HIST_RING)] = (uint16_t)from; hist[2 * (idx % CG_HIST_RING) + 1] = (uint16_t)to; }
+        }
+      };
       uint32_t after = end;   // global index just past the current block of sources
-      for (int b0 = ((n_src - 1) / WAVE) * WAVE; b0 >= 0 && after > lo; b0 -= WAVE) {
+      for (int b0 = ((n_src - 1) / WAVE) * WAVE; b0 >= 0 && after > lo_all; b0 -= WAVE) {
         const int i = b0 + e.lane;
         int n = i < n_src ? cntv[i] : 0;
         int incl = wave_incl_scan(n, e.lane);
         int blk_total = __builtin_amdgcn_readlane(incl, 63);
         uint32_t cbase = after - (uint32_t)blk_total;
         uint32_t off = cbase + (uint32_t)(incl - n);
-        bool mine = n > 0 && off + (uint32_t)n > lo;
+        bool mine = n > 0 && off + (uint32_t)n > lo_all;
         int s = mine ? (int)slist[i] : 0;
         const bool xs = mine && xany && x_isout(e, s);
         bool is_long = mine && !xs && (e.optr[s + 1] - e.optr[s]) > LONG_ROW;
@@ -268,7 +278,7 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
             const bool ex = w.at_extra(e);
             const int v = ex ? (int)w.vx : (int)e.ocol[w.k];
             if (!(ex ? x_blocked(e, w.j) : e.blocked(w.k))) {
-              if (idx >= lo) { e.ring[2 * (idx % CG_LOG_RING)] = (uint16_t)s; e.ring[2 * (idx % CG_LOG_RING) + 1] = (uint16_t)v; }
+              put(idx, s, v);
               ++idx;
             }
             w.next(e, ex);
@@ -280,7 +290,7 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
           int last = cur[s] < o1 ? (int)cur[s] : o1 - 1;
           for (int k = e.optr[s]; k <= last; ++k) {
             if (e.blocked(k)) continue;
-            if (idx >= lo) { e.ring[2 * (idx % CG_LOG_RING)] = (uint16_t)s; e.ring[2 * (idx % CG_LOG_RING) + 1] = e.ocol[k]; }
+            put(idx, s, e.ocol[k]);
             ++idx;
           }
         }
@@ -297,7 +307,7 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
             bool p = k <= last && !e.blocked(k);
             uint64_t m = ballot(p);
             uint32_t idx = idx0 + (uint32_t)below(m);
-            if (p && idx >= lo) { e.ring[2 * (idx % CG_LOG_RING)] = (uint16_t)ls; e.ring[2 * (idx % CG_LOG_RING) + 1] = e.ocol[k]; }
+            if (p) put(idx, ls, e.ocol[k]);
             idx0 += (uint32_t)__popcll(m);
           }
         }

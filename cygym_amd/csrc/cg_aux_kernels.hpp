@@ -26,6 +26,12 @@ __global__ void reset_kernel(KParams P, const int32_t* env_ids, int n) {
   const int XW = P.t.K + P.t.KW;
   if (P.t.K > 0 && P.snap.extra)
     for (int w = lane; w < XW; w += WAVE) P.b.extra[(size_t)env * XW + w] = P.snap.extra[(size_t)si * XW + w];
+  if (P.b.hist && P.snap.hist)   // the pickled env carries its logger and detector too (volt_typhoon_env.py:1904-1936)
+    for (int i = lane; i < CG_HIST_RING; i += WAVE)
+      ((uint32_t*)(P.b.hist + (size_t)env * CG_HIST_RING * 2))[i] = ((const uint32_t*)(P.snap.hist + (size_t)si * CG_HIST_RING * 2))[i];
+  if (P.b.forest && P.snap.forest)
+    for (int i = lane; i < CG_FOREST_WORDS; i += WAVE)
+      P.b.forest[(size_t)env * CG_FOREST_WORDS + i] = P.snap.forest[(size_t)si * CG_FOREST_WORDS + i];
   if (lane < CG_I_COUNT) {
     int32_t v = P.snap.ienv[(size_t)si * CG_I_COUNT + lane];
     if (lane == CG_I_RNG_TICK) v = tick;   // the draw counter is monotone across episodes

@@ -36,7 +36,14 @@ __device__ __forceinline__ void def_global(Env& e, const KP& P, int at, const in
       }
     }
     cost += -1.0 * ds;
-    if (e.log_total > 0) { e.eflags |= CG_E_DET_TRAIN; e.eflags &= ~CG_E_DET_RANDOM; }
+    if (e.log_total > 0) {   // Detector.train(non-empty logs) CDSimulator.py:692-695: the fit is the host's job
+      e.eflags |= CG_E_DET_TRAIN | CG_E_DET_PENDING; e.eflags &= ~CG_E_DET_RANDOM;
+      if (COLD(P.b.forest != nullptr) && e.lane == 0) {   // the request: which tick asked, and on how many logs
+        uint32_t* fo = P.b.forest + (size_t)e.env * CG_FOREST_WORDS;
+        fo[6] = (fo[3] == e.tick && fo[6] > 0) ? fo[6] + 1 : 1;   // several groups of one step_grouped tick may ask
+        fo[3] = e.tick; fo[4] = (uint32_t)e.log_total;
+      }
+    }
   } else if (at == 11) {  // :964-976, _device_state :419-428
     if (L > 0) {
       int d = dev[0];
@@ -425,13 +432,56 @@ __device__ __forceinline__ void def_per_device(Env& e, const KP& P, int at, cons
           if (__popcll(m) >= majority && anom) {
             uint32_t idx = (uint32_t)(e.log_total - w + e.lane);
             int snd = e.ring[2 * (idx % CG_LOG_RING)];
-            atomicAnd((unsigned int*)(e.flags + (snd & ~3)), ~((uint32_t)CG_F_COMP << ((snd & 3) * 8)));
-            e.busy[snd] = (uint8_t)cg_randint(e.draw(CG_SITE_STALL_SCAN, snd, s), 0, P.c.default_high);
+            if (snd < M) {
+              atomicAnd((unsigned int*)(e.flags + (snd & ~3)), ~((uint32_t)CG_F_COMP << ((snd & 3) * 8)));
+              e.busy[snd] = (uint8_t)cg_randint(e.draw(CG_SITE_STALL_SCAN, snd, s), 0, P.c.default_high);
+            }
           }
           wsync();
         }
       }
-      // untrained detector: all "D" (CDSimulator.py:718-719); trained mode is outside the pinned scope
+      else if (COLD(e.eflags & CG_E_DET_TRAIN)) {   // trained detector: IsolationForest.predict == -1 (CDSimulator.py:721-723)
+        const uint32_t* fo = nullptr;
+        const double* apl = nullptr;
+        if constexpr (XE) { if (P.b.forest) fo = P.b.forest + (size_t)e.env * CG_FOREST_WORDS; apl = P.t.apl; }
+        if (!fo || !apl || (e.eflags & CG_E_DET_PENDING)) {
+          e.eflags |= CG_E_UNPINNED;   // no current forest: all "D", flagged (cygym_spec.h)
+        } else {
+          // The window, the forest and hence the predictions are the same for every scan of this tick; a flagged
+          // sender ends up with the stall drawn by the LAST scan (ordinal n_mult - 1).  One lane per window entry
+          // walks both flat trees (<= 9 levels each, words from L2).
+          bool anom = false;
+          int snd = 0;
+          if (e.lane < w) {
+            const uint32_t idx = (uint32_t)(e.log_total - w + e.lane);
+            snd = e.ring[2 * (idx % CG_LOG_RING)];
+            const uint32_t to = e.ring[2 * (idx % CG_LOG_RING) + 1];
+            double depths = 0.0;
+#pragma nounroll
+            for (int t = 0; t < CG_FOREST_TREES; ++t) {
+              const uint32_t* tr = fo + CG_FOREST_HDR + t * CG_FOREST_NODES;
+              uint32_t nd = tr[0];
+#pragma nounroll
+              for (int it = 0; it < 16 && !CG_FN_LEAF(nd); ++it) {
+                const uint32_t x = CG_FN_FEAT(nd) ? to : (uint32_t)snd;
+                nd = tr[x <= CG_FN_THR(nd) ? CG_FN_LEFT(nd) : CG_FN_RIGHT(nd)];
+              }
+              uint32_t ns = CG_FN_NSAMP(nd);
+              if (ns >= CG_DET_APL_N) ns = CG_DET_APL_N - 1;
+              depths += ((double)CG_FN_DEPTH(nd) + apl[ns]) - 1.0;
+            }
+            const double sstar = __hiloint2double((int)fo[1], (int)fo[0]);
+            anom = depths < sstar && snd < M;   // (a ring loaded from the host with ids >= M never reaches LDS)
+          }
+          const uint64_t m = ballot(anom);
+          if (__popcll(m) >= w / 2 + 1 && anom) {
+            atomicAnd((unsigned int*)(e.flags + (snd & ~3)), ~((uint32_t)CG_F_COMP << ((snd & 3) * 8)));
+            e.busy[snd] = (uint8_t)cg_randint(e.draw(CG_SITE_STALL_SCAN, snd, n_mult - 1), 0, P.c.default_high);
+          }
+          wsync();
+        }
+      }
+      // untrained detector: all "D" (CDSimulator.py:718-719)
     }
   } else if (at == 13) {  // :1111-1123 -- acts on device_indices[0] once per listed active device
     int d0 = dev[0];

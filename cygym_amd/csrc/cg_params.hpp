@@ -18,6 +18,7 @@ struct DevTopo {
   int o_optr, o_ocol, o_os, o_ver, o_ano, o_dst, o_vul, o_nap, o_iptr, o_icol, o_ieid, o_oeid;
   int blob_bytes, lds_bytes, in_lds, multi;
   int K, KW, x_bytes;   // extra-edge list: capacity, blocked-bit words, bytes of its per-wave LDS section
+  const double* apl;    // [CG_DET_APL_N] leaf-term table of the trained detector (global; tail of the blob), or nullptr
   // global views (host-side convenience; kernels outside the tick use them)
   const uint8_t *dstatic, *vuln, *napps;
   const float *os_val, *version, *anomaly;
@@ -26,7 +27,6 @@ struct DevTopo {
 };
 
 struct KParams {
-  const KParams* self;  // device copy of this struct (fused kernel re-reads it every tick instead of pinning SGPRs)
   DevTopo t;
   cygym_config c;
   cygym_buffers b;
@@ -34,14 +34,15 @@ struct KParams {
   cygym_actions a;
   cygym_outputs o;
   int n_envs;
+  int env_begin, env_end;   // envs this launch ticks (cygym_step_range); action / output arrays stay indexed by env id
   int n_ticks;          // ticks per launch (cygym_rollout); actions / outputs are [n_ticks][N] arrays
   int wave_lds;         // bytes of LDS per wave
   int shared_lds;       // bytes of the workgroup-shared LDS section
   unsigned long long* dbg;   // diagnostic builds (-DCG_STAMPS): [N][16] s_memtime stamps per env
 };
 
-// how a kernel sees its parameters: the kernarg copy (per-tick kernel) or the device copy, through the constant
-// address space (rollout kernel)
+// how a kernel sees its parameters: as the by-value kernel argument (per-tick kernel), or through a constant-
+// address-space pointer to the kernarg segment itself, re-read at the top of every tick (rollout kernel)
 template <bool FUSED> struct KParamsOf { using type = const KParams; };
 template <> struct KParamsOf<true> { using type = const __attribute__((address_space(4))) KParams; };
 

@@ -6,6 +6,9 @@
 // ---------------- the tick ----------------
 // MT: devices per env when known at compile time (64, 256: chunk loops unroll and their LDS latencies
 // overlap), 0 = any M at run time.
+// XE: the FULL-FEATURE instantiation -- follows the edges evolve_network adds (extra-edge list), keeps the long
+// comm-log history (cygym_buffers.hist) and walks the trained detector's forest (cygym_buffers.forest).  The lean
+// instantiation (none of those buffers bound) carries none of that code.
 // Per-wave LDS carve + pointer table of one env (must match wave_lds_bytes on the host).
 // One lane per device PAIR: 12 floats = three 16-byte stores; static columns read as float2.
 __device__ __forceinline__ void write_obs(const uint8_t* flags, const float* osv, const float* ver, const float* ano,
@@ -74,19 +77,31 @@ __device__ __forceinline__ WaveAux env_setup(Env& e, uint8_t* smem, const KP& P,
 template <int WPB, int MT, bool FUSED, bool XE, bool WIDE>
 __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? CG_LB : 1)) void step_kernel(const KParams P0) {
   extern __shared__ __align__(16) uint8_t smem[];
-  // every use below goes through `P`: the kernarg copy for the single-tick kernel, the device copy for the
-  // fused one (so that it can be re-read, opaquely, at the top of every tick)
-  // The rollout kernel reads the parameters through a CONSTANT-address-space pointer: LLVM then knows that the
-  // pointers it loads from there are global ones (not LDS / scratch) and emits global_* instead of flat_*
-  // memory instructions (a flat access also ticks the LDS counter, so every LDS wait would queue behind it).
-  using KPT = typename KParamsOf<FUSED>::type;
+  // every use below goes through `P`: the by-value argument for the single-tick kernel; for the fused one a
+  // pointer to the kernarg segment itself (the struct is the only argument, so it sits at offset 0), so that it
+  // can be re-read, opaquely, at the top of every tick.  That pointer is in the CONSTANT address space: LLVM then
+  // knows that the pointers it loads from there are global ones (not LDS / scratch) and emits global_* instead
+  // of flat_* memory instructions (a flat access also ticks the LDS counter, so every LDS wait would queue
+  // behind it).  No device copy of the parameters, hence no upload before the launch and nothing shared
+  // between launches of one handle.
+#ifndef CG_KARG_PTR
+#define CG_KARG_PTR 1
+#endif
+  using KPT = typename KParamsOf<FUSED || CG_KARG_PTR>::type;
   KPT* pk;
-  if constexpr (FUSED) pk = (KPT*)(uintptr_t)P0.self; else pk = &P0;
+  if constexpr (FUSED || CG_KARG_PTR) {
+    // laundered: loads through it are not known dereferenceable at kernel entry, so the compiler leaves each one
+    // next to its use instead of hoisting ~150 scalars to the top and spilling them into VGPR lanes
+    const uint64_t pv = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t plo = (uint32_t)pv, phi = (uint32_t)(pv >> 32);
+    asm volatile("" : "+s"(plo), "+s"(phi));
+    pk = (KPT*)(((uint64_t)phi << 32) | plo);
+  } else pk = &P0;
 #define P (*pk)
   const int M = MT ? MT : P.t.M, MC = MT ? (MT + WAVE - 1) / WAVE : P.t.MC, Mp = MC * WAVE, MS = (M + 3) & ~3;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int env = uni(blockIdx.x * WPB + wave);
-  const bool live = env < P.n_envs;
+  const int env = uni(P.env_begin + blockIdx.x * WPB + wave);
+  const bool live = env < P.env_end;
   const int G = P.a.max_groups, L = P.a.max_devs;
 
   Env e;
@@ -181,7 +196,7 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? CG_LB : 1))
     // Re-derive everything uniform from the device copy of the parameters: keeping ~200 loop-invariant
     // scalars alive across the tick body would spill SGPRs into VGPRs and halve the occupancy.
     {
-      const uint64_t pv = (uint64_t)P0.self;
+      const uint64_t pv = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
       uint32_t plo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pv);
       uint32_t phi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(pv >> 32));
       asm volatile("" : "+s"(plo), "+s"(phi));   // opaque: nothing derived from it is hoisted out of the tick loop
@@ -399,6 +414,20 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? CG_LB : 1))
     }
     if (lane < CG_LOG_RING) ((uint32_t*)e.ring)[lane] = ((const uint32_t*)(P.snap.ring + (size_t)si * CG_LOG_RING * 2))[lane];
     e.blk_dirty = e.ring_dirty = true;
+    if constexpr (XE) {   // the pickled env carries its logger and detector too (volt_typhoon_env.py:1904-1936)
+      if (COLD(P.b.hist && P.snap.hist)) {
+        const uint32_t* hs = (const uint32_t*)(P.snap.hist + (size_t)si * CG_HIST_RING * 2);
+        uint32_t* hd = (uint32_t*)(P.b.hist + (size_t)env * CG_HIST_RING * 2);
+#pragma nounroll
+        for (int i = lane; i < CG_HIST_RING; i += WAVE) hd[i] = hs[i];
+      }
+      if (COLD(P.b.forest && P.snap.forest)) {
+        const uint32_t* fs = P.snap.forest + (size_t)si * CG_FOREST_WORDS;
+        uint32_t* fd = P.b.forest + (size_t)env * CG_FOREST_WORDS;
+#pragma nounroll
+        for (int i = lane; i < CG_FOREST_WORDS; i += WAVE) fd[i] = fs[i];
+      }
+    }
     if (COLD(XE && P.t.K > 0)) {   // the snapshot's extra-edge list (normally empty) replaces the episode's
       const int ns = P.snap.extra ? (int)((uint32_t)P.snap.ienv[(size_t)si * CG_I_COUNT + CG_I_FLAGS] >> CG_E_NX_SHIFT) : 0;
       const uint32_t* xs = P.snap.extra + (size_t)si * (P.t.K + P.t.KW);

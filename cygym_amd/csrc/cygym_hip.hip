@@ -67,13 +67,11 @@ struct cygym_handle {
   cygym_buffers b;
   cygym_buffers snap;
   bool bound, has_snap;
-  void* dev_blob;       // one allocation holding the topology copies
-  uint32_t* keybuf;     // randomize scratch [n_envs][Mp]
+  void* dev_blob;       // one allocation holding the topology copies (+ the detector's leaf-term table)
   int wpb, max_devs;
   bool few_waves;       // n_envs <= 16 per CU: one wave per env cannot use more than 4 waves per SIMD
   int wave_lds, shared_lds;
   hipEvent_t ev0, ev1;
-  KParams* dparams;     // device copy of the launch parameters (read by the fused kernel)
   unsigned long long* dbg;
   char err[256];
 };
@@ -92,14 +90,29 @@ static int fail(cygym_handle* h, int code, const char* fmt, const char* detail) 
     if (_e != hipSuccess) return fail(h, CYGYM_EHIP, #call ": %s", hipGetErrorString(_e)); \
   } while (0)
 
+// Development aid (never set by cygym_amd/build.py's default build): -DCG_DEV_MT=<0|64|256> compiles only the
+// instantiations of that size (and -DCG_DEV_WPB=<n> only that workgroup shape) -- a 10x shorter edit-compile-measure
+// loop.  Handles of any other shape fail at cygym_create.
+#ifdef CG_DEV_MT
+#define CG_HAS_MT(m) ((m) == CG_DEV_MT)
+#else
+#define CG_HAS_MT(m) 1
+#endif
+#ifdef CG_DEV_WPB
+#define CG_HAS_WPB(w) ((w) == CG_DEV_WPB)
+#else
+#define CG_HAS_WPB(w) 1
+#endif
 template <int MT, bool FUSED, bool XE, bool WIDE>
 static const void* kernel_for(int wpb) {
+  if constexpr (!CG_HAS_MT(MT)) return nullptr;
+  else
   switch (wpb) {
-    case 16: return (const void*)step_kernel<16, MT, FUSED, XE, WIDE>;
-    case 8: return (const void*)step_kernel<8, MT, FUSED, XE, WIDE>;
-    case 4: return (const void*)step_kernel<4, MT, FUSED, XE, WIDE>;
-    case 2: return (const void*)step_kernel<2, MT, FUSED, XE, WIDE>;
-    default: return (const void*)step_kernel<1, MT, FUSED, XE, WIDE>;
+    case 16: if constexpr (CG_HAS_WPB(16)) return (const void*)step_kernel<16, MT, FUSED, XE, WIDE>; else return nullptr;
+    case 8: if constexpr (CG_HAS_WPB(8)) return (const void*)step_kernel<8, MT, FUSED, XE, WIDE>; else return nullptr;
+    case 4: if constexpr (CG_HAS_WPB(4)) return (const void*)step_kernel<4, MT, FUSED, XE, WIDE>; else return nullptr;
+    case 2: if constexpr (CG_HAS_WPB(2)) return (const void*)step_kernel<2, MT, FUSED, XE, WIDE>; else return nullptr;
+    default: if constexpr (CG_HAS_WPB(1)) return (const void*)step_kernel<1, MT, FUSED, XE, WIDE>; else return nullptr;
   }
 }
 template <bool FUSED, bool XE, bool WIDE>
@@ -113,17 +126,23 @@ static const void* kernel_for_m(const cygym_handle* h) {
 // WIDE (lean per-tick kernel only): the block / unblock pools count their bits nine words at a time.  That costs
 // registers (108 VGPRs: 4 waves per SIMD), so it is used when the batch cannot fill more than that anyway
 // (envs <= 16 per CU) -- there a launch lasts as long as its slowest env, and block / unblock is that env.
-static const void* pick_kernel(const cygym_handle* h, bool fused) {
-  const bool xe = h->t.K > 0;
+static bool full_feature(const cygym_handle* h) { return h->t.K > 0 || h->b.forest || h->b.hist; }
+static const void* pick_kernel(const cygym_handle* h, bool fused, int full = -1) {
+  const bool xe = full < 0 ? full_feature(h) : full != 0;
   if (fused) return xe ? kernel_for_m<true, true, false>(h) : kernel_for_m<true, false, false>(h);
   if (xe) return kernel_for_m<false, true, false>(h);
   return h->few_waves ? kernel_for_m<false, false, true>(h) : kernel_for_m<false, false, false>(h);
 }
-static hipError_t set_lds_attr(cygym_handle* h) {
+static hipError_t set_lds_attr(cygym_handle* h) {   // every instantiation this handle may launch (lean and full-feature)
   const int lds = h->shared_lds + h->wave_lds * h->wpb;
-  hipError_t e = hipFuncSetAttribute(pick_kernel(h, false), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(pick_kernel(h, true), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  for (int full = (h->t.K > 0 ? 1 : 0); full < 2; ++full)
+    for (int fused = 0; fused < 2; ++fused) {
+      const void* k = pick_kernel(h, fused != 0, full);
+      if (!k) return hipErrorInvalidDeviceFunction;   // development subset build (CG_DEV_MT / CG_DEV_WPB)
+      hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) return e;
+    }
+  return hipSuccess;
 }
 
 extern "C" {
@@ -241,6 +260,7 @@ int cygym_create(const cygym_topology* topo, const cygym_config* cfg, int32_t n_
   t.o_os = take((size_t)M * 4); t.o_ver = take((size_t)M * 4); t.o_ano = take((size_t)M * 4);   // LDS only when that is free
   t.o_iptr = take((size_t)(M + 1) * 2); t.o_icol = take((size_t)(E > 0 ? E : 1) * 2); t.o_ieid = take((size_t)(E > 0 ? E : 1) * 2);
   t.o_oeid = take((size_t)(E > 0 ? E : 1) * 2);
+  const int o_apl = take(topo->det_apl ? (size_t)CG_DET_APL_N * 8 : 0);   // global only: read by trained scans
   t.blob_bytes = (int)off;
   t.multi = 0;   // duplicate (u,v) out-entries? (env._blocked holds pairs, so duplicates share their state)
   for (int u = 0; u < M && !t.multi; ++u)
@@ -260,6 +280,7 @@ int cygym_create(const cygym_topology* topo, const cygym_config* cfg, int32_t n_
   }
   memcpy(host + t.o_os, topo->os_val, (size_t)M * 4); memcpy(host + t.o_ver, topo->version, (size_t)M * 4);
   memcpy(host + t.o_ano, topo->anomaly, (size_t)M * 4);
+  if (topo->det_apl) memcpy(host + o_apl, topo->det_apl, (size_t)CG_DET_APL_N * 8);
   for (int i = 0; i <= M; ++i) { ((uint16_t*)(host + t.o_optr))[i] = (uint16_t)topo->out_ptr[i]; ((uint16_t*)(host + t.o_iptr))[i] = (uint16_t)topo->in_ptr[i]; }
   for (int k = 0; k < E; ++k) {
     ((uint16_t*)(host + t.o_ocol))[k] = (uint16_t)topo->out_col[k];
@@ -270,8 +291,6 @@ int cygym_create(const cygym_topology* topo, const cygym_config* cfg, int32_t n_
   hipError_t e1 = hipMalloc(&h->dev_blob, off);
   if (e1 == hipSuccess) e1 = hipMemcpy(h->dev_blob, host, off, hipMemcpyHostToDevice);
   free(host);
-  if (e1 == hipSuccess) e1 = hipMalloc((void**)&h->keybuf, (size_t)n_envs * t.Mp * 4);
-  if (e1 == hipSuccess) e1 = hipMalloc((void**)&h->dparams, sizeof(KParams));
   if (e1 == hipSuccess) e1 = hipEventCreate(&h->ev0);
   if (e1 == hipSuccess) e1 = hipEventCreate(&h->ev1);
   if (e1 != hipSuccess) { fail(nullptr, CYGYM_EHIP, "cygym_create: %s", hipGetErrorString(e1)); cygym_destroy(h); return CYGYM_EHIP; }
@@ -281,6 +300,7 @@ int cygym_create(const cygym_topology* topo, const cygym_config* cfg, int32_t n_
   t.os_val = (const float*)(d + t.o_os); t.version = (const float*)(d + t.o_ver); t.anomaly = (const float*)(d + t.o_ano);
   t.out_ptr = (const uint16_t*)(d + t.o_optr); t.out_col = (const uint16_t*)(d + t.o_ocol);
   t.in_ptr = (const uint16_t*)(d + t.o_iptr); t.in_col = (const uint16_t*)(d + t.o_icol); t.in_eid = (const uint16_t*)(d + t.o_ieid);
+  t.apl = topo->det_apl ? (const double*)(d + o_apl) : nullptr;
   // opt in to large dynamic LDS for every instantiation we may launch
   hipError_t e2 = set_lds_attr(h);
   if (e2 != hipSuccess) { fail(nullptr, CYGYM_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString(e2)); cygym_destroy(h); return CYGYM_EHIP; }
@@ -291,8 +311,6 @@ int cygym_create(const cygym_topology* topo, const cygym_config* cfg, int32_t n_
 void cygym_destroy(cygym_handle* h) {
   if (!h) return;
   if (h->dev_blob) (void)hipFree(h->dev_blob);
-  if (h->keybuf) (void)hipFree(h->keybuf);
-  if (h->dparams) (void)hipFree(h->dparams);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   delete h;
@@ -327,6 +345,7 @@ static KParams make_params(cygym_handle* h) {
   KParams P;
   memset(&P, 0, sizeof(P));
   P.t = h->t; P.c = h->c; P.b = h->b; P.n_envs = h->n_envs;
+  P.env_begin = 0; P.env_end = h->n_envs;
   P.wave_lds = h->wave_lds; P.shared_lds = h->shared_lds;
   P.dbg = h->dbg;
   return P;
@@ -355,6 +374,7 @@ int cygym_reset(cygym_handle* h, const cygym_buffers* snapshot, const int32_t* e
   if (rc) return rc;
   if (!env_ids) n = h->n_envs;
   if (n <= 0) return CYGYM_OK;
+  if (n > h->n_envs) return fail(h, CYGYM_EINVAL, "cygym_reset: more ids than envs%s", "");
   HIPCHK(h, hipSetDevice(h->device_id));
   KParams P = make_params(h);
   P.snap = *snapshot;
@@ -365,8 +385,9 @@ int cygym_reset(cygym_handle* h, const cygym_buffers* snapshot, const int32_t* e
   return CYGYM_OK;
 }
 
-int cygym_randomize(cygym_handle* h, const int32_t* env_ids, int32_t n, void* stream) {
+int cygym_randomize(cygym_handle* h, const int32_t* env_ids, int32_t n, uint32_t* scratch, void* stream) {
   if (!h || !h->bound) return fail(h, CYGYM_ENOTBOUND, "cygym_randomize: handle not bound%s", "");
+  if (!scratch) return fail(h, CYGYM_EINVAL, "cygym_randomize: null scratch buffer%s", "");
   if (!env_ids) n = h->n_envs;
   if (n <= 0) return CYGYM_OK;
   if (n > h->n_envs) return fail(h, CYGYM_EINVAL, "cygym_randomize: more ids than envs%s", "");
@@ -374,7 +395,7 @@ int cygym_randomize(cygym_handle* h, const int32_t* env_ids, int32_t n, void* st
   KParams P = make_params(h);
   const int threads = 256, waves_per_block = threads / WAVE;
   hipLaunchKernelGGL(randomize_kernel, dim3((n + waves_per_block - 1) / waves_per_block), dim3(threads), 0,
-                     (hipStream_t)stream, P, env_ids, n, h->keybuf);
+                     (hipStream_t)stream, P, env_ids, n, scratch);
   HIPCHK(h, hipGetLastError());
   return CYGYM_OK;
 }
@@ -389,13 +410,11 @@ int cygym_set_snapshot(cygym_handle* h, const cygym_buffers* snapshot) {
   return CYGYM_OK;
 }
 
-int cygym_step(cygym_handle* h, const cygym_actions* a, const cygym_outputs* o, void* stream) {
-  return cygym_rollout(h, 1, a, o, stream);
-}
-
-int cygym_rollout(cygym_handle* h, int32_t n_ticks, const cygym_actions* a, const cygym_outputs* o, void* stream) {
+static int launch_ticks(cygym_handle* h, int32_t n_ticks, int32_t env_begin, int32_t n, const cygym_actions* a,
+                        const cygym_outputs* o, void* stream) {
   if (!h || !h->bound) return fail(h, CYGYM_ENOTBOUND, "cygym_step: handle not bound%s", "");
   if (n_ticks < 1) return fail(h, CYGYM_EINVAL, "cygym_rollout: n_ticks must be >= 1%s", "");
+  if (env_begin < 0 || n < 0 || env_begin > h->n_envs - n) return fail(h, CYGYM_EINVAL, "cygym_step_range: env range outside [0, n_envs)%s", "");
   if (!a || !o || !a->mode || !a->n_groups || !a->atype || !a->n_exploit || !a->exploit || !a->app ||
       !a->dev_cnt || !a->dev_idx || !o->obs || !o->raw || !o->shaped || !o->done)
     return fail(h, CYGYM_EINVAL, "cygym_step: null action / output pointer%s", "");
@@ -406,15 +425,19 @@ int cygym_rollout(cygym_handle* h, int32_t n_ticks, const cygym_actions* a, cons
     HIPCHK(h, set_lds_attr(h));
   }
   if (h->c.auto_reset && !h->has_snap) return fail(h, CYGYM_EINVAL, "auto_reset needs cygym_set_snapshot first%s", "");
+  if (n == 0) return CYGYM_OK;
   HIPCHK(h, hipSetDevice(h->device_id));
   KParams P = make_params(h);
   P.a = *a; P.o = *o;
   P.n_ticks = n_ticks;
   P.snap = h->snap;
-  P.self = h->dparams;
-  if (n_ticks > 1) HIPCHK(h, hipMemcpyAsync(h->dparams, &P, sizeof(KParams), hipMemcpyHostToDevice, (hipStream_t)stream));
+  P.env_begin = env_begin; P.env_end = env_begin + n;
+  // The parameter block travels as the kernel argument only (the rollout kernel re-reads it from the kernarg
+  // segment): nothing is uploaded or shared between launches, so launches of one handle on different streams
+  // are independent as long as their env ranges are disjoint.  hipGetLastError below reports launch-time errors;
+  // a fault inside the kernel surfaces at the caller's next synchronisation.
   const int lds = h->shared_lds + h->wave_lds * h->wpb;
-  const dim3 grid((h->n_envs + h->wpb - 1) / h->wpb), block(h->wpb * WAVE);
+  const dim3 grid((n + h->wpb - 1) / h->wpb), block(h->wpb * WAVE);
   hipStream_t s = (hipStream_t)stream;
   {
     void* args[] = {(void*)&P};
@@ -422,6 +445,19 @@ int cygym_rollout(cygym_handle* h, int32_t n_ticks, const cygym_actions* a, cons
   }
   HIPCHK(h, hipGetLastError());
   return CYGYM_OK;
+}
+
+int cygym_step(cygym_handle* h, const cygym_actions* a, const cygym_outputs* o, void* stream) {
+  return launch_ticks(h, 1, 0, h ? h->n_envs : 0, a, o, stream);
+}
+
+int cygym_step_range(cygym_handle* h, int32_t env_begin, int32_t n, const cygym_actions* a, const cygym_outputs* o,
+                     void* stream) {
+  return launch_ticks(h, 1, env_begin, n, a, o, stream);
+}
+
+int cygym_rollout(cygym_handle* h, int32_t n_ticks, const cygym_actions* a, const cygym_outputs* o, void* stream) {
+  return launch_ticks(h, n_ticks, 0, h ? h->n_envs : 0, a, o, stream);
 }
 
 int cygym_observe(cygym_handle* h, int32_t role, float* out, void* stream) {

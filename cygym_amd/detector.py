@@ -1,0 +1,166 @@
+"""Host side of the trained detector (CDSimulator.py:681-723).
+
+The reference's `Detector` wraps scikit-learn's `IsolationForest(n_estimators=2, max_samples=256)`:
+`train(logs)` fits it on the `[from_device, to_device]` pairs of the last <= 2000 comm-log entries
+(volt_typhoon_env.py:955-961), `batch_predict(points)` labels a point "A" when `model.predict == -1`.
+
+In this build the split is:
+  * **train** is a host callback.  The tick of defender action 10 only records the request (forest header +
+    CG_E_DET_PENDING, cygym_spec.h); `fit_forest` below runs the very estimator the reference runs -- scikit-learn
+    is the reference's own third-party dependency, not something this repo restates -- on the env's history
+    ring, and `flatten_forest` turns the two fitted trees into the flat u32 layout the tick kernel walks.
+  * **batch_predict** runs on the device (cg_defender.hpp) / in the oracle (cygym_oracle.c): a walk over the flat
+    trees, one f64 add and one compare per point -- no pow, no log: the leaf term `apl[n]` is a 257-entry table
+    computed here with numpy (`apl_table`), and the decision threshold is folded into one f64 `S*` per forest
+    (`score_threshold`), found by bisection over the same numpy expressions scikit-learn evaluates.
+
+`fit_forest` seeds the numpy stream the fit draws from with the Philox draw addressed (env, tick, CG_SITE_DET_FIT):
+the reference draws from the process-global numpy stream there (IsolationForest(random_state=None)), which the
+oracle harness seeds with the same draw before the reference's step -- so a fixture's forest can be refitted
+bit for bit by this module (same scikit-learn version).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import rng as R
+from . import spec as S
+
+
+def apl_table() -> np.ndarray:
+    """sklearn.ensemble._iforest._average_path_length(n) for n = 0..256, f64 [257].
+    Same expression, evaluated by numpy (the table travels to device / oracle as data)."""
+    n = np.arange(S.DET_APL_N, dtype=np.float64)
+    out = np.zeros(S.DET_APL_N, np.float64)
+    out[2] = 1.0
+    m = n > 2
+    out[m] = 2.0 * (np.log(n[m] - 1.0) + np.euler_gamma) - 2.0 * (n[m] - 1.0) / n[m]
+    return out
+
+
+def _is_anomaly(s: float, denominator: float, offset: float) -> bool:
+    """IsolationForest.predict for a point whose summed depth is `s` (sklearn _compute_score_samples,
+    score_samples, decision_function, predict -- same numpy operations, on arrays like sklearn does)."""
+    depths = np.array([s], dtype=np.float64)
+    den = np.float64(denominator)
+    scores = 2 ** (-np.divide(depths, den, out=np.ones_like(depths), where=den != 0))
+    return bool(((-scores) - offset < 0)[0])
+
+
+def score_threshold(max_samples: int, n_estimators: int = 2, offset: float = -0.5) -> float:
+    """S*: the smallest f64 summed depth that is NOT an anomaly (anomaly <=> depths < S*).
+    Bisection over the (monotone) bit patterns of non-negative doubles."""
+    apl = apl_table()
+    denominator = n_estimators * float(apl[min(int(max_samples), S.DET_APL_N - 1)])
+    if denominator == 0.0:          # a single training sample: every score is 0.5 -> nothing is an anomaly
+        return 0.0
+    lo = np.array([0.0]).view(np.uint64)[0]          # anomaly(lo) may be True
+    hi = np.array([1024.0]).view(np.uint64)[0]       # never an anomaly
+    f = lambda bits: _is_anomaly(float(np.array([bits], np.uint64).view(np.float64)[0]), denominator, offset)  # noqa: E731
+    if not f(lo):
+        return 0.0
+    assert not f(hi)
+    lo, hi = int(lo), int(hi)
+    while hi - lo > 1:
+        mid = (lo + hi) // 2
+        if f(mid):
+            lo = mid
+        else:
+            hi = mid
+    return float(np.array([hi], np.uint64).view(np.float64)[0])
+
+
+def flatten_forest(model) -> np.ndarray:
+    """A fitted sklearn IsolationForest -> u32 [FOREST_WORDS] (layout: cygym_spec.h).  Header words 3..5 (the
+    request / answer ticks) are left 0 for the caller."""
+    ests = model.estimators_
+    if len(ests) != S.FOREST_TREES:
+        raise ValueError(f"expected {S.FOREST_TREES} trees, got {len(ests)}")
+    if any(list(f) != [0, 1] for f in model.estimators_features_):
+        raise ValueError("feature sub-sampling is not part of the reference's detector")
+    words = np.zeros(S.FOREST_WORDS, np.uint32)
+    sstar = score_threshold(int(model.max_samples_), len(ests), float(model.offset_))
+    words[0:2] = np.array([sstar], np.float64).view(np.uint32)
+    counts = []
+    for t, est in enumerate(ests):
+        tr = est.tree_
+        n = int(tr.node_count)
+        if n > S.FOREST_NODES - 1:
+            raise ValueError(f"tree {t} has {n} nodes")
+        depth = np.asarray(tr.compute_node_depths(), np.int64)
+        base = S.FOREST_HDR + t * S.FOREST_NODES
+        for i in range(n):
+            l, r = int(tr.children_left[i]), int(tr.children_right[i])
+            if l == -1:     # leaf
+                ns = int(tr.n_node_samples[i])
+                if not (0 <= ns < 512 and 1 <= depth[i] <= 15):
+                    raise ValueError("leaf does not fit the node encoding")
+                words[base + i] = (1 << 31) | (int(depth[i]) << 9) | ns
+            else:
+                thr = float(tr.threshold[i])
+                ft = int(tr.feature[i])
+                fl = int(np.floor(thr))
+                if ft not in (0, 1) or not (0 <= fl < 4096):
+                    raise ValueError("internal node does not fit the node encoding")
+                words[base + i] = (ft << 30) | (fl << 18) | (l << 9) | r
+        counts.append(n)
+    words[2] = counts[0] | (counts[1] << 16)
+    return words
+
+
+def predict_flat(words: np.ndarray, points, apl: np.ndarray | None = None) -> np.ndarray:
+    """Numpy walk over a flattened forest: True where IsolationForest.predict would say -1.  The host-side twin
+    of the device walk, used to check `flatten_forest` against sklearn's own predict."""
+    apl = apl_table() if apl is None else apl
+    words = np.asarray(words, np.uint32)
+    sstar = float(words[0:2].view(np.float64)[0])
+    out = np.zeros(len(points), bool)
+    for p, (a, b) in enumerate(points):
+        depths = 0.0
+        for t in range(S.FOREST_TREES):
+            base = S.FOREST_HDR + t * S.FOREST_NODES
+            w = int(words[base])
+            for _ in range(16):
+                if w >> 31:
+                    break
+                x = b if (w >> 30) & 1 else a
+                w = int(words[base + (((w >> 9) & 0x1FF) if x <= ((w >> 18) & 0xFFF) else (w & 0x1FF))])
+            depths += (float((w >> 9) & 0xF) + float(apl[min(w & 0x1FF, S.DET_APL_N - 1)])) - 1.0
+        out[p] = depths < sstar
+    return out
+
+
+def fit_seed(seed: int, env_id: int, tick: int) -> int:
+    """The 32-bit seed of the numpy stream IsolationForest.fit draws from at (env, tick)."""
+    return int(R.draw(seed, env_id, tick, S.SITE_DET_FIT, 0, 0))
+
+
+def fit_forest(X, seed32: int, n_fits: int = 1) -> np.ndarray:
+    """Detector.train(logs) (CDSimulator.py:688-695): fit the reference's estimator on the [from, to] pairs and
+    flatten it.  `n_fits` > 1: the tick asked several times (action 10 in several groups of one step_grouped
+    call); like the reference, fit that often on the same rows from ONE continuing numpy stream and keep the last.
+    Raises when scikit-learn is missing -- there is no substitute for the reference's estimator."""
+    try:
+        from sklearn.ensemble import IsolationForest
+    except ImportError as e:   # pragma: no cover
+        raise RuntimeError("trained-detector mode needs scikit-learn (the reference's own dependency, "
+                           "CDSimulator.py:683); install it or do not use defender action 10") from e
+    X = np.asarray(X, dtype=np.int64).reshape(-1, 2)
+    if len(X) == 0:
+        raise ValueError("Detector.train on an empty log is the random-detection mode (CDSimulator.py:688-690)")
+    model = IsolationForest(n_estimators=2, max_samples=256, n_jobs=1, random_state=np.random.RandomState(int(seed32)))
+    rows = [[int(a), int(b)] for a, b in X]
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")     # "max_samples (256) is greater than the total number of samples"
+        for _ in range(max(1, int(n_fits))):
+            model.fit(rows)
+    return flatten_forest(model)
+
+
+def training_window(hist_row: np.ndarray, log_total: int) -> np.ndarray:
+    """The rows Detector.train sees: the last <= TRAIN_WINDOW entries of the env's history ring
+    ([HIST_RING][2] u16, entry i of the log lives at i % HIST_RING), oldest first."""
+    n = min(int(log_total), S.TRAIN_WINDOW)
+    idx = (np.arange(int(log_total) - n, int(log_total)) % S.HIST_RING).astype(np.int64)
+    return np.asarray(hist_row).reshape(S.HIST_RING, 2)[idx].astype(np.int64)

@@ -1,7 +1,7 @@
 """Python mirror of include/cygym_spec.h (bit layouts, counter columns, RNG sites).
 
-tests/test_spec.py parses the header and checks every constant here against it,
-so the two cannot drift apart.
+tests/test_host_cpu.py::test_spec_mirror_matches_header parses the header and checks
+every constant here against it, so the two cannot drift apart.
 """
 
 # per-device dynamic flags (CDSimulatorComponents.py:217-243 flattened)
@@ -16,6 +16,7 @@ D_DC, D_SERVER = 0x01, 0x02
 # per-env flag bits
 E_HAS_CKPT, E_EVO_INIT, E_DET_TRAIN, E_DET_RANDOM = 0x01, 0x02, 0x04, 0x08
 E_PREV_SET, E_TOPO_OVF, E_BUSY_SAT = 0x10, 0x20, 0x40
+E_DET_PENDING, E_UNPINNED = 0x100, 0x200
 E_NX_SHIFT = 16   # bits 16..31 of ienv[I_FLAGS]: live entries of the env's extra-edge list
 
 # ienv columns
@@ -30,12 +31,19 @@ MODE_DEFENDER, MODE_ATTACKER = 0, 1
 MODE_PARTIAL = 0x100
 LOG_RING = 32
 SCAN_WINDOW = 30
+HIST_RING = 2048
+TRAIN_WINDOW = 2000
+
+# trained detector (IsolationForest) -- layout of one env's forest, see cygym_spec.h
+FOREST_TREES, FOREST_NODES, FOREST_HDR = 2, 512, 8
+FOREST_WORDS = FOREST_HDR + FOREST_TREES * FOREST_NODES
+DET_APL_N = 257
 
 (SITE_STALL_REVERT, SITE_STALL_CLEAN, SITE_STALL_PATCH, SITE_STALL_SCAN,
  SITE_STALL_ISOLATE, SITE_PICK_BLOCK, SITE_PICK_UNBLOCK, SITE_PROBE_SRC,
  SITE_ZERODAY, SITE_ARR_CLIENT, SITE_ARR_SERVER, SITE_ARR_TIME,
  SITE_EVO_POISSON, SITE_EVO_COIN, SITE_EVO_PICK_IN, SITE_EVO_PICK_ACT,
- SITE_EVO_ATT, SITE_EVO_PA, SITE_SHUFFLE, SITE_DET_COIN, SITE_LAZY) = range(1, 22)
+ SITE_EVO_ATT, SITE_EVO_PA, SITE_SHUFFLE, SITE_DET_COIN, SITE_LAZY, SITE_DET_FIT) = range(1, 23)
 SITE_ACTGEN = 64
 
 POISSON_TABLE = 16

@@ -4,7 +4,9 @@
  * Plain C across the boundary: pointers, sizes, PODs.  No torch / C++ types.
  * Every device buffer is CALLER-OWNED (the Python host allocates torch tensors
  * and passes tensor.data_ptr()); the library never allocates or frees HBM except
- * for its private copy of the (<= ~100 KB) shared topology made in cygym_create.
+ * for its private copy of the (<= ~100 KB) shared topology and static tables made in
+ * cygym_create and two parameter blocks of a few KB (the scratch of cygym_randomize
+ * is caller-owned too, see there).
  *
  * Each entry point cites the reference interface it replaces (paths relative to
  * the reference checkout).  The reference has no FFI of its own -- it is 100 %
@@ -30,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CYGYM_ABI_VERSION 2
+#define CYGYM_ABI_VERSION 3
 
 #define CYGYM_OK            0
 #define CYGYM_EINVAL       -1  /* bad argument / shape                       */
@@ -60,6 +62,10 @@ typedef struct cygym_topology {
   const int32_t* in_ptr;    /* [M+1] CSR of _innbrs                             */
   const int32_t* in_col;    /* [E]                                              */
   const int32_t* in_eid;    /* [E] out-CSR slot of each in-entry (blocked bit)  */
+  const double*  det_apl;   /* [CG_DET_APL_N] sklearn.ensemble._iforest._average_path_length(n), n = 0..256: the leaf
+                               term of IsolationForest's score (CDSimulator.py:683, :721-723), evaluated by the host
+                               with numpy so that device and oracle add the very same f64 values.  NULL: a scan in
+                               trained-detector mode raises CG_E_UNPINNED                                          */
 } cygym_topology;
 
 /* Scalar knobs: plain attributes of the reference env object
@@ -117,6 +123,13 @@ typedef struct cygym_buffers {
   int32_t*  ienv;       /* [N][CG_I_COUNT]                                      */
   double*   fenv;       /* [N][CG_D_COUNT]                                      */
   uint32_t* extra;      /* [N][CG_X_WORDS(K)] edges added by evolve_network (cygym_spec.h); NULL iff K == 0 */
+  uint32_t* forest;     /* [N][CG_FOREST_WORDS] the env's fitted isolation forest (cygym_spec.h), or NULL.  Detector.train
+                           (CDSimulator.py:688-695) is a HOST callback: the tick of action 10 records the request in the
+                           forest header and sets CG_E_DET_PENDING; the host fits scikit-learn's IsolationForest on the
+                           last <= CG_TRAIN_WINDOW entries of `hist`, writes the flattened trees here and clears the bit
+                           (cygym_amd/detector.py).  Detector.batch_predict (:721-723) then runs in the tick kernel.   */
+  uint16_t* hist;       /* [N][CG_HIST_RING][2] the last 2048 comm-log (from,to) pairs -- what action 10 trains on
+                           (volt_typhoon_env.py:955-961) -- or NULL (then only `ring` is kept)                          */
   int32_t   n_envs;     /* leading dimension (N, or 1 for a broadcast snapshot) */
   int32_t   reserved;
 } cygym_buffers;
@@ -174,13 +187,22 @@ int cygym_reset(cygym_handle* h, const cygym_buffers* snapshot, const int32_t* e
  * config.auto_reset (episode end inside cygym_step).  Pass NULL to clear. */
 int cygym_set_snapshot(cygym_handle* h, const cygym_buffers* snapshot);
 
-/* Replaces: randomize_compromise_and_ownership() volt_typhoon_env.py:330-383 */
-int cygym_randomize(cygym_handle* h, const int32_t* env_ids, int32_t n, void* stream);
+/* Replaces: randomize_compromise_and_ownership() volt_typhoon_env.py:330-383.
+ * scratch: DEVICE uint32 [n][ceil(M/64)*64] owned by the caller (the shuffle keys of the n envs). */
+int cygym_randomize(cygym_handle* h, const int32_t* env_ids, int32_t n, uint32_t* scratch, void* stream);
 
 /* Replaces: step(action) volt_typhoon_env.py:818-1333 and
  * step_grouped(groups) :694-779, incl. evolve_network CyberDefenseEnv.py:583-875,
  * arrivals :575-596 / CDSimulator.py:244-348, logger/detector CDSimulator.py:663-742. */
 int cygym_step(cygym_handle* h, const cygym_actions* a, const cygym_outputs* o, void* stream);
+
+/* cygym_step over the envs [env_begin, env_begin + n) only: the arrays of `a` and `o` are still indexed by env id
+ * (full [N] leading dimension).  Lets a closed-loop driver pipeline sub-batches on several streams -- one
+ * sub-batch's policy evaluation and the tail of its slowest env overlap the other sub-batches' ticks -- the
+ * batched counterpart of the reference's process-per-rollout fan-out (do_agent.py:1928-1942).  Calls on one
+ * handle that run concurrently on different streams must cover disjoint env ranges. */
+int cygym_step_range(cygym_handle* h, int32_t env_begin, int32_t n, const cygym_actions* a, const cygym_outputs* o,
+                     void* stream);
 
 /* n_ticks consecutive ticks in ONE launch: every array of `a` and `o` has a leading tick
  * dimension ([n_ticks][N]...), the actions of all ticks are staged beforehand (open-loop

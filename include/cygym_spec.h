@@ -51,6 +51,13 @@
 #define CG_E_TOPO_OVF   0x20 /* evolve wanted to add an edge that did not fit
                                 the per-env extra-edge list (max_extra_edges) */
 #define CG_E_BUSY_SAT   0x40 /* a busy counter saturated at 255            */
+/* 0x80 is kernel-private (star edges verified for the current owned set)   */
+#define CG_E_DET_PENDING 0x100 /* action 10 asked for Detector.train(non-empty logs) (volt_typhoon_env.py:945-962):
+                                  the host must fit the env's isolation forest and install it (cygym_abi.h,
+                                  cygym_buffers.forest) before the next scan                            */
+#define CG_E_UNPINNED   0x200 /* sticky: a scan ran in TRAINED mode without a current forest (no forest buffer
+                                  bound, or CG_E_DET_PENDING still set); its predictions were taken as all "D",
+                                  which the reference does not promise -- results of this env are unpinned */
 #define CG_E_NX_SHIFT   16   /* bits 16..31: number of live entries of the env's
                                 extra-edge list (edges evolve_network added,
                                 CyberDefenseEnv.py:738-843)                   */
@@ -101,6 +108,43 @@ enum {
 /* ---- comm-log ring ---- */
 #define CG_LOG_RING 32       /* entries kept per env (fast scan reads 30)  */
 #define CG_SCAN_WINDOW 30    /* volt_typhoon_env.py:1052                   */
+#define CG_HIST_RING 2048    /* optional long history (cygym_buffers.hist): what Detector.train fits on    */
+#define CG_TRAIN_WINDOW 2000 /* action 10 trains on the last <= 2000 logs  volt_typhoon_env.py:958        */
+
+/* ---- trained detector: IsolationForest(n_estimators=2, max_samples=256) CDSimulator.py:683 ----
+ * One env's fitted forest, u32 [CG_FOREST_WORDS] (cygym_buffers.forest):
+ *   header  [0],[1]  S*: f64 bits (lo, hi).  A log point is an anomaly ("A") iff  v0 + v1 < S*, where
+ *                    v_t = (depth_t + apl[n_t]) - 1.0 is the value of the leaf it reaches in tree t
+ *                    (sklearn _parallel_compute_tree_depths) -- S* is the smallest f64 sum for which
+ *                    sklearn's own  -(2 ** -(s / (2 * apl[max_samples_]))) - offset_ < 0  is false; the host
+ *                    finds it by bisection with the same numpy expressions, so the kernel needs no pow.
+ *           [2]      node count of tree 0 | tree 1 << 16
+ *           [3]      rng tick of the action-10 tick that asked for this training  (written by the tick)
+ *           [4]      len(logger.logs) at that moment                              (written by the tick)
+ *           [5]      rng tick whose request the installed forest answers          (written by the host)
+ *           [6]      how many times that tick asked (a step_grouped tick may carry action 10 in several groups:
+ *                    the reference then fits several times on the same logs, each fit continuing the numpy
+ *                    stream -- the host does the same and keeps the last forest)   (written by the tick)
+ *           [7]      reserved
+ *   tree t: words [CG_FOREST_HDR + t * CG_FOREST_NODES, +node count), node 0 = root
+ *     internal node: bit 31 = 0 | feature << 30 (0: from_device, 1: to_device) | floor(threshold) << 18 (12 bits)
+ *                    | left child << 9 | right child;  go left iff x[feature] <= threshold (ids are integers,
+ *                    so comparing with floor(threshold) is exact)
+ *     leaf:          bit 31 = 1 | depth << 9 (root = 1, sklearn compute_node_depths) | n_node_samples (9 bits)
+ * apl[n] = sklearn _average_path_length(n), n = 0..CG_DET_APL_N-1: a per-handle f64 table handed over by the host
+ * (cygym_topology.det_apl) so that no log() is evaluated on the device or in the oracle.                      */
+#define CG_FOREST_TREES 2
+#define CG_FOREST_NODES 512
+#define CG_FOREST_HDR 8
+#define CG_FOREST_WORDS (CG_FOREST_HDR + CG_FOREST_TREES * CG_FOREST_NODES)
+#define CG_DET_APL_N 257
+#define CG_FN_LEAF(w)   ((w) >> 31)
+#define CG_FN_FEAT(w)   (((w) >> 30) & 1u)
+#define CG_FN_THR(w)    (((w) >> 18) & 0xFFFu)
+#define CG_FN_LEFT(w)   (((w) >> 9) & 0x1FFu)
+#define CG_FN_RIGHT(w)  ((w) & 0x1FFu)
+#define CG_FN_DEPTH(w)  (((w) >> 9) & 0xFu)
+#define CG_FN_NSAMP(w)  ((w) & 0x1FFu)
 
 /* ---- RNG sites: one id per random call site on the step path ---- */
 enum {
@@ -125,6 +169,7 @@ enum {
   CG_SITE_SHUFFLE,           /* volt_typhoon_env.py:359          a=device (sort key)  */
   CG_SITE_DET_COIN,          /* CDSimulator.py:716               a=window pos b=scan  */
   CG_SITE_LAZY,              /* CDSimulator.py:328 (no observable effect)             */
+  CG_SITE_DET_FIT,           /* CDSimulator.py:694 IsolationForest.fit: seed of the numpy stream it draws from */
   CG_SITE_ACTGEN = 64        /* synthetic action script of bench.py (not reference)   */
 };
 

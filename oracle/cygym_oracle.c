@@ -13,8 +13,11 @@
  * (SURVEY.md section 4), so this oracle is pinned against OUTPUTS OF THE REFERENCE
  * ITSELF, run in the build container with its RNG call sites fed from the same
  * Philox stream (oracle/harness/ref_harness.py -> tests/golden/*.npz;
- * tests/test_oracle_golden.py).  Detector "trained" (IsolationForest) mode is
- * outside the pinned scope: parity unpinned there.
+ * tests/test_oracle_golden.py).  Detector "trained" mode: Detector.train is a host
+ * callback (scikit-learn's IsolationForest, the reference's own dependency; the
+ * harness exports the forests the reference fitted, flattened as in cygym_spec.h),
+ * Detector.batch_predict is restated below as a walk over those flat trees and is
+ * pinned by the fixtures whose names end in "_trained".
  *
  * Reference (paths relative to the reference checkout):
  *   step            volt_typhoon_env.py:818-1333
@@ -42,6 +45,8 @@ typedef struct {
   uint32_t* extra; /* [CG_X_WORDS(K)] edges added by evolve_network, or NULL */
   int K;
   uint16_t* ring;
+  uint16_t* hist;   /* [CG_HIST_RING][2] long comm-log history, or NULL */
+  uint32_t* forest; /* [CG_FOREST_WORDS] fitted isolation forest, or NULL */
   int32_t* ienv;
   double* fenv;
   uint32_t env_id, tick;
@@ -112,6 +117,7 @@ static void log_comm(env_t* e, int from, int to) { /* CDSimulator.py:120, :667 *
   uint32_t n = (uint32_t)e->ienv[CG_I_LOG_TOTAL];
   uint16_t* r = e->ring + 2 * (n % CG_LOG_RING);
   r[0] = (uint16_t)from; r[1] = (uint16_t)to;
+  if (e->hist) { uint16_t* q = e->hist + 2 * (n % CG_HIST_RING); q[0] = (uint16_t)from; q[1] = (uint16_t)to; }
   e->ienv[CG_I_LOG_TOTAL] = (int32_t)(n + 1);
 }
 static void set_busy(env_t* e, int d, int v) {
@@ -121,6 +127,27 @@ static void set_busy(env_t* e, int d, int v) {
 static void clear_wl(env_t* e, int d) { e->wl[d] = 0; e->flags[d] &= (uint8_t)~CG_F_WLADV; }
 static int stall(env_t* e, uint32_t site, int d, int b, int lo, int hi) {
   return cg_randint(drw(e, site, (uint32_t)d, (uint32_t)b), lo, hi);
+}
+
+/* IsolationForest.predict(point) == -1 for one (from, to) log point, over the flattened forest of cygym_spec.h:
+ * depths = sum over trees of (node depth of the leaf + apl[n_node_samples of the leaf] - 1.0)
+ * (sklearn _parallel_compute_tree_depths), anomaly iff depths < S* (the header's threshold). */
+static int forest_anomaly(const uint32_t* fo, const double* apl, unsigned from, unsigned to) {
+  uint64_t sb = (uint64_t)fo[0] | ((uint64_t)fo[1] << 32);
+  double sstar, depths = 0.0;
+  memcpy(&sstar, &sb, 8);
+  for (int t = 0; t < CG_FOREST_TREES; ++t) {
+    const uint32_t* tr = fo + CG_FOREST_HDR + t * CG_FOREST_NODES;
+    uint32_t w = tr[0];
+    for (int it = 0; it < 16 && !CG_FN_LEAF(w); ++it) {
+      unsigned x = CG_FN_FEAT(w) ? to : from;
+      w = tr[x <= CG_FN_THR(w) ? CG_FN_LEFT(w) : CG_FN_RIGHT(w)];
+    }
+    unsigned n = CG_FN_NSAMP(w);
+    if (n >= CG_DET_APL_N) n = CG_DET_APL_N - 1;
+    depths += ((double)CG_FN_DEPTH(w) + apl[n]) - 1.0;
+  }
+  return depths < sstar;
 }
 
 /* ---- defender global actions, shared by step (:918-976) and _step_apply_only (:627-668) */
@@ -153,9 +180,14 @@ static void def_global(env_t* e, int at, const int16_t* dev, int L, double* cost
       }
     }
     *cost += -1.0 * ds;
-    if (e->ienv[CG_I_LOG_TOTAL] > 0) { /* Detector.train(non-empty) CDSimulator.py:692-695 */
-      e->ienv[CG_I_FLAGS] |= CG_E_DET_TRAIN;
+    if (e->ienv[CG_I_LOG_TOTAL] > 0) { /* Detector.train(non-empty) CDSimulator.py:692-695: the fit itself is
+                                          the host's job (cygym_spec.h); the tick records the request */
+      e->ienv[CG_I_FLAGS] |= CG_E_DET_TRAIN | CG_E_DET_PENDING;
       e->ienv[CG_I_FLAGS] &= ~CG_E_DET_RANDOM;
+      if (e->forest) {
+        e->forest[6] = (e->forest[3] == e->tick && e->forest[6] > 0) ? e->forest[6] + 1 : 1;
+        e->forest[3] = e->tick; e->forest[4] = (uint32_t)e->ienv[CG_I_LOG_TOTAL];
+      }
     }
   } else if (at == 11) {
     if (L > 0) {
@@ -227,10 +259,20 @@ static void def_per_device(env_t* e, int at, const int16_t* dev, int L, int app,
           int anom[CG_SCAN_WINDOW];
           int n_anom = 0;
           int fl = e->ienv[CG_I_FLAGS];
+          int trained = (fl & CG_E_DET_TRAIN) && !(fl & CG_E_DET_RANDOM);
+          if (trained && (!e->forest || !e->t->det_apl || (fl & CG_E_DET_PENDING))) {
+            e->ienv[CG_I_FLAGS] |= CG_E_UNPINNED; /* no current forest: all "D", flagged (cygym_spec.h) */
+            trained = 0;
+          }
           for (int j = 0; j < w; ++j) { /* Detector.batch_predict CDSimulator.py:714-723 */
             int a = 0;
             if (fl & CG_E_DET_RANDOM) a = (cg_index(drw(e, CG_SITE_DET_COIN, (uint32_t)j, (uint32_t)ord), 2) == 0);
-            /* untrained -> all "D"; trained (IsolationForest) -> unpinned, treated as "D" */
+            else if (trained) { /* IsolationForest.predict == -1 (:721-723) over the flat trees */
+              uint32_t idx = total - (uint32_t)w + (uint32_t)j;
+              const uint16_t* pt = e->ring + 2 * (idx % CG_LOG_RING);
+              a = forest_anomaly(e->forest, e->t->det_apl, pt[0], pt[1]);
+            }
+            /* untrained -> all "D" (:718-719) */
             anom[j] = a; n_anom += a;
           }
           int majority = w / 2 + 1;
@@ -240,6 +282,7 @@ static void def_per_device(env_t* e, int at, const int16_t* dev, int L, int app,
             for (int j = 0; j < w; ++j) if (anom[j]) {
               uint32_t idx = total - (uint32_t)w + (uint32_t)j;
               int snd = e->ring[2 * (idx % CG_LOG_RING)];
+              if (snd >= e->M) continue; /* a ring loaded with foreign ids: the reference would raise KeyError */
               e->flags[snd] &= (uint8_t)~CG_F_COMP;
               set_busy(e, snd, stall(e, CG_SITE_STALL_SCAN, snd, ord, 0, e->c->default_high));
             }
@@ -727,6 +770,8 @@ static void bind_env(env_t* e, const cygym_topology* t, const cygym_config* c, c
   e->K = b->extra ? t->max_extra_edges : 0;
   e->extra = e->K > 0 ? b->extra + (size_t)idx * CG_X_WORDS(e->K) : NULL;
   e->ring = b->ring + (size_t)idx * CG_LOG_RING * 2;
+  e->hist = b->hist ? b->hist + (size_t)idx * CG_HIST_RING * 2 : NULL;
+  e->forest = b->forest ? b->forest + (size_t)idx * CG_FOREST_WORDS : NULL;
   e->ienv = b->ienv + (size_t)idx * CG_I_COUNT;
   e->fenv = b->fenv + (size_t)idx * CG_D_COUNT;
   e->env_id = (uint32_t)(c->env_id_base + idx);
@@ -741,6 +786,8 @@ static void snapshot_restore(env_t* e, const cygym_buffers* s, int idx) {
   memcpy(e->blocked, s->blocked + (size_t)si * e->EW, (size_t)e->EW * 4);
   if (e->extra && s->extra) memcpy(e->extra, s->extra + (size_t)si * CG_X_WORDS(e->K), (size_t)CG_X_WORDS(e->K) * 4);
   memcpy(e->ring, s->ring + (size_t)si * CG_LOG_RING * 2, CG_LOG_RING * 2 * 2);
+  if (e->hist && s->hist) memcpy(e->hist, s->hist + (size_t)si * CG_HIST_RING * 2, CG_HIST_RING * 2 * 2);
+  if (e->forest && s->forest) memcpy(e->forest, s->forest + (size_t)si * CG_FOREST_WORDS, CG_FOREST_WORDS * 4);
   memcpy(e->ienv, s->ienv + (size_t)si * CG_I_COUNT, CG_I_COUNT * 4);
   memcpy(e->fenv, s->fenv + (size_t)si * CG_D_COUNT, CG_D_COUNT * 8);
   e->ienv[CG_I_RNG_TICK] = tick; /* the draw counter is monotone across episodes */

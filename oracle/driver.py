@@ -54,7 +54,7 @@ OTHER_SHAPES = {"blocked": ("EW", np.uint32), "ring": ("R", np.uint16), "ienv": 
 STATE_KEYS = abi.STATE_PLANES + tuple(OTHER_SHAPES)
 
 
-def alloc_state(n, M, EW, K=0):
+def alloc_state(n, M, EW, K=0, detector=False):
     """Struct-of-arrays state.  `live` / `stash` are the [N][4][M] buffers of the ABI; the
     per-plane entries (flags, busy, ..., st_comp_by) are numpy VIEWS into them."""
     dims = {"EW": (EW,), "R": (S.LOG_RING, 2), "I": (S.I_COUNT,), "D": (S.D_COUNT,)}
@@ -67,6 +67,9 @@ def alloc_state(n, M, EW, K=0):
         st[k] = np.zeros((n,) + dims[d], dt)
     st["blocked_in"] = np.zeros((n, EW), np.uint32)   # derived, library-side only: the oracle never reads it
     st["extra"] = np.zeros((n, abi.x_words(K)), np.uint32)   # edges added by evolve_network (K = max_extra)
+    # trained-detector mode: the env's flattened isolation forest and the long comm-log history it is fitted on
+    st["forest"] = np.zeros((n, S.FOREST_WORDS if detector else 0), np.uint32)
+    st["hist"] = np.full((n, S.HIST_RING if detector else 0, 2), 0xFFFF, np.uint16)
     st["ring"][:] = 0xFFFF
     return st
 
@@ -110,13 +113,17 @@ def actions_struct(act) -> abi.Actions:
 class OracleBatch:
     """N envs over one shared topology, stepped by the C oracle."""
 
-    def __init__(self, topo: abi.TopologyArrays, cfg: abi.EnvConfig, n_envs: int):
+    def __init__(self, topo: abi.TopologyArrays, cfg: abi.EnvConfig, n_envs: int, detector: bool = False):
         self.topo = topo.normalised()
+        if detector and self.topo.det_apl is None:
+            from cygym_amd import detector as D
+            self.topo.det_apl = D.apl_table()
+        self.detector = bool(detector)
         self.topo.validate()
         self.cfg = cfg
         self.N = n_envs
         self.M = self.topo.M
-        self.state = alloc_state(n_envs, self.M, self.topo.EW, self.topo.max_extra)
+        self.state = alloc_state(n_envs, self.M, self.topo.EW, self.topo.max_extra, self.detector)
         self.snapshot = None
         self.obs = np.zeros((n_envs, self.M, 6), np.float32)
         self.raw = np.zeros(n_envs, np.float64)
@@ -138,7 +145,22 @@ class OracleBatch:
         if "extra" in init and self.state["extra"].size:
             src = np.asarray(init["extra"], np.uint32)
             self.state["extra"][...] = src if src.shape[0] == self.N else np.broadcast_to(src, self.state["extra"].shape)
+        for k, fill in (("forest", 0), ("hist", 0xFFFF)):
+            self.state[k][...] = fill
+            if k in init and self.state[k].size:
+                src = np.asarray(init[k]).astype(self.state[k].dtype)
+                self.state[k][...] = src if src.shape[0] == self.N else np.broadcast_to(src, self.state[k].shape)
         self.snapshot = copy_state(self.state)
+
+    def install_forest(self, env: int, words):
+        """What the host does after Detector.train: write the flattened forest (header words 3, 4 -- the
+        request the tick recorded -- stay) and clear CG_E_DET_PENDING."""
+        f = self.state["forest"][env]
+        w = np.asarray(words, np.uint32)
+        f[0:3] = w[0:3]
+        f[5] = f[3]
+        f[S.FOREST_HDR:] = w[S.FOREST_HDR:]
+        self.state["ienv"][env, S.I_FLAGS] &= ~S.E_DET_PENDING
 
     def step(self, act: dict, begin=0, end=None):
         c = self.cfg.to_c()

@@ -1,8 +1,19 @@
 """Generate tests/golden/*.npz by running the reference itself (see ref_harness.py).
 
-Run in the build container only:   python oracle/harness/make_golden.py [name ...]
+Run in the build container only:
+    python oracle/harness/make_golden.py [name ...]            (re)write tests/golden/
+    python oracle/harness/make_golden.py --check [name ...]    regenerate into a temp dir, fail on any difference
 The fixtures are plain arrays: exported topology, initial struct-of-arrays state,
 the action script, and the expected state / rewards / observations after every tick.
+
+Reproducibility.  Every scenario is generated in its OWN fresh interpreter, started with address-space
+randomisation off (`setarch -R`) and PYTHONHASHSEED=0.  The reason: the reference's network generator keeps
+`Vulnerability` objects -- which define no __hash__ -- in Python sets (CDSimulator.generateVul / generateExploits:
+`self.vulneralbilities`) and then does `random.choice(list(that_set))` (`_attach_extra`, `changeVulTarget`), so the
+network it builds depends on object ADDRESSES, i.e. on everything the process allocated before.  Generated back to
+back in one interpreter, a scenario's `static_vuln` therefore depended on which scenarios ran before it (round-1
+finding); in a fresh, non-randomised process the allocation history and hence the result is the same every time.
+Initialisation is outside the parity path (the harness exports its result); the tick itself has no such dependence.
 """
 from __future__ import annotations
 
@@ -33,8 +44,6 @@ def mixed_actions(M, def_types, att_types, kmax, X=2, unique=True):
         mode = DEF if (t % 2 == 0) else ATT
         if mode == DEF:
             at = int(rs.choice(def_types))
-            if at == 5 and env.simulator.detector.trained:
-                at = 8  # trained (IsolationForest) detector mode is outside the pinned scope
             dv = dev_list(rs, M, kmax, unique)
             if at in (2, 3, 8) and rs.rand() < 0.3:
                 dv = []
@@ -82,7 +91,7 @@ def s256_mixed():
 
 @scenario("s16_train")
 def s16_train():
-    """Action 10 (detector training) present; scans stop once the detector is trained."""
+    """Action 10 (detector training) present; later scans run the trained detector."""
     env0 = H.build_env(16, 14, init_seed=9, strip_vuln_frac=0.3)
     return H.run_scenario(env0, 2, 120, mixed_actions(16, ALL_DEF + [10, 10], ALL_ATT, 4), seed=14), 1
 
@@ -273,20 +282,128 @@ def s16_zeroday():
     return H.run_scenario(env0, 2, 120, mixed_actions(M, ALL_DEF, ALL_ATT, 4, X=3), seed=23), 1
 
 
-def main(names):
-    os.makedirs(GOLDEN, exist_ok=True)
-    for name in names:
-        res, G = SCENARIOS[name]()
-        if isinstance(res, list):
-            for bl, r in res:
-                path = os.path.join(GOLDEN, f"{name}_{bl.replace(' ', '_').lower()}.npz")
-                n, t = H.save_fixture(path, r, G)
-                print(f"{path}: N={n} T={t} {os.path.getsize(path) / 1024:.1f} KiB")
-        else:
-            path = os.path.join(GOLDEN, f"{name}.npz")
-            n, t = H.save_fixture(path, res, G)
-            print(f"{path}: N={n} T={t} {os.path.getsize(path) / 1024:.1f} KiB")
+def trained_actions(M, kmax, X=2, grouped=False):
+    """Spread-heavy attacker (fills the comm log), defender dominated by scans (5) and detector training (10)."""
+    def fn(e, t, env, rs):
+        if t % 2 == 1 or t < 3:
+            at = int(rs.choice([1, 1, 1, 2]))
+            return ATT, (at, np.array([int(rs.randint(0, X))]), [], 0)
+        if grouped and rs.rand() < 0.25:      # step_grouped honours action 10 too (volt_typhoon_env.py:654-664)
+            groups = [(int(rs.choice([10, 1, 2, 8])), np.array([0]), dev_list(rs, M, kmax), 0) for _ in range(int(rs.randint(1, 4)))]
+            return DEF, groups
+        at = int(rs.choice([5, 5, 5, 5, 10, 10, 1, 6, 7, 8, 13]))
+        dv = dev_list(rs, M, kmax, unique=rs.rand() < 0.8)
+        if at == 10 and rs.rand() < 0.5:
+            dv = []
+        return DEF, (at, np.array([0]), dv, 0)
+    return fn
+
+
+@scenario("s16_trained")
+def s16_trained():
+    """Trained-detector mode (CDSimulator.py:688-695, :721-723): action 10 fits the IsolationForest on the last
+    <= 2000 logs, every later scan (action 5) goes through its predictions, flagged senders are un-compromised
+    and stalled (volt_typhoon_env.py:1051-1069).  Retraining several times per episode."""
+    M = 16
+    env0 = H.build_env(M, 14, init_seed=131, strip_vuln_frac=0.2, extra_reachable=1)
+    return H.run_scenario(env0, 3, 260, trained_actions(M, 5), seed=41), 1
+
+
+@scenario("s64_trained")
+def s64_trained():
+    """The same at 64 devices with longer device lists, grouped ticks carrying action 10, and a log that grows
+    past the 2000-entry training window and the 2048-entry history ring."""
+    M = 64
+    env0 = H.build_env(M, 56, init_seed=141, strip_vuln_frac=0.3, extra_reachable=3)
+    return H.run_scenario(env0, 2, 220, trained_actions(M, 12, grouped=True), seed=42, env_id_base=300), 4
+
+
+def outputs_of(name):
+    """File stems a scenario writes."""
+    if name == "s16_baselines":
+        return [f"{name}_{b}" for b in ("no_defense", "no_attack", "preset")]
+    if name == "s16_none":
+        return [f"{name}_{b}" for b in ("nash", "no_defense", "no_attack", "preset")]
+    return [name]
+
+
+def generate_one(name, out_dir):
+    os.makedirs(out_dir, exist_ok=True)
+    res, G = SCENARIOS[name]()
+    if isinstance(res, list):
+        for bl, r in res:
+            path = os.path.join(out_dir, f"{name}_{bl.replace(' ', '_').lower()}.npz")
+            n, t = H.save_fixture(path, r, G)
+            print(f"{path}: N={n} T={t} {os.path.getsize(path) / 1024:.1f} KiB", flush=True)
+    else:
+        path = os.path.join(out_dir, f"{name}.npz")
+        n, t = H.save_fixture(path, res, G)
+        print(f"{path}: N={n} T={t} {os.path.getsize(path) / 1024:.1f} KiB", flush=True)
+
+
+def spawn(name, out_dir):
+    """One scenario in its own fresh interpreter: no ASLR, fixed hash seed, no bytecode written (see module doc)."""
+    import platform
+    import shutil
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--one", name, "--out", out_dir]
+    if shutil.which("setarch"):
+        cmd = ["setarch", platform.machine(), "-R"] + cmd
+    else:
+        print("[make_golden] warning: setarch not found, address-space randomisation stays on", file=sys.stderr)
+    env = dict(os.environ, PYTHONHASHSEED="0", PYTHONDONTWRITEBYTECODE="1")
+    subprocess.run(cmd, check=True, env=env)
+
+
+def compare_dirs(new_dir, old_dir, stems):
+    """Every array of every fixture must be identical (same key set, dtype, shape, bytes)."""
+    bad = []
+    for stem in stems:
+        a_path, b_path = os.path.join(new_dir, stem + ".npz"), os.path.join(old_dir, stem + ".npz")
+        if not os.path.exists(b_path):
+            bad.append(f"{stem}: not committed under {old_dir}")
+            continue
+        a, b = np.load(a_path), np.load(b_path)
+        if set(a.files) != set(b.files):
+            bad.append(f"{stem}: key sets differ: {sorted(set(a.files) ^ set(b.files))}")
+            continue
+        for k in a.files:
+            x, y = a[k], b[k]
+            if x.dtype != y.dtype or x.shape != y.shape or not np.array_equal(x, y):
+                bad.append(f"{stem}: {k} differs")
+    return bad
+
+
+def main(argv):
+    import argparse
+    import tempfile
+    ap = argparse.ArgumentParser()
+    ap.add_argument("names", nargs="*")
+    ap.add_argument("--one", help="(internal) generate this scenario in the current process")
+    ap.add_argument("--out", default=GOLDEN)
+    ap.add_argument("--check", action="store_true", help="regenerate into a temp dir and compare with tests/golden")
+    args = ap.parse_args(argv)
+    if args.one:
+        generate_one(args.one, args.out)
+        return 0
+    names = args.names or list(SCENARIOS)
+    if not args.check:
+        for name in names:
+            spawn(name, GOLDEN)
+        keysets = {stem: frozenset(np.load(os.path.join(GOLDEN, stem + ".npz")).files) for n in SCENARIOS for stem in outputs_of(n)
+                   if os.path.exists(os.path.join(GOLDEN, stem + ".npz"))}
+        if len(set(keysets.values())) > 1:
+            print("[make_golden] warning: fixtures do not share one key set (regenerate all of them)", file=sys.stderr)
+        return 0
+    with tempfile.TemporaryDirectory(prefix="cygym_golden_check_") as tmp:
+        for name in names:
+            spawn(name, tmp)
+        bad = compare_dirs(tmp, GOLDEN, [s for n in names for s in outputs_of(n)])
+    for line in bad:
+        print("DIFF", line)
+    print(f"[make_golden --check] {len(names)} scenario(s): {'clean' if not bad else str(len(bad)) + ' difference(s)'}")
+    return 1 if bad else 0
 
 
 if __name__ == "__main__":
-    main(sys.argv[1:] or list(SCENARIOS))
+    sys.exit(main(sys.argv[1:]))

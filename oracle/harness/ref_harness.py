@@ -296,6 +296,9 @@ def _inj_triangular(left, mode, right, size=None):
     return np.array([float(val)])
 
 
+_ORIG_NP_SEED = np.random.seed
+
+
 def install_rng():
     mods = load_reference()
     rnd = mods["random"]
@@ -523,6 +526,13 @@ def flatten_dynamic(env, static):
     base = len(logs) - len(tail)
     for k, l in enumerate(tail):
         ring[(base + k) % S.LOG_RING] = (int(l["from_device"]), int(l["to_device"]))
+    hist = np.full((S.HIST_RING, 2), 0xFFFF, np.uint16)     # the long history Detector.train fits on
+    htail = logs[-S.HIST_RING:]
+    hbase = len(logs) - len(htail)
+    if htail:
+        idx = (hbase + np.arange(len(htail))) % S.HIST_RING
+        hist[idx, 0] = [int(l["from_device"]) for l in htail]
+        hist[idx, 1] = [int(l["to_device"]) for l in htail]
     ienv = np.zeros(S.I_COUNT, np.int64)
     ienv[S.I_STEP_NUM] = env.step_num
     ienv[S.I_DEF_STEP] = env.defender_step
@@ -555,7 +565,26 @@ def flatten_dynamic(env, static):
     fenv[S.D_PREV_ATT_POT] = 0.0 if pp is None else float(pp)
     return dict(flags=flags, busy=busy, wl=wl, comp_by=comp_by, st_flags=st_flags, st_busy=st_busy,
                 st_wl=st_wl, st_comp_by=st_comp_by, blocked=blocked, ring=ring, ienv=ienv, fenv=fenv,
-                extra=extra)
+                extra=extra, hist=hist)
+
+
+def export_forest(env, rs_check=None):
+    """Flatten the forest the reference's Detector holds (cygym_amd/detector.py, layout in cygym_spec.h) and
+    check the flat walk against the reference's own batch_predict before it becomes a fixture."""
+    from cygym_amd import detector as D
+    det = env.simulator.detector
+    words = D.flatten_forest(det.model)
+    M = len(env.simulator.subnet.net)
+    if M <= 48:
+        pts = [(a, b) for a in range(M) for b in range(M)]
+    else:
+        rr = np.random.RandomState(M) if rs_check is None else rs_check
+        pts = [(int(a), int(b)) for a, b in rr.randint(0, M, size=(3000, 2))]
+    pts += [(int(l["from_device"]), int(l["to_device"])) for l in env.simulator.logger.logs[-64:]]
+    ref = np.array([p == "A" for p in det.batch_predict(pts)])
+    got = D.predict_flat(words, pts)
+    assert np.array_equal(ref, got), "flattened forest disagrees with the reference's batch_predict"
+    return words
 
 
 def extra_edges(env, static):
@@ -653,6 +682,12 @@ def run_scenario(env0, n_envs, n_ticks, action_fn, *, seed=0, env_id_base=0, pre
                 CTX.end()
         init_dyn = flatten_dynamic(env, static)
         init_dyn["ienv"][S.I_RNG_TICK] = rng_tick
+        det = env.simulator.detector
+        init_dyn["forest"] = np.zeros(S.FOREST_WORDS, np.uint32)
+        if det.trained:
+            init_dyn["forest"] = export_forest(env)
+        fit_id = id(getattr(det.model, "estimators_", None))
+        det_events = []     # (tick, forest words, training rows) of every Detector.train(non-empty) of this env
         ticks = []
         acts = []
         for t in range(n_ticks):
@@ -662,6 +697,10 @@ def run_scenario(env0, n_envs, n_ticks, action_fn, *, seed=0, env_id_base=0, pre
                 agent_cnt = len(env.simulator.subnet.net) + 1
             env.mode = "defender" if (mode & 0xFF) == S.MODE_DEFENDER else "attacker"
             CTX.begin(seed, env_id, rng_tick, env)
+            # IsolationForest(random_state=None).fit draws from the process-global numpy stream (CDSimulator.py:683,
+            # :694): seed it with the draw addressed (env, tick, CG_SITE_DET_FIT) -- nothing else on the step path
+            # reads that stream once poisson / triangular are injected
+            _ORIG_NP_SEED(int(R.draw(seed, env_id, rng_tick, S.SITE_DET_FIT, 0, 0)))
             err = None
             try:
                 state, raw, shaped, done, info, logs = env.step(action) if agent_cnt is None else env.step(action, agent_cnt)
@@ -671,6 +710,13 @@ def run_scenario(env0, n_envs, n_ticks, action_fn, *, seed=0, env_id_base=0, pre
                 CTX.end()
             if err is not None:
                 raise RuntimeError(f"scenario produced a reference exception at env {e} tick {t}: {err}")
+            det = env.simulator.detector
+            if det.trained and id(getattr(det.model, "estimators_", None)) != fit_id:   # refitted during this tick
+                fit_id = id(det.model.estimators_)
+                rows = [(int(l["from_device"]), int(l["to_device"])) for l in env.simulator.logger.logs[-S.TRAIN_WINDOW:]]
+                grouped = isinstance(action, (list, tuple)) and action and isinstance(action[0], (list, tuple))
+                n_fits = sum(1 for g in action if int(g[0]) == 10) if grouped else 1   # every action-10 group refits
+                det_events.append((t, rng_tick, export_forest(env), np.asarray(rows, np.int32).reshape(-1, 2), n_fits))
             rng_tick += 1
             dyn = flatten_dynamic(env, static)
             dyn["ienv"][S.I_RNG_TICK] = rng_tick
@@ -686,7 +732,8 @@ def run_scenario(env0, n_envs, n_ticks, action_fn, *, seed=0, env_id_base=0, pre
                 dyn["draws"] = list(CTX.trace)
             ticks.append(dyn)
             acts.append((mode, action))
-        per_env.append(dict(init=init_dyn, pre=pre_dyn, ticks=ticks, acts=acts))
+        pre_dyn["forest"] = np.zeros(S.FOREST_WORDS, np.uint32)
+        per_env.append(dict(init=init_dyn, pre=pre_dyn, ticks=ticks, acts=acts, det_events=det_events))
     return dict(static=static, config=config, envs=per_env, seed=seed, env_id_base=env_id_base)
 
 
@@ -742,15 +789,32 @@ def save_fixture(path, result, max_groups=1):
     N = len(envs)
     T = len(envs[0]["ticks"])
     keys = ["flags", "busy", "wl", "comp_by", "st_flags", "st_busy", "st_wl", "st_comp_by",
-            "blocked", "ring", "ienv", "fenv"]
-    if int(st.get("max_extra", 0)) > 0:
-        keys.append("extra")
+            "blocked", "ring", "ienv", "fenv", "extra"]    # `extra` has zero width when max_extra == 0
     for k in keys:
         out[f"init_{k}"] = np.stack([e["init"][k] for e in envs])
         out[f"pre_{k}"] = np.stack([e["pre"][k] for e in envs])
         out[f"exp_{k}"] = np.stack([np.stack([tk[k] for tk in e["ticks"]]) for e in envs])
     for k in ["raw", "shaped", "done", "obs", "obs_def", "obs_att", "topo_same"]:
         out[f"exp_{k}"] = np.stack([np.stack([np.asarray(tk[k]) for tk in e["ticks"]]) for e in envs])
+    # comm-log history (what Detector.train fits on): before the first tick and after the last one
+    out["init_hist"] = np.stack([e["init"]["hist"] for e in envs])
+    out["pre_hist"] = np.stack([e["pre"]["hist"] for e in envs])
+    out["fin_hist"] = np.stack([e["ticks"][-1]["hist"] for e in envs])
+    out["init_forest"] = np.stack([e["init"]["forest"] for e in envs])
+    # every Detector.train(non-empty logs) of the run (action 10): env, tick, rng tick, the forest the reference
+    # fitted (flattened: cygym_spec.h) and the rows it was fitted on
+    ev = [(i, t, rt, w, x, nf) for i, e in enumerate(envs) for (t, rt, w, x, nf) in e["det_events"]]
+    out["det_env"] = np.asarray([v[0] for v in ev], np.int32)
+    out["det_tick"] = np.asarray([v[1] for v in ev], np.int32)
+    out["det_rng_tick"] = np.asarray([v[2] for v in ev], np.int32)
+    out["det_n_fits"] = np.asarray([v[5] for v in ev], np.int32)    # fits the reference did in that tick (grouped ticks)
+    out["det_forest"] = np.stack([v[3] for v in ev]) if ev else np.zeros((0, S.FOREST_WORDS), np.uint32)
+    out["det_rows_ptr"] = np.cumsum([0] + [len(v[4]) for v in ev]).astype(np.int64)
+    out["det_rows"] = np.concatenate([v[4] for v in ev]).astype(np.int32) if ev else np.zeros((0, 2), np.int32)
+    import sklearn
+    from cygym_amd import detector as D
+    out["det_sklearn_version"] = np.array(sklearn.__version__)
+    out["static_det_apl"] = D.apl_table()
     enc = [encode_actions(e["acts"], st["M"], max_groups) for e in envs]
     for k in ["mode", "n_groups", "atype", "n_exploit", "exploit", "app", "dev_cnt", "is_none"]:
         out[f"act_{k}"] = np.stack([a[k] for a in enc])

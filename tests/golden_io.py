@@ -30,7 +30,7 @@ class Fixture:
             M=int(st["M"]), X=int(st["X"]), dstatic=st["dstatic"], vuln=st["vuln"], napps=st["napps"],
             os_val=st["os_val"], version=st["version"], anomaly=st["anomaly"], out_ptr=st["out_ptr"],
             out_col=st["out_col"], in_ptr=st["in_ptr"], in_col=st["in_col"], in_eid=st["in_eid"],
-            max_extra=int(st.get("max_extra", 0))).normalised()
+            max_extra=int(st.get("max_extra", 0)), det_apl=st["det_apl"]).normalised()
         self.K = self.topo.max_extra   # > 0: the fixture follows the edges evolve_network adds (extra-edge list)
         cfg = dict(zip([str(k) for k in z["config_keys"]], z["config_vals"]))
         inv = {v: k for k, v in abi.BASELINES.items()}
@@ -59,6 +59,20 @@ class Fixture:
             self.exp["extra"] = z["exp_extra"]
             if self.pre is not None:
                 self.pre["extra"] = z["pre_extra"]
+        # trained-detector mode: history ring the fits read, forests the reference fitted (one event per
+        # Detector.train(non-empty logs)), the rows each was fitted on
+        self.init["hist"] = z["init_hist"]
+        self.init["forest"] = z["init_forest"]
+        if self.pre is not None:
+            self.pre["hist"] = z["pre_hist"]
+        self.fin_hist = z["fin_hist"]
+        self.det_events = {}
+        ptr = z["det_rows_ptr"]
+        for i, (e, t) in enumerate(zip(z["det_env"], z["det_tick"])):
+            self.det_events.setdefault(int(t), []).append(
+                dict(env=int(e), rng_tick=int(z["det_rng_tick"][i]), forest=z["det_forest"][i], rows=z["det_rows"][ptr[i]:ptr[i + 1]],
+                     n_fits=int(z["det_n_fits"][i])))
+        self.sklearn_version = str(z["det_sklearn_version"])
         for k in ("raw", "shaped", "done", "obs", "obs_def", "obs_att", "topo_same"):
             self.exp[k] = z["exp_" + k]
         # per-env flat device lists -> padded [N][T][L]
@@ -138,6 +152,31 @@ class Fixture:
     def follows_topology(self) -> bool:
         return self.K > 0
 
+    def service_detectors(self, t, state, install):
+        """Play the host's part of Detector.train after tick t: for every training the reference did at this tick,
+        check what the tick recorded (request header, CG_E_DET_PENDING, the history ring the fit would read) against
+        the reference's own training rows, then hand the reference-fitted forest to `install(env, words)`.
+        `state`: numpy views of ienv / forest / hist after the tick."""
+        from cygym_amd import detector as D
+        for ev in self.det_events.get(t, []):
+            e = ev["env"]
+            fl = int(state["ienv"][e, S.I_FLAGS])
+            assert fl & S.E_DET_PENDING and fl & S.E_DET_TRAIN, f"{self.name} t={t} env {e}: no pending training"
+            hdr = np.asarray(state["forest"][e][:S.FOREST_HDR]).astype(np.int64)
+            lt = int(state["ienv"][e, S.I_LOG_TOTAL])
+            assert hdr[3] == ev["rng_tick"] and hdr[4] == lt and hdr[6] == ev["n_fits"], \
+                f"{self.name} t={t} env {e}: request header {hdr[3:7]} vs ({ev['rng_tick']}, {lt}, {ev['n_fits']} fits)"
+            rows = D.training_window(np.asarray(state["hist"][e]), lt)
+            np.testing.assert_array_equal(rows, ev["rows"], err_msg=f"{self.name} t={t} env {e}: training rows")
+            install(e, ev["forest"])
+
+    def check_final_hist(self, got_hist, log_total):
+        for e in range(self.N):
+            n = min(int(log_total[e]), S.HIST_RING)
+            idx = np.arange(int(log_total[e]) - n, int(log_total[e])) % S.HIST_RING
+            np.testing.assert_array_equal(np.asarray(got_hist[e]).reshape(S.HIST_RING, 2).astype(np.int64)[idx],
+                                          self.fin_hist[e].astype(np.int64)[idx], err_msg=f"{self.name}: hist env {e}")
+
 
 def compare_state(got: dict, exp: dict, label: str, ring_total=None):
     """Bit-exact comparison of the integer planes; returns list of mismatch strings."""
@@ -200,7 +239,7 @@ def check_oracle_against_fixture(fx: "Fixture") -> int:
     oracle/harness/fuzz_reference.py."""
     from oracle import driver as od
     name = fx.name
-    ob = od.OracleBatch(fx.topo, fx.cfg, fx.N)
+    ob = od.OracleBatch(fx.topo, fx.cfg, fx.N, detector=True)
     ob.load_state(fx.init)
     act = od.alloc_actions(fx.N, fx.G, fx.L)
     alive = np.ones(fx.N, bool)   # without an extra-edge list parity is defined while the topology is unchanged
@@ -208,6 +247,8 @@ def check_oracle_against_fixture(fx: "Fixture") -> int:
     for t in range(fx.T):
         fx.actions(t, act, flags=ob.state["flags"])
         obs, raw, shaped, done = ob.step(act)
+        fx.service_detectors(t, ob.state, ob.install_forest)
+        assert not (ob.state["ienv"][:, S.I_FLAGS] & S.E_UNPINNED).any(), f"{name} t={t}: a scan ran without a current forest"
         same = fx.exp["topo_same"][:, t].astype(bool)
         # where the reference ADDED edges (evolve star / PA), the build must have flagged it
         ovf = (ob.state["ienv"][:, S.I_FLAGS] & S.E_TOPO_OVF) != 0
@@ -230,4 +271,6 @@ def check_oracle_against_fixture(fx: "Fixture") -> int:
         np.testing.assert_array_equal(ob.observe(1)[sel], fx.exp["obs_def"][sel, t], err_msg=f"{name} obs_def t={t}")
         np.testing.assert_array_equal(ob.observe(2)[sel], fx.exp["obs_att"][sel, t], err_msg=f"{name} obs_att t={t}")
         checked += 1
+    if alive.all():
+        fx.check_final_hist(ob.state["hist"], ob.state["ienv"][:, S.I_LOG_TOTAL])
     return checked

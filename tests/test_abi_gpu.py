@@ -88,3 +88,67 @@ def test_launches_follow_the_callers_stream():
         np.testing.assert_array_equal(sa[k], sb[k], err_msg=k)
     np.testing.assert_array_equal(a.raw.cpu().numpy(), out["raw"][-1].cpu().numpy())
     a.close(); b.close()
+
+
+def test_sub_batches_on_streams_equal_full_batch_steps():
+    """cygym_step_range: the batch stepped as 4 sub-batches, each on its own stream (the pipelined closed-loop
+    driver of bench.py), gives the same state, rewards and observations as full-batch cygym_step."""
+    from cygym_amd.batched_env import BatchedCyberDefenseEnv
+    from cygym_amd.topology import make_topology
+    topo, init, ck = make_topology(64, 4, seed=6)
+    cfg = abi.EnvConfig(seed=6, **ck)
+    N, S_ = 300, 4     # ragged: the last sub-batch is shorter
+    a = BatchedCyberDefenseEnv(topo, cfg, N, init, device="cuda:0", max_groups=1, max_devs=8)
+    b = BatchedCyberDefenseEnv(topo, cfg, N, init, device="cuda:0", max_groups=1, max_devs=8)
+    scripts = []
+    for t in range(30):
+        act = {k: torch.empty_like(v) for k, v in a.act.items()}
+        a.gen_actions(t, act)
+        scripts.append(act)
+    torch.cuda.synchronize()
+    for t in range(30):
+        a.step(scripts[t])
+    streams = [torch.cuda.Stream(device="cuda:0") for _ in range(S_)]
+    per = (N + S_ - 1) // S_
+    for j, st in enumerate(streams):
+        lo, n = j * per, max(0, min(per, N - j * per))
+        with torch.cuda.stream(st):
+            for t in range(30):
+                b.step_range(lo, n, scripts[t])
+    torch.cuda.synchronize()
+    sa, sb = a.state_numpy(), b.state_numpy()
+    for k in ("live", "stash", "blocked", "ring", "ienv", "fenv"):
+        np.testing.assert_array_equal(sa[k], sb[k], err_msg=k)
+    np.testing.assert_array_equal(a.raw.cpu().numpy(), b.raw.cpu().numpy())
+    np.testing.assert_array_equal(a.obs.cpu().numpy(), b.obs.cpu().numpy())
+    # ranges outside the batch are refused, an empty one is a no-op
+    assert b.lib.cygym_step_range(b._h, N - 2, 3, C.byref(b.actions_struct()), C.byref(b._out), None) == EINVAL
+    assert b.lib.cygym_step_range(b._h, 5, 0, C.byref(b.actions_struct()), C.byref(b._out), None) == 0
+    a.close(); b.close()
+
+
+def test_malformed_action_tensors_are_python_errors():
+    """The kernels index the action tensors by raw pointer: wrong dtype / shape / device must be rejected on the
+    host (a short tensor would otherwise be an out-of-bounds read on the GPU)."""
+    from cygym_amd.batched_env import BatchedCyberDefenseEnv
+    from cygym_amd.topology import make_topology
+    topo, init, ck = make_topology(16, 2, seed=2)
+    env = BatchedCyberDefenseEnv(topo, abi.EnvConfig(seed=2, **ck), 8, init, device="cuda:0", max_groups=2, max_devs=4)
+    good = {k: v.clone() for k, v in env.act.items()}
+    env.step(good)
+    for k, bad in (("mode", good["mode"].to(torch.int64)), ("atype", good["atype"][:4].contiguous()),
+                   ("exploit", good["exploit"][:, :, :3].contiguous()), ("dev_cnt", good["dev_cnt"][:, :1].contiguous()),
+                   ("dev_idx", good["dev_idx"].cpu()), ("app", good["app"].t())):
+        with pytest.raises(ValueError):
+            env.step({**good, k: bad})
+    act, out = env.alloc_rollout(3)
+    env.rollout(act, out)
+    with pytest.raises(ValueError):
+        env.rollout({**act, "n_groups": act["n_groups"][:2].contiguous()}, out)
+    with pytest.raises(ValueError):
+        env.rollout(act, {**out, "obs": out["obs"][:, :4].contiguous()})
+    # raw ABI: more ids than envs, missing scratch
+    ids = torch.zeros(9, dtype=torch.int32, device="cuda:0")
+    assert env.lib.cygym_reset(env._h, None, C.c_void_p(ids.data_ptr()), 9, None) == EINVAL
+    assert env.lib.cygym_randomize(env._h, None, 8, None, None) == EINVAL
+    env.close()

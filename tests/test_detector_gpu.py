@@ -1,0 +1,89 @@
+"""Trained-detector mode on the GPU: the product's own host callback (BatchedCyberDefenseEnv.service_detectors,
+scikit-learn fit on the device-side history ring) replayed over the fixtures in which the reference trains, and the
+diagnostic for scans that run without a current forest."""
+import numpy as np
+import pytest
+
+import golden_io as gio
+from cygym_amd import abi
+from cygym_amd import spec as S
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+sklearn = pytest.importorskip("sklearn")
+
+
+@pytest.mark.parametrize("name", ["s16_trained", "s64_trained"])
+def test_product_trains_and_scans_like_the_reference(name):
+    """No forest is taken from the fixture here: action 10 -> service_detectors() fits on the env's own history ring
+    with the Philox-addressed seed; the forests must come out as the reference's, and every later scan with them."""
+    from cygym_amd.batched_env import BatchedCyberDefenseEnv
+    from oracle import driver as od
+    fx = gio.Fixture(name)
+    if fx.sklearn_version != sklearn.__version__:
+        pytest.skip(f"fixture fitted with scikit-learn {fx.sklearn_version}, here {sklearn.__version__}")
+    env = BatchedCyberDefenseEnv(fx.topo, fx.cfg, fx.N, fx.init, device="cuda:0", max_groups=fx.G, max_devs=fx.L, detector=True)
+    act = od.alloc_actions(fx.N, fx.G, fx.L)
+    fitted = 0
+    for t in range(fx.T):
+        fx.actions(t, act, flags=env.state["flags"].cpu().numpy())
+        env.set_actions_numpy(act)
+        obs, raw, shaped, done = env.step()
+        n = env.service_detectors()
+        assert n == len(fx.det_events.get(t, [])), f"{name} t={t}: {n} forests fitted"
+        for ev in fx.det_events.get(t, []):
+            got = env.state["forest"][ev["env"]].cpu().numpy().view(np.uint32)
+            np.testing.assert_array_equal(got[:3], ev["forest"][:3], err_msg=f"{name} t={t} header")
+            np.testing.assert_array_equal(got[S.FOREST_HDR:], ev["forest"][S.FOREST_HDR:], err_msg=f"{name} t={t} trees")
+        fitted += n
+        got = env.state_numpy()
+        got["ienv"] = got["ienv"].copy()
+        got["ienv"][:, S.I_FLAGS] &= ~0x80
+        bad = gio.compare_state(got, fx.expected_state(t), f"{name} t={t}")
+        assert not bad, "\n".join(bad[:8])
+        np.testing.assert_allclose(raw.cpu().numpy(), fx.exp["raw"][:, t], rtol=0, atol=1e-9)
+    assert fitted == sum(len(v) for v in fx.det_events.values()) > 0
+    assert not (env.state["ienv"][:, S.I_FLAGS] & S.E_UNPINNED).any()
+    env.close()
+
+
+@pytest.mark.parametrize("detector", [False, True])
+def test_scan_without_current_forest_is_flagged(detector):
+    """Action 10 then a scan while the training is still pending (or with no forest buffer bound at all, lean
+    kernels): all-"D" and the sticky CG_E_UNPINNED bit -- on the GPU exactly as in the oracle."""
+    from cygym_amd.batched_env import BatchedCyberDefenseEnv
+    from cygym_amd.topology import make_topology
+    from oracle import driver as od
+    topo, init, ck = make_topology(64, 4, seed=5)
+    cfg = abi.EnvConfig(seed=5, **ck)
+    N = 96
+    env = BatchedCyberDefenseEnv(topo, cfg, N, init, device="cuda:0", max_groups=1, max_devs=8, detector=detector)
+    ob = od.OracleBatch(topo, cfg, N, detector=detector)
+    ob.load_state(init)
+    act = od.alloc_actions(N, 1, 8)
+    script = [(S.MODE_ATTACKER, 1), (S.MODE_DEFENDER, 10), (S.MODE_DEFENDER, 5), (S.MODE_ATTACKER, 1), (S.MODE_DEFENDER, 5)]
+    for i, (mode, at) in enumerate(script):
+        act["mode"][:] = mode
+        act["atype"][:] = at
+        act["n_exploit"][:] = 1
+        act["exploit"][:, 0, 0] = 0
+        act["dev_cnt"][:] = 3 if at == 5 else 0
+        act["dev_idx"][:, :3] = [3, 9, 17]
+        env.set_actions_numpy(act)
+        env.step()
+        ob.step(act)
+        if detector and i == 3:      # now answer the request: the last scan runs the forest, oracle and GPU alike
+            assert env.service_detectors() == N
+            for e in range(N):
+                ob.install_forest(e, env.state["forest"][e].cpu().numpy().view(np.uint32))
+        got = env.state_numpy()
+        got["ienv"] = got["ienv"].copy()
+        got["ienv"][:, S.I_FLAGS] &= ~0x80
+        bad = gio.compare_state(got, ob.state, f"tick {i}")
+        assert not bad, "\n".join(bad[:8])
+        np.testing.assert_array_equal(got["ienv"][:, S.I_FLAGS] & (S.E_UNPINNED | S.E_DET_PENDING),
+                                      ob.state["ienv"][:, S.I_FLAGS] & (S.E_UNPINNED | S.E_DET_PENDING))
+    fl = env.state_numpy()["ienv"][:, S.I_FLAGS]
+    assert (fl & S.E_UNPINNED).all()                      # the scan at tick 2 ran on a pending request
+    assert bool((fl & S.E_DET_PENDING).any()) == (not detector)
+    env.close()

@@ -23,10 +23,21 @@ def _env(topo, cfg, n, init, **kw):
     return BatchedCyberDefenseEnv(topo, cfg, n, init, device="cuda:0", **kw)
 
 
-@pytest.mark.parametrize("name", gio.fixture_names())
-def test_hip_matches_reference_fixture(name):
+def _fixture_cases():
+    """Every fixture through the full-feature kernels (detector buffers bound); those in which the reference never
+    trains its detector also through the lean kernels."""
+    out = []
+    for name in gio.fixture_names():
+        out.append((name, True))
+        if not np.load(gio.os.path.join(gio.GOLDEN, name + ".npz"))["det_env"].size:
+            out.append((name, False))
+    return out
+
+
+@pytest.mark.parametrize("name,detector", _fixture_cases())
+def test_hip_matches_reference_fixture(name, detector):
     fx = gio.Fixture(name)
-    env = _env(fx.topo, fx.cfg, fx.N, fx.init, max_groups=fx.G, max_devs=fx.L)
+    env = _env(fx.topo, fx.cfg, fx.N, fx.init, max_groups=fx.G, max_devs=fx.L, detector=detector)
     from oracle import driver as od
     act = od.alloc_actions(fx.N, fx.G, fx.L)
     alive = np.ones(fx.N, bool)
@@ -35,7 +46,10 @@ def test_hip_matches_reference_fixture(name):
         fx.actions(t, act, flags=env.state["flags"].cpu().numpy())
         env.set_actions_numpy(act)
         obs, raw, shaped, done = env.step()
+        if fx.det_events.get(t):   # the host's part of Detector.train, with the forest the reference fitted
+            fx.service_detectors(t, env.state_numpy(), env.install_forest)
         got = env.state_numpy()
+        assert not (got["ienv"][:, S.I_FLAGS] & S.E_UNPINNED).any(), f"{name} t={t}: a scan ran without a current forest"
         same = fx.exp["topo_same"][:, t].astype(bool)
         ovf = (got["ienv"][:, S.I_FLAGS] & S.E_TOPO_OVF) != 0
         if fx.follows_topology():   # the edges evolve_network adds are part of the compared state
@@ -61,6 +75,9 @@ def test_hip_matches_reference_fixture(name):
             np.testing.assert_array_equal(env.observe(2).cpu().numpy()[sel], fx.exp["obs_att"][sel, t])
         checked += 1
     assert checked > 0
+    if detector and alive.all():
+        got = env.state_numpy()
+        fx.check_final_hist(got["hist"], got["ienv"][:, S.I_LOG_TOTAL])
     env.close()
 
 
