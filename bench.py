@@ -49,7 +49,10 @@ WORKLOADS = {
     "cfg4": (16384, 256, 1, "BASELINE configs[3], per-GPU shard: 131072 envs x 256 devices over 8 GPUs = 16384 per GPU"),
     "cfg5": (4096, 2048, 32, "BASELINE configs[4]: 4096 envs x 2048 devices / 32 subnets"),
 }
-DEFAULT_SUB = {"target": 4, "cfg2": 4, "cfg3": 4, "cfg4": 4, "cfg5": 2}
+# Sub-batches of the pipelined per-tick leg.  Measured (tools/exp_subbatch.py): it pays only when the batch
+# oversubscribes the chip (more envs than resident waves: cfg3 / cfg4 +16 %, cfg5 +19 %); at 4096 envs every env has
+# its own resident wave and a second stream only adds launches (-7 %), so those workloads step with one launch per tick.
+DEFAULT_SUB = {"target": 1, "cfg2": 1, "cfg3": 2, "cfg4": 2, "cfg5": 4}
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 PMC_SUMMARY = "r02_pmc_summary.json"   # profiles/: per workload and kernel class, bytes per launch from the --pmc passes
@@ -172,18 +175,26 @@ def run_workload(D: Dist, name, n_per_gpu, K, W, reps, sub, fused_T, seed, max_e
     sub = max(1, min(int(sub), N))
     streams = [torch.cuda.Stream(device=dev) for _ in range(sub)] if sub > 1 else []
     per = (N + sub - 1) // sub
-    ev_go = torch.cuda.Event()
 
-    def pipelined():
-        ev_go.record(main)
+    def _pipelined(cur):
         for st in streams:
-            st.wait_event(ev_go)
+            st.wait_stream(cur)
         for t in range(W, W + K):
             for j, st in enumerate(streams):
                 with torch.cuda.stream(st):
                     env.step_range(j * per, max(0, min(per, N - j * per)), scripts[t])
         for st in streams:
-            main.wait_stream(st)
+            cur.wait_stream(st)
+
+    def pipelined():
+        graph.replay()
+
+    graph = None
+    if sub > 1:   # capture the S x K launches once (fork / join of the side streams inside the capture)
+        cap = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(cap):
+            pass
+        graph = torch.cuda.CUDAGraph()
 
     def leg(issue, launches_per_tick, what):
         wall, ev, walls = timed_reps(D, env, keep, reps, issue)
@@ -195,8 +206,14 @@ def run_workload(D: Dist, name, n_per_gpu, K, W, reps, sub, fused_T, seed, max_e
 
     one = leg(single, 1, "K launches of cygym_step, one full-batch launch per tick")
     if sub > 1:
-        per_tick = leg(pipelined, sub, f"K ticks of cygym_step_range on {sub} sub-batches of {per} envs, one HIP stream each "
-                       "(closed-loop capable: every tick is its own launch)")
+        with torch.cuda.stream(cap):
+            _pipelined(cap)                     # warm-up outside the capture
+            torch.cuda.synchronize(dev)
+            with torch.cuda.graph(graph, stream=cap):
+                _pipelined(cap)
+        torch.cuda.synchronize(dev)
+        per_tick = leg(pipelined, sub, f"K ticks of cygym_step_range on {sub} sub-batches of {per} envs, one HIP stream each, replayed "
+                       "from one HIP graph (closed-loop capable: every tick of every sub-batch is its own launch)")
         per_tick["single_launch"] = {k: one[k] for k in ("value", "ms_per_step", "roofline", "rep_spread")}
         same_sub = per_tick["last_raw_reward_sum"] == one["last_raw_reward_sum"]
     else:

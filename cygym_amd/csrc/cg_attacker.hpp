@@ -120,7 +120,7 @@ __device__ __forceinline__ int spread_x_counts(Env& e, const uint16_t* cur, cons
 }
 
 template <bool XE, class KP>
-__device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32_t* expl, int n_expl,
+__device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32_t* expl, int ex0, int n_expl,
                                                 uint64_t* srcb) {
   const int M = e.M, MC = e.MC, Mp = MC * WAVE;
   uint32_t* T = e.scr;                          // [Mp] first-compromise time (source id + 1)
@@ -139,7 +139,7 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
   const bool xany = XE && x_cnt(e) > 0;   // this env has added edges: their sources walk merged rows
   int zocc = 0;
   for (int j = 0; j < n_expl; ++j) {
-    int raw = expl[j];
+    int raw = j == 0 ? ex0 : expl[j];   // expl[0] was fetched with the tick's header
     if (P.c.zero_day) {  // :1131-1146
       uint32_t mask = (uint32_t)P.c.zero_day_owned_mask;
       bool in = raw >= 0 && raw < 32 && ((mask >> raw) & 1u);
@@ -165,42 +165,48 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
     wsync();
     SUBSTAMP(10);
     [[maybe_unused]] int n_rounds = 0;   // read by the stamps of diagnostic builds
-    // fix-point rounds: a source re-examines its pick and, if an earlier source took it, resumes the scan
-    for (int round = 0; round <= M + 1; ++round) {
+    // Sweep 0: every source scans its row from the start and takes its pick.  Sweeps >= 1: a source whose pick an
+    // EARLIER source took (the only way to lose one: dc sources and reachable targets never lose) resumes behind it.
+    // The sources are in id order and a take only matters to later sources, so within a sweep the blocks run in
+    // ascending order and see each other's takes; a sweep in which no source lost its pick proves the fix point.
+    for (int sweep = 0; sweep <= M + 1; ++sweep) {
       ++n_rounds;
-      bool changed = round == 0;
+      bool lost_any = false;
       for (int b0 = 0; b0 < n_src; b0 += WAVE) {
         const int i = b0 + e.lane;
         bool coop = false;
-        int s = 0, o0 = 0, o1 = 0, k0 = 0;
+        int s = 0, o1 = 0, k0 = 0;
         uint8_t st = 0;
         if (i < n_src) {
           s = slist[i];
-          o0 = e.optr[s]; o1 = e.optr[s + 1]; k0 = cur[s]; st = e.dst[s];
+          const int o0 = e.optr[s];
+          o1 = e.optr[s + 1]; st = e.dst[s];
+          k0 = sweep == 0 ? o0 : (int)cur[s];
           const bool dc = st & CG_D_DC;
-          int k = k0;
           const bool shortrow = o1 - o0 <= LONG_ROW;
           const bool full = !shortrow && (st & CG_D_FULLROW) && !dc;
-          if (COLD(xany && x_isout(e, s))) {   // row with added edges: handled by spread_x_round below
-          } else if (shortrow || full) {
-            // Short rows and full rows share ONE re-examination of the current pick (rounds > 0): under divergence a
-            // wave runs both arms one after the other, so only the lanes that lost their pick may enter a scan.
-            bool keep = false;
-            if (round > 0 && k0 < o1) {
-              const int vc = full ? (k0 - o0) + ((k0 - o0) >= s ? 1 : 0) : (int)e.ocol[k0];
-              keep = !e.blocked(k0) && (dc || spread_ok(T, vc, s));
-            }
-            if (!keep) {
-              const int from = round == 0 ? k0 : k0 + 1;
-              if (shortrow) k = spread_scan_lane(e, T, s, dc, from, o1);
-              else          k = spread_scan_full(e, T, cand, s, from, o0, o1);
-            }
-          } else {
-            coop = round == 0 || (k0 < o1 && !(dc || spread_ok(T, e.ocol[k0], s)));
+          const bool xrow = COLD(xany && x_isout(e, s));   // row with added edges: handled by spread_x_round below
+          bool rescan = sweep == 0;
+          if (sweep > 0 && k0 < o1 && !dc && !xrow) {
+            const int vc = full ? (k0 - o0) + ((k0 - o0) >= s ? 1 : 0) : (int)e.ocol[k0];
+            rescan = !spread_ok(T, vc, s);
           }
-          if (!coop && !(xany && x_isout(e, s))) {
-            if (k != k0) { cur[s] = (uint16_t)k; changed = true; }
-            if (k < o1 && (round == 0 || k != k0)) spread_take(T, e.ocol[k], s);
+          if (rescan && !xrow) {
+            if (shortrow || full) {
+              const int from = sweep == 0 ? o0 : k0 + 1;
+              uint32_t low = 0;
+              int k, v = 0;
+              if (shortrow) { k = spread_scan_lane(e, T, s, dc, from, o1); if (k < o1) { v = e.ocol[k]; low = T[v] & 3u; } }
+              else {
+                k = spread_scan_full(e, T, cand, s, from, o0, o1);
+                if (k < o1) { v = (k - o0) + ((k - o0) >= s ? 1 : 0); low = T[v] & 3u; }
+              }
+              cur[s] = (uint16_t)k;
+              if (k < o1) atomicMin(&T[v], ((uint32_t)(s + 1) << 2) | low);
+              if (sweep > 0) lost_any = true;
+            } else {
+              coop = true;
+            }
           }
         }
         uint64_t nm = ballot(coop);   // long rows that are not "full": wave-cooperative (re)scan
@@ -209,17 +215,18 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
           nm &= nm - 1;
           const int ls = __builtin_amdgcn_readlane(s, src_lane), lo1 = __builtin_amdgcn_readlane(o1, src_lane), lk0 = __builtin_amdgcn_readlane(k0, src_lane);
           const int lst = __builtin_amdgcn_readlane((int)st, src_lane);
-          int k = spread_scan_coop(e, T, ls, lst & CG_D_DC, round == 0 ? lk0 : lk0 + 1, lo1);
-          if (k != lk0) changed = true;
+          const int k = spread_scan_coop(e, T, ls, lst & CG_D_DC, sweep == 0 ? lk0 : lk0 + 1, lo1);
+          if (sweep > 0) lost_any = true;
           if (e.lane == 0) {
             cur[ls] = (uint16_t)k;
             if (k < lo1) spread_take(T, e.ocol[k], ls);
           }
         }
+        if (sweep > 0) wsync();   // the next block must see this block's takes
       }
-      if constexpr (XE) { if (COLD(xany)) { if (spread_x_round(e, T, cur, slist, n_src, round)) changed = true; } }
+      if constexpr (XE) { if (COLD(xany)) { if (spread_x_round(e, T, cur, slist, n_src, sweep) && sweep > 0) lost_any = true; } }
       wsync();
-      if (!__any(changed)) break;
+      if (sweep > 0 && !__any(lost_any)) break;
     }
     SUBSTAMP(11);
     SUBVAL(15, n_rounds);

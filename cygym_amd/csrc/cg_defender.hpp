@@ -151,8 +151,8 @@ __device__ __forceinline__ Pick pool_pick(const PoolPtrs q, bool want, uint32_t 
   const int r = (int)cg_index(u, (uint32_t)n);
   const bool from_out = r < n_out;
   int slot = -1, j = -1;
-  if (from_out) slot = range_select(q.blk, o0, o1, want, r);
-  else          j = range_select(q.bin, i0, i1, want, r - n_out);
+  if (from_out) slot = WIDE ? range_select_wide(q.blk, o0, o1, want, r) : range_select(q.blk, o0, o1, want, r);
+  else          j = WIDE ? range_select_wide(q.bin, i0, i1, want, r - n_out) : range_select(q.bin, i0, i1, want, r - n_out);
   if (from_out) { p.slot = slot; p.j = q.oeid[slot]; p.x = q.ocol[slot]; }      // independent loads
   else          { p.j = j; p.slot = q.ieid[j]; p.x = q.icol[j]; }
   return p;
@@ -306,20 +306,26 @@ __device__ __forceinline__ void def_per_device(Env& e, const KP& P, int at, cons
       // Speculate: every remaining entry picks on the bitmasks as they stand.  An entry is exact unless an
       // EARLIER remaining entry flips an edge ending at its device (or is the same device); apply the exact
       // prefix in parallel and repeat from the first inexact entry (at least one entry retires per pass).
+      // The first-touch table is stamped with the pass number (high bits), so it is cleared once per chunk of the
+      // list, not once per pass: an entry of an older pass compares as "nobody touched this device yet".
+      for (int i = e.lane; i < e.MC * WAVE; i += WAVE) fh[i] = 0u;
+      wsync();
+      uint32_t epoch = 0;
       while (am) {
-        for (int i = e.lane; i < e.MC * WAVE; i += WAVE) fh[i] = 0xFFFFFFFFu;
-        wsync();
+        epoch += 0x100u;   // (pass + 1) << 8, above the 6 lane bits
         const bool mine = (am >> e.lane) & 1ull;
         Pick pk; pk.slot = -1; pk.j = -1; pk.x = -1;
         if (mine) {
           uint32_t uu = u;
           if (!simple) { const int b = occ[d]; if (b > 0) uu = e.draw(site, d, b); }
           pk = pool_pick<WIDE>(q, want, uu, o0, o1, i0, i1);
-          if (pk.slot >= 0) atomicMin(&fh[pk.x], (uint32_t)e.lane);
-          if (!simple) atomicMin(&fh[d], (uint32_t)e.lane);   // a repeated device must wait for its first occurrence
+          // key = epoch | (63 - lane): atomicMax keeps the newest pass and, within it, the smallest lane
+          if (pk.slot >= 0) atomicMax(&fh[pk.x], epoch | (uint32_t)(63 - e.lane));
+          if (!simple) atomicMax(&fh[d], epoch | (uint32_t)(63 - e.lane));   // a repeated device must wait for its first occurrence
         }
         wsync();
-        const bool taint = mine && fh[d] < (uint32_t)e.lane;
+        const uint32_t ft = mine ? fh[d] : 0u;
+        const bool taint = mine && (ft & ~0xFFu) == epoch && (63u - (ft & 0x3Fu)) < (uint32_t)e.lane;
         const uint64_t tm = ballot(taint);
         const int q0 = tm ? __builtin_ctzll(tm) : WAVE;
         const bool apply = mine && pk.slot >= 0 && e.lane < q0;

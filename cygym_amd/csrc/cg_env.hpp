@@ -22,11 +22,11 @@ struct Env {
   int K;
   bool x_dirty;
   // shared LDS (topology)
-  const uint16_t *optr, *ocol;
+  const uint16_t *optr, *ocol, *iptr_l;
   const uint8_t *dst, *vul, *nap;
   const float *osv, *ver, *ano;
-  // in-CSR + slot<->entry maps: global memory (L2-resident blob); read by block/unblock and evolve only
-  const uint16_t *iptr_g, *icol_g, *ieid_g, *oeid_g;
+  // in-CSR columns + slot<->entry maps: global memory (L2-resident blob); read by block/unblock only
+  const uint16_t *icol_g, *ieid_g, *oeid_g;
   uint8_t* stash;    // global [4][M] of this env
   // misc
   int M, MC, MS, lane, env;
@@ -42,7 +42,7 @@ struct Env {
     return cg_draw(seed, env_id, tick, site, a, b);
   }
   __device__ __forceinline__ bool blocked(int slot) const { return (blk[slot >> 5] >> (slot & 31)) & 1u; }
-  __device__ __forceinline__ int iptr(int d) const { return iptr_g[d]; }
+  __device__ __forceinline__ int iptr(int d) const { return iptr_l[d]; }
   __device__ __forceinline__ void set_busy(int d, int v) {
     if (v > 255) { v = 255; eflags |= CG_E_BUSY_SAT; }
     busy[d] = (uint8_t)v;
@@ -93,10 +93,33 @@ __device__ __forceinline__ int range_select(const uint32_t* blk, int a, int b, b
     if (w == w0) x &= 0xFFFFFFFFu << (a & 31);
     if (w == w1 && ((b & 31) != 0)) x &= 0xFFFFFFFFu >> (32 - (b & 31));
     int c = __popc(x);
-    if (r < c) return (w << 5) + nth_bit32(x, r);
+    if (r < c) return (w << 5) + nth_bit32_bisect(x, r);
     r -= c;
   }
   return -1;
+}
+
+// range_select with up to nine words read at once (rows of <= 256 slots) and the in-word rank by bisection; per-lane
+// callers only (block / unblock pools), see range_popc_wide
+__device__ __forceinline__ int range_select_wide(const uint32_t* blk, int a, int b, bool want, int r) {
+  const int w0 = a >> 5, w1 = (b - 1) >> 5;
+  if (w1 - w0 >= 9) return range_select(blk, a, b, want, r);
+  const uint32_t inv = want ? 0u : 0xFFFFFFFFu;
+  const uint32_t m_lo = 0xFFFFFFFFu << (a & 31), m_hi = (b & 31) ? 0xFFFFFFFFu >> (32 - (b & 31)) : 0xFFFFFFFFu;
+  int cum = 0, wsel = 0, rbase = 0;
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {   // which word holds rank r: nine independent reads, values die in their popcount
+    const int w = w0 + j;
+    uint32_t v = blk[w <= w1 ? w : w1] ^ inv;
+    if (j == 0) v &= m_lo;
+    if (w == w1) v &= m_hi;
+    cum += w <= w1 ? __popc(v) : 0;
+    if (cum <= r && w < w1) { wsel = j + 1; rbase = cum; }
+  }
+  uint32_t xs = blk[w0 + wsel] ^ inv;   // one more read for the word itself
+  if (wsel == 0) xs &= m_lo;
+  if (w0 + wsel == w1) xs &= m_hi;
+  return ((w0 + wsel) << 5) + nth_bit32_bisect(xs, r - rbase);
 }
 
 // multiplicity of every device in a list -> bytes in scr (as uint8 [Mp]); ids >= M ignored.

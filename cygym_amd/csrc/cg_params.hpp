@@ -8,10 +8,10 @@ constexpr int WAVE = 64;
 
 // The shared topology lives in ONE packed device blob whose layout is also the layout of the
 // workgroup-shared LDS section (copied with 16-byte loads): byte offsets o_* into the blob.
-//   [optr u16 M+1][ocol u16 E][dst u8 M][vul u8 M][nap u8 M] | [os f32 M][ver f32 M][ano f32 M] | [iptr u16 M+1][icol u16 E][ieid u16 E][oeid u16 E]
+//   [optr u16 M+1][ocol u16 E][dst u8 M][vul u8 M][nap u8 M][iptr u16 M+1] | [os f32 M][ver f32 M][ano f32 M] | [icol u16 E][ieid u16 E][oeid u16 E]
 //   (ieid: out-slot of an in-entry; oeid: in-entry of an out-slot)
 // The first `lds_bytes` bytes are staged in LDS: up to and including the float columns (in_lds), or without them
-// when that buys more resident waves (choose_launch); the in-CSR is read from the L2-resident blob.
+// when that buys more resident waves (choose_launch); the in-CSR columns are read from the L2-resident blob.
 struct DevTopo {
   int M, X, E, EW, MC, Mp;
   const uint8_t* blob;

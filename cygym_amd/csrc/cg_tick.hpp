@@ -61,7 +61,7 @@ __device__ __forceinline__ WaveAux env_setup(Env& e, uint8_t* smem, const KP& P,
   e.optr = (const uint16_t*)(smem + P.t.o_optr); e.ocol = (const uint16_t*)(smem + P.t.o_ocol);
   e.osv = (const float*)(smem + P.t.o_os); e.ver = (const float*)(smem + P.t.o_ver); e.ano = (const float*)(smem + P.t.o_ano);   // valid when P.t.in_lds
   e.dst = smem + P.t.o_dst; e.vul = smem + P.t.o_vul; e.nap = smem + P.t.o_nap;
-  e.iptr_g = (const uint16_t*)(P.t.blob + P.t.o_iptr); e.icol_g = (const uint16_t*)(P.t.blob + P.t.o_icol);
+  e.iptr_l = (const uint16_t*)(smem + P.t.o_iptr); e.icol_g = (const uint16_t*)(P.t.blob + P.t.o_icol);
   e.ieid_g = (const uint16_t*)(P.t.blob + P.t.o_ieid); e.oeid_g = (const uint16_t*)(P.t.blob + P.t.o_oeid);
   e.M = M; e.MC = MC; e.MS = MS; e.lane = lane; e.env = env;
   e.cbits = 32 - __builtin_clz((unsigned)(4 * ((MS / 4 + WAVE - 1) / WAVE)));
@@ -75,7 +75,10 @@ __device__ __forceinline__ WaveAux env_setup(Env& e, uint8_t* smem, const KP& P,
 // FUSED: cygym_rollout (n_ticks > 1).  The per-env scalars are parked in LDS between ticks so that they are
 // not loop-carried registers; the single-tick instantiation has a compile-time trip count of 1.
 template <int WPB, int MT, bool FUSED, bool XE, bool WIDE>
-__global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? CG_LB : 1)) void step_kernel(const KParams P0) {
+// Register budget (second launch-bound = minimum waves per SIMD): the fused kernel and the WIDE per-tick kernel must keep 4 waves per SIMD (16 per CU: with one wave
+// per env and <= 16 envs per CU that is the whole batch in ONE residency round -- at 3 per SIMD a quarter of the
+// batch would wait for a second round); the full-feature per-tick kernel is capped for 6.
+__global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? CG_LB : (WIDE ? 4 : 1))) void step_kernel(const KParams P0) {
   extern __shared__ __align__(16) uint8_t smem[];
   // every use below goes through `P`: the by-value argument for the single-tick kernel; for the fused one a
   // pointer to the kernarg segment itself (the struct is the only argument, so it sits at offset 0), so that it
@@ -118,6 +121,8 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? CG_LB : 1))
   int32_t ie[CG_I_COUNT];
   double fe[CG_D_COUNT];
   int mode = 0, ng = 0, at0 = 8, cnt0 = 0, nexp0 = 0, app0 = -1;
+  int ex0 = -1;   // first exploit id of an attacker spread: fetched as soon as the header says so (its latency hides
+                  // behind the staging), not inside the spread where the heaviest envs would wait a full round trip
   uint4 r0 = make_uint4(0, 0, 0, 0);
   uint32_t ringw = 0;
   constexpr int PF_BLK = 2, PF_DEV = 1;   // words / list entries per lane prefetched into registers
@@ -138,6 +143,7 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? CG_LB : 1))
     cnt0 = P.a.dev_cnt[(size_t)env * G];
     nexp0 = P.a.n_exploit[(size_t)env * G];
     app0 = P.a.app[(size_t)env * G];
+    if ((mode & 0xFF) == CG_MODE_ATTACKER && at0 == 1 && ng == 0) ex0 = P.a.exploit[(size_t)env * G * CG_MAX_EXPLOITS];
     if (vec && lane < items) r0 = ((const uint4*)g_live)[lane];
     if (lane < CG_LOG_RING) ringw = ((const uint32_t*)(P.b.ring + (size_t)env * CG_LOG_RING * 2))[lane];
 #pragma unroll
@@ -218,6 +224,7 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? CG_LB : 1))
     cnt0 = P.a.dev_cnt[te * G];
     nexp0 = P.a.n_exploit[te * G];
     app0 = P.a.app[te * G];
+    if ((mode & 0xFF) == CG_MODE_ATTACKER && at0 == 1 && ng == 0) ex0 = P.a.exploit[te * G * CG_MAX_EXPLOITS];
     const int16_t* gd = P.a.dev_idx + te * L;
     for (int q = lane; q < L; q += WAVE) e.devl[q] = gd[q];
     wsync();
@@ -283,7 +290,7 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? CG_LB : 1))
         int ne = nexp0;
         if (ne > CG_MAX_EXPLOITS) ne = CG_MAX_EXPLOITS;
         __builtin_amdgcn_s_setprio(3);   // the spread bounds the launch: win issue arbitration over short envs
-        attacker_spread<XE>(e, P, P.a.exploit + te * G * CG_MAX_EXPLOITS, ne, srcb);
+        attacker_spread<XE>(e, P, P.a.exploit + te * G * CG_MAX_EXPLOITS, ex0, ne, srcb);
         __builtin_amdgcn_s_setprio(0);
       } else {
         attacker_probe<XE>(e, srcb, cost);

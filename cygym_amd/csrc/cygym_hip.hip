@@ -39,7 +39,11 @@
 #define CG_FUSED_LB 4
 #endif
 #ifndef CG_LB
-#define CG_LB 6
+// Full-feature per-tick kernels: 4 waves per SIMD (128 VGPRs).  At 6 (80 VGPRs) they spilled 5-11 VGPRs on top of
+// ~150 SGPRs kept in VGPR lanes, and with the parameter block read through the laundered kernarg pointer that
+// combination miscompiled: a spilled SGPR pair (an f64 env accumulator) came back clobbered after the divergent
+// block / unblock code at run-time sizes (caught by every full-feature fixture test).  No VGPR spills, no problem.
+#define CG_LB 4
 #endif
 #define CG_E_STAR_OK 0x80  // kernel-private: star edges verified for the current owned set
 
@@ -159,8 +163,9 @@ static size_t wave_lds_bytes(const DevTopo& t, int max_devs) {
              align_up((size_t)max_devs * 2, 16) + (size_t)t.x_bytes + 128 /* scalar parking of the fused kernel */;
   return align_up(w, 16);
 }
-// The in-CSR (iptr/icol/ieid/oeid, ~2/3 of the blob) is read by block/unblock only (~9 % of env-ticks):
-// it stays in global memory (L2-resident) and only the first o_iptr bytes are staged in LDS every tick.
+// The in-CSR columns and slot maps (icol/ieid/oeid, ~2/3 of the blob) are read by block/unblock only (~9 % of
+// env-ticks): they stay in global memory (L2-resident); the staged prefix ends before them (o_icol), or already
+// before the float columns (o_os).
 static int choose_launch(cygym_handle* h, int max_devs) {
   DevTopo& t = h->t;
   const size_t lds_cap = 160 * 1024;
@@ -171,7 +176,7 @@ static int choose_launch(cygym_handle* h, int max_devs) {
   // The three static float columns (os / version / anomaly, 12 bytes per device) feed only the observation
   // writer: they ride in LDS unless leaving them in the L2-resident blob buys more resident waves (M >= 1024).
   for (int floats = 1; floats >= 0; --floats) {
-    const size_t shared = (size_t)(floats ? t.o_iptr : t.o_os);
+    const size_t shared = (size_t)(floats ? t.o_icol : t.o_os);
     for (int wpb = 16; wpb >= 1; wpb >>= 1) {
       if (forced && wpb != forced) continue;
       const size_t per_wg = shared + wave * wpb;
@@ -184,7 +189,7 @@ static int choose_launch(cygym_handle* h, int max_devs) {
     }
   }
   if (!best) return -1;
-  const size_t shared = (size_t)(best_floats ? t.o_iptr : t.o_os);
+  const size_t shared = (size_t)(best_floats ? t.o_icol : t.o_os);
   h->wpb = best; h->wave_lds = (int)wave; h->shared_lds = (int)shared;
   t.lds_bytes = (int)shared; t.in_lds = best_floats;   // in_lds: the float columns are staged too
   h->max_devs = max_devs;
@@ -257,8 +262,9 @@ int cygym_create(const cygym_topology* topo, const cygym_config* cfg, int32_t n_
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 16); return (int)o; };
   t.o_optr = take((size_t)(M + 1) * 2); t.o_ocol = take((size_t)(E > 0 ? E : 1) * 2);
   t.o_dst = take(M); t.o_vul = take(M); t.o_nap = take(M);
+  t.o_iptr = take((size_t)(M + 1) * 2);   // in-row bounds: always staged (block / unblock and evolve read them per lane)
   t.o_os = take((size_t)M * 4); t.o_ver = take((size_t)M * 4); t.o_ano = take((size_t)M * 4);   // LDS only when that is free
-  t.o_iptr = take((size_t)(M + 1) * 2); t.o_icol = take((size_t)(E > 0 ? E : 1) * 2); t.o_ieid = take((size_t)(E > 0 ? E : 1) * 2);
+  t.o_icol = take((size_t)(E > 0 ? E : 1) * 2); t.o_ieid = take((size_t)(E > 0 ? E : 1) * 2);
   t.o_oeid = take((size_t)(E > 0 ? E : 1) * 2);
   const int o_apl = take(topo->det_apl ? (size_t)CG_DET_APL_N * 8 : 0);   // global only: read by trained scans
   t.blob_bytes = (int)off;

@@ -26,6 +26,9 @@ from . import abi, host_logic as HL
 from . import spec as S
 
 
+_NP_OF = {torch.int32: np.int32, torch.int16: np.int16, torch.uint8: np.uint8}
+
+
 class Discrete:
     """Stand-in for gym.spaces.Discrete (n, sample, contains)."""
 
@@ -210,16 +213,22 @@ class CyberDefenseEnvView:
 
     # ---- the tick -------------------------------------------------------------
     def _launch(self, groups, grouped, partial=False):
+        """Tick THIS env only: its row of the batch's action tensors is written (a few bytes, host to device) and
+        the launch covers the one-env range [i, i + 1) (cygym_step_range) -- the cost of a view's step does not
+        depend on how many envs the batch holds."""
         b, i = self._b, self._i
-        act = {k: v.cpu().numpy() for k, v in b.act.items()}
-        act["n_groups"][:] = -1                          # every other env of the batch stays put
-        HL.encode_into(act, i, self.mode, groups, grouped, b.M)
+        row = {k: np.zeros((1,) + tuple(v.shape[1:]), dtype=_NP_OF[v.dtype]) for k, v in b.act.items()}
+        row["exploit"][:] = -1
+        row["app"][:] = -1
+        HL.encode_into(row, 0, self.mode, groups, grouped, b.M)
         if partial:
-            act["mode"][i] |= S.MODE_PARTIAL
-        b.set_actions_numpy(act)
-        obs, raw, shaped, done = b.step()
-        torch.cuda.synchronize(b.device)
-        self.state = obs[i].reshape(-1).cpu().numpy().astype(np.float64)
+            row["mode"][0] |= S.MODE_PARTIAL
+        for k, v in b.act.items():
+            v[i:i + 1].copy_(torch.from_numpy(row[k]))
+        obs, raw, shaped, done = b.step_range(i, 1)
+        if b.detector and any(int(g[0]) == 10 for g in groups):
+            b.service_detectors()        # Detector.train is synchronous in the reference (volt_typhoon_env.py:961)
+        self.state = obs[i].reshape(-1).cpu().numpy().astype(np.float64)   # (.cpu() synchronises with the launch)
         return float(raw[i].item()), float(shaped[i].item()), bool(done[i].item())
 
     def _info(self, action_taken, executed=None, grouped=False, partial=False):
