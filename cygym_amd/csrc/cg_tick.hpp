@@ -123,9 +123,16 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? CG_LB : (WI
   int mode = 0, ng = 0, at0 = 8, cnt0 = 0, nexp0 = 0, app0 = -1;
   int ex0 = -1;   // first exploit id of an attacker spread: fetched as soon as the header says so (its latency hides
                   // behind the staging), not inside the spread where the heaviest envs would wait a full round trip
-  uint4 r0 = make_uint4(0, 0, 0, 0);
+  // Prefetch depths (items per lane held in registers between the load and the LDS store): at a compile-time size
+  // the whole state is one item per lane; at run-time sizes (up to 2048 devices: 8 items of the live block, 5
+  // blocked words, 8 KB of topology per wave) deep enough that the prologue stays ONE memory round trip instead of
+  // a load -> wait -> store chain per item.
+  constexpr int PF_LIVE = MT ? (MT / 4 + WAVE - 1) / WAVE : 8;
+  uint4 rl[PF_LIVE];
+#pragma unroll
+  for (int j = 0; j < PF_LIVE; ++j) rl[j] = make_uint4(0, 0, 0, 0);
   uint32_t ringw = 0;
-  constexpr int PF_BLK = 2, PF_DEV = 1;   // words / list entries per lane prefetched into registers
+  constexpr int PF_BLK = MT ? 2 : 5, PF_DEV = 1;   // words / list entries per lane prefetched into registers
   uint32_t bw[PF_BLK], bwi[PF_BLK];
   int16_t dv[PF_DEV];
   const bool vec = (M & 3) == 0;
@@ -144,7 +151,10 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? CG_LB : (WI
     nexp0 = P.a.n_exploit[(size_t)env * G];
     app0 = P.a.app[(size_t)env * G];
     if ((mode & 0xFF) == CG_MODE_ATTACKER && at0 == 1 && ng == 0) ex0 = P.a.exploit[(size_t)env * G * CG_MAX_EXPLOITS];
-    if (vec && lane < items) r0 = ((const uint4*)g_live)[lane];
+    if (vec) {
+#pragma unroll
+      for (int j = 0; j < PF_LIVE; ++j) { const int i = lane + j * WAVE; rl[j] = ((const uint4*)g_live)[i < items ? i : 0]; }
+    }
     if (lane < CG_LOG_RING) ringw = ((const uint32_t*)(P.b.ring + (size_t)env * CG_LOG_RING * 2))[lane];
 #pragma unroll
     for (int j = 0; j < PF_BLK; ++j) {
@@ -160,7 +170,7 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? CG_LB : (WI
     const uint4* src = (const uint4*)P.t.blob;
     uint4* dstp = (uint4*)smem;
     const int n16 = P.t.lds_bytes >> 4, stride = WPB * WAVE;
-    constexpr int PF_BLOB = 4;
+    constexpr int PF_BLOB = MT ? 4 : 8;
     uint4 br[PF_BLOB];
 #pragma unroll
     for (int j = 0; j < PF_BLOB; ++j) { const int i = threadIdx.x + j * stride; br[j] = src[i < n16 ? i : n16 - 1]; }   // unconditional: stays in registers
@@ -170,8 +180,9 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? CG_LB : (WI
   }
   if (live) {
     if (vec) {
-      if (lane < items) ((uint4*)e.flags)[lane] = r0;
-      for (int i = lane + WAVE; i < items; i += WAVE) ((uint4*)e.flags)[i] = ((const uint4*)g_live)[i];
+#pragma unroll
+      for (int j = 0; j < PF_LIVE; ++j) { const int i = lane + j * WAVE; if (i < items) ((uint4*)e.flags)[i] = rl[j]; }
+      for (int i = lane + PF_LIVE * WAVE; i < items; i += WAVE) ((uint4*)e.flags)[i] = ((const uint4*)g_live)[i];
     } else {
       for (int pl = 0; pl < 4; ++pl)
         for (int i = lane; i < MS; i += WAVE) e.flags[pl * MS + i] = i < M ? g_live[pl * M + i] : (pl == 0 ? (uint8_t)CG_F_NYA : (uint8_t)0);

@@ -61,8 +61,8 @@ def make_topology(M: int, n_blocks: int = 1, seed: int = 0, n_exploits: int = 2,
     for v, u in edges:
         outdeg[v] += 1
     deg = indeg + outdeg
-    n_dc = max(1, int(math.ceil(M / 50)))
-    n_owned = max(1, int(round(0.05 * M)))
+    from .interchange import scaling_knobs
+    n_dc, n_owned, _ = scaling_knobs(M)   # initialize_environment's knobs at the reference defaults (:1580-1591)
     order = np.argsort(-deg, kind="stable")
     dcs = order[:n_dc]
     owned = rs.choice(M, size=min(n_owned, M), replace=False)

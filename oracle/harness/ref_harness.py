@@ -367,205 +367,8 @@ def build_env(M, n_active, *, init_seed=1, overrides=None, strip_vuln_frac=0.0,
     return env
 
 
-def exploit_index_map(env):
-    ids = [e.id for e in env.simulator.exploits]
-    return {eid: i for i, eid in reversed(list(enumerate(ids)))}
-
-
-def flatten_static(env):
-    """Topology + static per-device columns, as the kernels consume them."""
-    net = env.simulator.subnet.net
-    ids = list(net.keys())
-    M = len(ids)
-    assert ids == list(range(M)), "device ids must be 0..M-1 in dict order"
-    exps = env.simulator.exploits
-    X = len(exps)
-    dstatic = np.zeros(M, np.uint8)
-    vuln = np.zeros(M, np.uint8)
-    napps = np.zeros(M, np.uint8)
-    os_val = np.zeros(M, np.float32)
-    version = np.zeros(M, np.float32)
-    anomaly = np.zeros(M, np.float32)
-    for i, d in net.items():
-        if getattr(d, "device_type", None) == "DomainController":
-            dstatic[i] |= S.D_DC
-        if d.wtype == "server":
-            dstatic[i] |= S.D_SERVER
-        napps[i] = min(255, len(d.apps))
-        for e, ex in enumerate(exps):
-            hit = any(v.id in ex.target for app in d.apps.values() for v in app.vulnerabilities.values())
-            if hit:
-                vuln[i] |= (1 << e)
-        os_val[i] = env.os_to_float(d.OS)
-        try:
-            version[i] = float(d.version)
-        except Exception:
-            version[i] = -1.0
-        a = d.anomaly_score
-        anomaly[i] = -1.0 if a is None else float(a)
-    out_ptr = np.zeros(M + 1, np.int32)
-    out_col = []
-    for u in range(M):
-        nb = env._outnbrs.get(u, [])
-        out_col.extend(int(v) for v in nb)
-        out_ptr[u + 1] = len(out_col)
-    out_col = np.asarray(out_col, np.int32)
-    # in-CSR in the order of env._innbrs, each entry mapped to an out-CSR slot
-    in_ptr = np.zeros(M + 1, np.int32)
-    in_col, in_eid = [], []
-    used = {}
-    for v in range(M):
-        for u in env._innbrs.get(v, []):
-            u = int(u)
-            k = used.get((u, v), 0)
-            row = out_col[out_ptr[u]:out_ptr[u + 1]]
-            pos = [j for j, w in enumerate(row) if w == v]
-            assert k < len(pos), f"in-edge ({u},{v}) has no matching out entry"
-            in_col.append(u)
-            in_eid.append(int(out_ptr[u]) + pos[k])
-            used[(u, v)] = k + 1
-        in_ptr[v + 1] = len(in_col)
-    return dict(M=M, X=X, dstatic=dstatic, vuln=vuln, napps=napps, os_val=os_val, version=version,
-                anomaly=anomaly, out_ptr=out_ptr, out_col=out_col, in_ptr=in_ptr,
-                in_col=np.asarray(in_col, np.int32), in_eid=np.asarray(in_eid, np.int32))
-
-
-def flatten_config(env):
-    assert not env.turbo, "turbo=True (throttled workloads / skipped detector) is outside the restated path"
-    return dict(
-        num_of_device=int(env.numOfDevice), min_network_size=int(env.Min_network_size),
-        max_exploits=int(env.MaxExploits), evolve_period=int(env._evolve_period),
-        work_scale=float(env.work_scale), comp_scale=float(env.comp_scale), def_scale=float(env.def_scale),
-        gamma=float(env.γ), lambda_events=float(env.lambda_events), p_add=float(env.p_add),
-        p_attacker=float(env.p_attacker),
-        workload_cap=(-1 if env.workload_cap is None else int(env.workload_cap)),
-        workload_period_base=int(env.workload_period_base), workload_period_max=int(env.workload_period_max),
-        scaling_vulnerability=int(bool(env.scaling_vulnerability)), fast_scan=int(bool(env.fast_scan)),
-        n_att_actions=int(env.attacker_action_space.n), n_def_actions=int(env.defender_action_space.n),
-        zero_day=int(bool(env.zero_day)), default_high=int(env.default_high),
-        baseline={"Nash": 0, "No Defense": 1, "Preset": 2, "No Attack": 3}[env.base_line],
-        zero_day_owned_mask=zero_day_mask(env),
-    )
-
-
-def zero_day_mask(env):
-    if not getattr(env, "zero_day", False):
-        return 0
-    m = 0
-    for i in set(env.common_exploit_indices) | set(env.private_exploit_indices):
-        m |= (1 << int(i))
-    return m
-
-
-def flatten_dynamic(env, static):
-    """Per-env mutable state as the SoA planes of include/cygym_spec.h."""
-    net = env.simulator.subnet.net
-    M = static["M"]
-    emap = exploit_index_map(env)
-    flags = np.zeros(M, np.uint8)
-    busy = np.zeros(M, np.int32)
-    wl = np.zeros(M, np.int32)
-    comp_by = np.zeros(M, np.uint8)
-    st_flags = np.zeros(M, np.uint8)
-    st_busy = np.zeros(M, np.int32)
-    st_wl = np.zeros(M, np.int32)
-    st_comp_by = np.zeros(M, np.uint8)
-    active_ids = getattr(env, "_active_ids", None)
-    busy_set = env._busy_devices
-    busy_ids = {d.id for d in busy_set} if not isinstance(busy_set, dict) else {d.id for d in busy_set.keys()}
-    for i, d in net.items():
-        f = 0
-        if d.isCompromised: f |= S.F_COMP
-        if d.attacker_owned: f |= S.F_OWNED
-        if d.Known_to_attacker: f |= S.F_KNOWN
-        if d.reachable_by_attacker: f |= S.F_REACH
-        if d.Not_yet_added: f |= S.F_NYA
-        if active_ids is not None and i in active_ids: f |= S.F_EVOACT
-        if i in busy_ids: f |= S.F_BUSYC
-        w = d.workload
-        if w is not None:
-            pt = int(w.processing_time or 0)
-            wl[i] = pt
-            if getattr(w, "adversarial", False): f |= S.F_WLADV
-        flags[i] = f
-        busy[i] = int(d.busy_time or 0)
-        for eid in d.compromised_by:
-            comp_by[i] |= (1 << emap[eid])
-        st = env._device_ckpts.get(i)
-        if st is not None:
-            sf = S.S_VALID
-            if st["isCompromised"]: sf |= S.F_COMP
-            if st["Known_to_attacker"]: sf |= S.F_KNOWN
-            if st["reachable_by_attacker"]: sf |= S.F_REACH
-            if st["Not_yet_added"]: sf |= S.F_NYA
-            sw = st["workload"]
-            if sw:
-                st_wl[i] = int(sw["processing_time"])
-                if sw["adversarial"]: sf |= S.F_WLADV
-            st_flags[i] = sf
-            st_busy[i] = int(st["busy_time"])
-            for eid in st["compromised_by"]:
-                st_comp_by[i] |= (1 << emap[eid])
-    E = len(static["out_col"])
-    blocked = np.zeros(E, np.uint8)
-    for (u, v) in env._blocked:
-        lo, hi = static["out_ptr"][u], static["out_ptr"][u + 1]
-        for j in range(lo, hi):
-            if static["out_col"][j] == v:
-                blocked[j] = 1
-    # edges evolve_network added since the export (CyberDefenseEnv.py:738-843): the multiset difference
-    # between the live neighbour cache and the exported CSR, as the env's extra-edge list
-    K = int(static.get("max_extra", 0))
-    xe = extra_edges(env, static)
-    extra = abi.pack_extra(xe, [(u, v) in env._blocked for (u, v) in xe], K) if K > 0 else np.zeros(0, np.uint32)
-    if K == 0:
-        xe = []
-    logs = env.simulator.logger.logs
-    ring = np.full((S.LOG_RING, 2), -1, np.int32)
-    tail = logs[-S.LOG_RING:]
-    base = len(logs) - len(tail)
-    for k, l in enumerate(tail):
-        ring[(base + k) % S.LOG_RING] = (int(l["from_device"]), int(l["to_device"]))
-    hist = np.full((S.HIST_RING, 2), 0xFFFF, np.uint16)     # the long history Detector.train fits on
-    htail = logs[-S.HIST_RING:]
-    hbase = len(logs) - len(htail)
-    if htail:
-        idx = (hbase + np.arange(len(htail))) % S.HIST_RING
-        hist[idx, 0] = [int(l["from_device"]) for l in htail]
-        hist[idx, 1] = [int(l["to_device"]) for l in htail]
-    ienv = np.zeros(S.I_COUNT, np.int64)
-    ienv[S.I_STEP_NUM] = env.step_num
-    ienv[S.I_DEF_STEP] = env.defender_step
-    ienv[S.I_ATT_STEP] = env.attacker_step
-    ienv[S.I_WORK_DONE] = env.work_done
-    ienv[S.I_CKPT_CNT] = env.checkpoint_count
-    ienv[S.I_REVERT_CNT] = env.revert_count
-    ienv[S.I_SCAN_CNT] = env.scan_cnt
-    ienv[S.I_COMP_CNT] = env.compromised_devices_cnt
-    ienv[S.I_EDGES_BLOCKED] = env.edges_blocked
-    ienv[S.I_EDGES_ADDED] = env.edges_added
-    ef = 0
-    if env.checkpoint is not None: ef |= S.E_HAS_CKPT
-    if active_ids is not None: ef |= S.E_EVO_INIT
-    det = env.simulator.detector
-    if det.trained: ef |= S.E_DET_TRAIN
-    if det.random_detection: ef |= S.E_DET_RANDOM
-    if getattr(env, "_prev_att_potential", None) is not None: ef |= S.E_PREV_SET
-    ienv[S.I_FLAGS] = ef | (len(xe) << S.E_NX_SHIFT)
-    ienv[S.I_LOG_TOTAL] = len(logs)
-    disc = 0
-    for e, ex in enumerate(env.simulator.exploits):
-        if getattr(ex, "discovered", False):
-            disc |= (1 << e)
-    ienv[S.I_DISCOVERED] = disc
-    fenv = np.zeros(S.D_COUNT, np.float64)
-    fenv[S.D_DEF_COST] = env.defensive_cost
-    fenv[S.D_CLEAN_COST] = env.clearning_cost
-    pp = getattr(env, "_prev_att_potential", None)
-    fenv[S.D_PREV_ATT_POT] = 0.0 if pp is None else float(pp)
-    return dict(flags=flags, busy=busy, wl=wl, comp_by=comp_by, st_flags=st_flags, st_busy=st_busy,
-                st_wl=st_wl, st_comp_by=st_comp_by, blocked=blocked, ring=ring, ienv=ienv, fenv=fenv,
-                extra=extra, hist=hist)
+from cygym_amd.interchange import (exploit_index_map, flatten_static, flatten_config, zero_day_mask,   # noqa: E402,F401
+                                    flatten_dynamic, extra_edges)
 
 
 def export_forest(env, rs_check=None):
@@ -585,47 +388,6 @@ def export_forest(env, rs_check=None):
     got = D.predict_flat(words, pts)
     assert np.array_equal(ref, got), "flattened forest disagrees with the reference's batch_predict"
     return words
-
-
-def extra_edges(env, static):
-    """Sorted (u, v) list of the edges present in env._outnbrs but not in the exported CSR.  Also checks
-    the two ordering facts the flat restatement relies on: a rebuilt neighbour row is the exported row
-    merged with the added edges by ascending neighbour id, and env._active_ids iterates ascending."""
-    from collections import Counter
-    M = static["M"]
-    op, oc = static["out_ptr"], static["out_col"]
-    ip, ic = static["in_ptr"], static["in_col"]
-    added = []
-    for u in range(M):
-        base = [int(v) for v in oc[op[u]:op[u + 1]]]
-        cur = [int(v) for v in env._outnbrs.get(u, [])]
-        diff = Counter(cur) - Counter(base)
-        assert not (Counter(base) - Counter(cur)), f"edges of {u} disappeared"
-        for v, c in diff.items():
-            assert c == 1 and v not in base, f"added edge ({u},{v}) duplicates an existing one"
-            added.append((u, int(v)))
-        if diff:
-            xs = sorted(diff)
-            merged, j = [], 0
-            for v in base:
-                while j < len(xs) and xs[j] < v:
-                    merged.append(xs[j]); j += 1
-                merged.append(v)
-            merged.extend(xs[j:])
-            assert merged == cur, f"row {u}: merged order {merged} != cache {cur}"
-    added.sort()
-    if added:
-        for d in {v for _, v in added}:
-            base = [int(u) for u in ic[ip[d]:ip[d + 1]]]
-            xs = sorted(u for (u, v) in added if v == d)
-            merged, j = [], 0
-            for u in base:
-                while j < len(xs) and xs[j] < u:
-                    merged.append(xs[j]); j += 1
-                merged.append(u)
-            merged.extend(xs[j:])
-            assert merged == [int(u) for u in env._innbrs.get(d, [])], f"in-row {d} order"
-    return added
 
 
 class AscendingSet(set):
@@ -660,6 +422,11 @@ def run_scenario(env0, n_envs, n_ticks, action_fn, *, seed=0, env_id_base=0, pre
     `action` is whatever the reference's step() accepts (None, a 4-tuple, or a list of
     4-tuples for step_grouped).  Returns a dict of stacked arrays."""
     install_rng()
+    if getattr(env0, "zero_day", False):   # the product's restatement of the zero-day bookkeeping (:1504-1563) vs the reference's sets
+        from cygym_amd.interchange import zero_day_bookkeeping
+        zb = zero_day_bookkeeping(len(env0.simulator.exploits), env0.k_known, env0.j_private, sorted(env0.private_exploit_indices))
+        assert set(zb["common"]) == set(env0.common_exploit_indices) and set(zb["private"]) == set(env0.private_exploit_indices)
+        assert zb["owned_mask"] == zero_day_mask(env0) and len(zb["pool"]) == len(env0.unknown_pool_ids)
     static = flatten_static(env0)
     static["max_extra"] = int(max_extra)   # capacity of the per-env extra-edge list in this fixture
     config = flatten_config(env0)

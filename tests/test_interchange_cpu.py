@@ -1,0 +1,66 @@
+"""cygym_amd/interchange.py without the reference: the scaling knobs and zero-day bookkeeping it mirrors, and
+`from_reference_env` on a stand-in object that exposes the attribute surface the function reads (the real check --
+the reference's own env objects -- runs in the oracle harness, which exports every golden fixture through it)."""
+from types import SimpleNamespace as NS
+
+import numpy as np
+
+from cygym_amd import interchange as I
+from cygym_amd import spec as S
+
+
+def test_scaling_knobs_and_zero_day_sets():
+    assert I.scaling_knobs(256) == (6, 13, 3) and I.scaling_knobs(2048) == (41, 102, 3) and I.scaling_knobs(16) == (1, 1, 3)
+    assert I.scaling_knobs(40, scaling_vulnerability=False) == (3, 5, 3)                # :1588-1591
+    assert I.scaling_knobs(100, sv_apps_per_device=0.05)[2] == 8
+    z = I.zero_day_bookkeeping(3, k_known=1, j_private=2, private_pick=[2])
+    assert z["common"] == [0] and z["pool"] == [1, 2] and z["private"] == [2] and z["owned_mask"] == 0b101
+    assert z["prior_pi"] == {1: 0.5, 2: 0.5}
+    assert I.zero_day_bookkeeping(2, k_known=-3, j_private=None)["owned_mask"] == 0b01   # invalid knobs fall back (:1508-1511)
+
+
+def _fake_env():
+    """Four devices: 0 is an attacker-owned hub with edges to everyone, 3 is a domain controller and not yet added."""
+    vul = NS(id="CVE-A")
+    ex = NS(id="EXP-A", target={"CVE-A": vul}, discovered=False)
+    def dev(i, **kw):
+        d = NS(id=i, device_type="workstation", wtype="server", apps={0: NS(vulnerabilities={"CVE-A": vul} if i in (1, 2) else {})},
+               OS=NS(id=i), version=1.0 + i, anomaly_score=None, isCompromised=False, attacker_owned=False,
+               Known_to_attacker=False, reachable_by_attacker=False, Not_yet_added=False, workload=None, busy_time=0,
+               compromised_by=set())
+        d.__dict__.update(kw)
+        return d
+    net = {0: dev(0, attacker_owned=True, isCompromised=True, Known_to_attacker=True),
+           1: dev(1, isCompromised=True, compromised_by={"EXP-A"}, busy_time=2, workload=NS(processing_time=3, adversarial=True)),
+           2: dev(2, reachable_by_attacker=True),
+           3: dev(3, device_type="DomainController", wtype="client", Not_yet_added=True)}
+    env = NS(simulator=NS(subnet=NS(net=net), exploits=[ex], logger=NS(logs=[{"from_device": 0, "to_device": 1}] * 3),
+                          detector=NS(trained=False, random_detection=False)),
+             _outnbrs={0: [1, 2, 3], 1: [0], 2: [3], 3: []}, _innbrs={0: [1], 1: [0], 2: [0], 3: [0, 2]}, _blocked={(0, 2)},
+             _busy_devices=[net[1]], _device_ckpts={}, os_to_float=lambda os: float(os.id), turbo=False,
+             numOfDevice=3, Min_network_size=2, MaxExploits=6, _evolve_period=2, work_scale=1.0, comp_scale=30.0, def_scale=1.0,
+             γ=0.99, lambda_events=0.7, p_add=0.1, p_attacker=0.0, workload_cap=None, workload_period_base=50, workload_period_max=200,
+             scaling_vulnerability=True, fast_scan=True, attacker_action_space=NS(n=4), defender_action_space=NS(n=14),
+             zero_day=False, default_high=3, base_line="Nash", step_num=7, defender_step=4, attacker_step=3, work_done=2,
+             checkpoint_count=0, revert_count=0, scan_cnt=1, compromised_devices_cnt=5, edges_blocked=1, edges_added=0,
+             checkpoint=None, defensive_cost=1.5, clearning_cost=0.3)
+    return env
+
+
+def test_from_reference_env_reads_the_attribute_surface():
+    topo, init, kw = I.from_reference_env(_fake_env())
+    topo.validate()
+    assert topo.M == 4 and topo.X == 1 and topo.E == 5
+    np.testing.assert_array_equal(topo.out_ptr, [0, 3, 4, 5, 5])
+    np.testing.assert_array_equal(topo.out_col, [1, 2, 3, 0, 3])
+    np.testing.assert_array_equal(topo.dstatic, [S.D_SERVER, S.D_SERVER, S.D_SERVER, S.D_DC])
+    np.testing.assert_array_equal(topo.vuln, [0, 1, 1, 0])
+    f = init["flags"][0]
+    assert f[0] == S.F_COMP | S.F_OWNED | S.F_KNOWN and f[1] == S.F_COMP | S.F_BUSYC | S.F_WLADV
+    assert f[2] == S.F_REACH and f[3] == S.F_NYA
+    assert init["busy"][0, 1] == 2 and init["wl"][0, 1] == 3 and init["comp_by"][0, 1] == 1
+    np.testing.assert_array_equal(init["blocked"][0], [0, 1, 0, 0, 0])        # (0, 2) is the second out-slot of device 0
+    assert init["ienv"][0, S.I_STEP_NUM] == 7 and init["ienv"][0, S.I_LOG_TOTAL] == 3 and init["fenv"][0, S.D_DEF_COST] == 1.5
+    assert kw["comp_scale"] == 30.0 and kw["n_att_actions"] == 4 and kw["baseline"] == "Nash" and kw["workload_cap"] == -1
+    from cygym_amd import abi
+    abi.EnvConfig(seed=1, **kw).to_c()       # the keyword dict is a valid EnvConfig
