@@ -380,6 +380,20 @@ class BatchedCyberDefenseEnv:
                    self._h, "cygym_observe")
         return out
 
+    def visibility_mask(self, role: str) -> torch.Tensor:
+        """IPPO / MAPPO's `build_visibility_mask(env, role)` (IPPO.py:74-96) for every env at once, on the device:
+        [N, M] float32, 1 where the device is visible to the role -- attacker: Known_to_attacker and attacker_owned and
+        not Not_yet_added; defender: attacker_owned and not Not_yet_added.  Pure tensor ops on the flag plane (no
+        launch of this library, no host round trip), for closed-loop policies that mask their per-device heads."""
+        f = self.state["flags"]
+        if role == "attacker":
+            want = S.F_KNOWN | S.F_OWNED
+        elif role == "defender":
+            want = S.F_OWNED
+        else:
+            raise ValueError("role must be 'attacker' or 'defender'")
+        return ((f & (want | S.F_NYA)) == want).to(torch.float32)
+
     def timer_start(self):
         _lib.check(self.lib.cygym_timer_start(self._h, self._stream()), self._h, "cygym_timer_start")
 

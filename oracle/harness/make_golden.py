@@ -6,13 +6,15 @@ Run in the build container only:
 The fixtures are plain arrays: exported topology, initial struct-of-arrays state,
 the action script, and the expected state / rewards / observations after every tick.
 
-Reproducibility.  Every scenario is generated in its OWN fresh interpreter, started with address-space
-randomisation off (`setarch -R`) and PYTHONHASHSEED=0.  The reason: the reference's network generator keeps
-`Vulnerability` objects -- which define no __hash__ -- in Python sets (CDSimulator.generateVul / generateExploits:
-`self.vulneralbilities`) and then does `random.choice(list(that_set))` (`_attach_extra`, `changeVulTarget`), so the
-network it builds depends on object ADDRESSES, i.e. on everything the process allocated before.  Generated back to
-back in one interpreter, a scenario's `static_vuln` therefore depended on which scenarios ran before it (round-1
-finding); in a fresh, non-randomised process the allocation history and hence the result is the same every time.
+Reproducibility.  The reference's network generator keeps `App` / `Vulnerability` objects -- which define no
+__hash__ -- in Python sets (CDSimulator.py:26, :30) and then does `random.choice(list(that_set))` (`_attach_extra`,
+`changeVulTarget`), so the network it builds depends on object ADDRESSES, i.e. on everything the process allocated
+before: generated back to back in one interpreter, a scenario's `static_vuln` depended on which scenarios ran
+before it (round-1 finding), and even in fresh interpreters it moved when this harness's own imports changed.
+Two measures: (1) ref_harness gives those two classes a creation-order hash (class attributes swapped at start-up,
+reference files untouched), which removes the address dependence at its root; (2) every scenario is generated in
+its OWN fresh interpreter with PYTHONHASHSEED=0 (string-keyed sets) and, belt and braces, address-space
+randomisation off (`setarch -R`; `--aslr` leaves it on, to show that the result no longer depends on it).
 Initialisation is outside the parity path (the harness exports its result); the tick itself has no such dependence.
 """
 from __future__ import annotations
@@ -341,13 +343,18 @@ def generate_one(name, out_dir):
         print(f"{path}: N={n} T={t} {os.path.getsize(path) / 1024:.1f} KiB", flush=True)
 
 
+ASLR = False
+
+
 def spawn(name, out_dir):
     """One scenario in its own fresh interpreter: no ASLR, fixed hash seed, no bytecode written (see module doc)."""
     import platform
     import shutil
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--one", name, "--out", out_dir]
-    if shutil.which("setarch"):
+    if ASLR:
+        pass
+    elif shutil.which("setarch"):
         cmd = ["setarch", platform.machine(), "-R"] + cmd
     else:
         print("[make_golden] warning: setarch not found, address-space randomisation stays on", file=sys.stderr)
@@ -382,7 +389,10 @@ def main(argv):
     ap.add_argument("--one", help="(internal) generate this scenario in the current process")
     ap.add_argument("--out", default=GOLDEN)
     ap.add_argument("--check", action="store_true", help="regenerate into a temp dir and compare with tests/golden")
+    ap.add_argument("--aslr", action="store_true", help="leave address-space randomisation on in the child interpreters")
     args = ap.parse_args(argv)
+    global ASLR
+    ASLR = args.aslr
     if args.one:
         generate_one(args.one, args.out)
         return 0

@@ -151,3 +151,23 @@ def test_facade_graph_follows_added_edges():
     assert g.get_eid(u0, v0) == fx.topo.E and g.get_eid(v0, v0, error=False) in (-1, g.get_eid(v0, v0, error=False))
     assert {(u, v) for (u, v, b) in exp if b} <= g.blocked_edges()
     batch.close()
+
+
+def test_visibility_mask_on_device_matches_the_object_walk():
+    """BatchedCyberDefenseEnv.visibility_mask (device tensor ops) == IPPO.build_visibility_mask's walk over the
+    facade's Device objects (IPPO.py:74-96), for both roles, on a state that has every flag combination."""
+    from cygym_amd.batched_env import BatchedCyberDefenseEnv
+    from cygym_amd.env_view import CyberDefenseEnvView
+    fx = gio.Fixture("s24_star")
+    env = BatchedCyberDefenseEnv(fx.topo, fx.cfg, fx.N, fx.init, device="cuda:0", max_groups=fx.G, max_devs=fx.L)
+    st = {k: fx.exp[k][:, 120] for k in gio.STATE_KEYS}
+    st["extra"] = fx.exp["extra"][:, 120]
+    env.load_state(st)
+    for role in ("attacker", "defender"):
+        got = env.visibility_mask(role).cpu().numpy()
+        for e in range(fx.N):
+            devs = CyberDefenseEnvView(env, e)._get_ordered_devices()
+            exp = [float((d.Known_to_attacker if role == "attacker" else True) and d.attacker_owned and not d.Not_yet_added) for d in devs]
+            np.testing.assert_array_equal(got[e], np.asarray(exp, np.float32), err_msg=f"{role} env {e}")
+        assert got.sum() > 0
+    env.close()

@@ -64,16 +64,18 @@ def main():
                        episode_limit=int(rs.choice([1000, 37])), auto_reset=int(rs.rand() < 0.5),
                        zero_day=int(rs.rand() < 0.2), zero_day_owned_mask=int(rs.randint(0, 4))))
         cfg = abi.EnvConfig(seed=int(rs.randint(1 << 30)), env_id_base=int(rs.randint(1 << 20)), baseline=baseline, **ck)
-        env = BatchedCyberDefenseEnv(topo, cfg, N, init, device="cuda:0", max_groups=G, max_devs=L)
-        fused = BatchedCyberDefenseEnv(topo, cfg, N, init, device="cuda:0", max_groups=G, max_devs=L)
-        ob = od.OracleBatch(topo, cfg, N)
+        det = rs.rand() < 0.3         # trained-detector mode: action 10 -> host fit -> scans walk the forest (full-feature kernels)
+        env = BatchedCyberDefenseEnv(topo, cfg, N, init, device="cuda:0", max_groups=G, max_devs=L, detector=det)
+        fused = BatchedCyberDefenseEnv(topo, cfg, N, init, device="cuda:0", max_groups=G, max_devs=L, detector=det)
+        ob = od.OracleBatch(topo, cfg, N, detector=det)
         ob.load_state(init)
         shuffle = rs.rand() < 0.6
         if shuffle:
             for b in (env, fused, ob):
                 b.randomize()
         script = []
-        meddle = rs.rand() < 0.4      # host-side calls between ticks (then no fused replay of the script)
+        n_trained = 0
+        meddle = det or rs.rand() < 0.4      # host-side calls between ticks (then no fused replay of the script)
         for t in range(ticks):
             if meddle and t and t % 23 == 0:   # reset / reshuffle a random subset, flip the baseline, like do_agent.py:189-196
                 ids = np.flatnonzero(rs.rand(N) < 0.3).astype(np.int32)
@@ -104,7 +106,7 @@ def main():
                         pick = owned[rs.permutation(owned.size)[:k]]
                         if rs.rand() < 0.3 and k > 1:
                             pick[1] = pick[0]           # a repeated device
-                        act["atype"][e, 0] = int(rs.choice([6, 6, 9, 9, 1, 7, 13]))
+                        act["atype"][e, 0] = int(rs.choice([6, 6, 9, 9, 1, 7, 13] + ([10, 10, 5, 5, 5] if det else [])))
                         act["dev_cnt"][e, 0] = k
                         act["dev_idx"][e, :k] = pick
             if G > 1:   # widen the single-action script to G groups; every 4th tick some defenders call step_grouped
@@ -138,6 +140,14 @@ def main():
             obs, raw, shaped, done = env.step()
             o_obs, o_raw, o_shaped, o_done = ob.step(act)
             bad = []
+            if det:   # the host's part of Detector.train: fit on the device-side history ring, hand the same forest to the oracle
+                pend = np.flatnonzero(ob.state["ienv"][:, S.I_FLAGS] & S.E_DET_PENDING)
+                n_fit = env.service_detectors()
+                n_trained += n_fit
+                if n_fit != pend.size:
+                    bad.append(f"{n_fit} forests fitted, oracle has {pend.size} pending")
+                for e in pend:
+                    ob.install_forest(int(e), env.state["forest"][int(e)].cpu().numpy().view(np.uint32))
             if not np.allclose(raw.cpu().numpy(), o_raw, rtol=0, atol=1e-9):
                 bad.append("raw reward")
             if t % 5 == 0 or t == ticks - 1:
@@ -155,8 +165,11 @@ def main():
                 sys.exit(1)
         if meddle:
             nxmax = int((ob.state["ienv"][:, S.I_FLAGS].astype(np.int64) >> S.E_NX_SHIFT).max())
+            scans = int(ob.state["ienv"][:, S.I_SCAN_CNT].sum())
+            unp = int(((ob.state["ienv"][:, S.I_FLAGS] & S.E_UNPINNED) != 0).sum())
             print(f"case {case}: ok  M={M} K={K} N={N} L={L} G={G} with host-side resets / reshuffles / config changes "
-                  f"ticks={ticks} max_extra_edges={nxmax} [{time.time() - t_start:.0f}s]", flush=True)
+                  f"ticks={ticks} max_extra_edges={nxmax}" + (f" detector: {n_trained} forests fitted, {scans} scans, {unp} unpinned envs" if det else "")
+                  + f" [{time.time() - t_start:.0f}s]", flush=True)
             env.close(); fused.close()
             continue
         # the same script as ONE fused rollout must land in the same state
