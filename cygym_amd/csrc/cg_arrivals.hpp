@@ -88,8 +88,7 @@ template <class KP>
 __device__ __forceinline__ void arrivals(Env& e, const KP& P, int step_num, int n_active, int idle, int free_s) {
   int free_c = idle - free_s;
   int n1 = n_active > 1 ? n_active : 1;
-  int half = 0;
-  while (4 * (half + 1) * (half + 1) <= n1) ++half;   // int(0.5*sqrt(n)) (:141-145)
+  const int half = half_isqrt(n1);   // int(0.5*sqrt(n)) (:141-145)
   int period = P.c.workload_period_base + half;
   if (period < 10) period = 10;
   if (period > P.c.workload_period_max) period = P.c.workload_period_max;

@@ -82,7 +82,7 @@ template <int WPB, int MT, bool FUSED, bool XE, bool WIDE>
 // per env and <= 16 envs per CU that is the whole batch in ONE residency round -- at 3 per SIMD a quarter of the
 // batch would wait for a second round).  The lean per-tick kernel at a compile-time size is capped for 6 waves per SIMD
 // (80 VGPRs, no spills): batches that oversubscribe the chip (16384 envs) step 9 % faster than at 5.
-__global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? CG_LB : (WIDE ? 4 : (MT && MT <= 256 ? CG_LEAN_LB : 1)))) void step_kernel(const KParams P0) {
+__global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? CG_LB : (WIDE ? 4 : (MT && MT <= 256 ? (WPB <= 8 ? CG_LEAN_LB : CG_LEAN_LB - 1) : 1)))) void step_kernel(const KParams P0) {
   extern __shared__ __align__(16) uint8_t smem[];
   // every use below goes through `P`: the by-value argument for the single-tick kernel; for the fused one a
   // pointer to the kernarg segment itself (the struct is the only argument, so it sits at offset 0), so that it
@@ -358,12 +358,13 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? CG_LB : (WI
     c_comp += __popc(cmp);
     c_cdc += __popc(cmp & st);
   }
-  const int current_work = wave_sum_bits(c_fin, e.cbits);
-  const int n_active = wave_sum_bits(c_act, e.cbits);
-  const int n_idle = wave_sum_bits(c_idle, e.cbits);
-  const int n_fsrv = wave_sum_bits(c_fsrv, e.cbits);
-  const int n_comp = wave_sum_bits(c_comp, e.cbits);
-  const int n_comp_dc = wave_sum_bits(c_cdc, e.cbits);
+  // six per-lane counts (each <= 32, sums <= 2048) as three packed 16 + 16-bit wave reductions on the DPP path
+  const uint32_t s_fa = (uint32_t)wave_sum(c_fin | (c_act << 16));
+  const uint32_t s_is = (uint32_t)wave_sum(c_idle | (c_fsrv << 16));
+  const uint32_t s_cd = (uint32_t)wave_sum(c_comp | (c_cdc << 16));
+  const int current_work = (int)(s_fa & 0xFFFFu), n_active = (int)(s_fa >> 16);
+  const int n_idle = (int)(s_is & 0xFFFFu), n_fsrv = (int)(s_is >> 16);
+  const int n_comp = (int)(s_cd & 0xFFFFu), n_comp_dc = (int)(s_cd >> 16);
   ie[CG_I_WORK_DONE] += current_work;
   wsync();
   if (!partial) arrivals(e, P, ie[CG_I_STEP_NUM], n_active, n_idle, n_fsrv);   // changes wl only: the counts above stand
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? CG_LB : (WI
     if (mode == CG_MODE_ATTACKER) ie[CG_I_ATT_STEP] += 1; else ie[CG_I_DEF_STEP] += 1;
   }
   const bool done = ie[CG_I_STEP_NUM] > P.c.episode_limit;
-  if (dirty || (ie[CG_I_STEP_NUM] % P.c.evolve_period) == 0) evolve<XE>(e, P);
+  if (dirty || umod(ie[CG_I_STEP_NUM], P.c.evolve_period) == 0) evolve<XE>(e, P);
   if (ng == 0) {   // :1330 rebuild of the cached busy set
     for (int w = lane; w < NW; w += WAVE) F[w] = (F[w] & ~(ONES * CG_F_BUSYC)) | (nz01(Bz[w]) << 6);
   }

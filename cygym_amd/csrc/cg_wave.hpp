@@ -68,6 +68,19 @@ __device__ __forceinline__ int cdf_lookup(uint32_t u, const Tab& thr, int n) {
   return k;
 }
 
+// x mod p for non-negative x and p > 0, without the ~35-instruction division sequence when p is a power of two
+// (env._evolve_period is 2 in every reference configuration)
+__device__ __forceinline__ int umod(int x, int p) {
+  return ((p & (p - 1)) == 0) ? (x & (p - 1)) : (x % p);
+}
+// floor(sqrt(n) / 2) for 1 <= n < 2^22: float estimate, then an exact integer correction (the oracle counts up)
+__device__ __forceinline__ int half_isqrt(int n) {
+  int h = (int)(__builtin_sqrtf((float)n) * 0.5f);
+  while (4 * (h + 1) * (h + 1) <= n) ++h;
+  while (h > 0 && 4 * h * h > n) --h;
+  return h;
+}
+
 // ---- SWAR on 4 device bytes per 32-bit word ----
 #define ONES 0x01010101u
 __device__ __forceinline__ uint32_t nz01(uint32_t b) {   // 0x01 in every byte of b that is non-zero
