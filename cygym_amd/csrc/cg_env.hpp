@@ -70,13 +70,16 @@ __device__ __forceinline__ int range_popc(const uint32_t* blk, int a, int b) {
 // latency.  For per-lane callers whose rows differ a lot in length (block / unblock pools: a full row next to a
 // two-entry row) the rolled loop above makes every lane wait out the longest row, one word per trip.  It costs
 // registers, so only the per-tick kernel -- whose launch lasts as long as its slowest env -- uses it.
+#ifndef CG_WIDE_W
+#define CG_WIDE_W 9
+#endif
 __device__ __forceinline__ int range_popc_wide(const uint32_t* blk, int a, int b) {
   if (a >= b) return 0;
   const int w0 = a >> 5, w1 = (b - 1) >> 5;
-  if (w1 - w0 >= 9) return range_popc(blk, a, b);
+  if (w1 - w0 >= CG_WIDE_W) return range_popc(blk, a, b);
   int n = 0;
 #pragma unroll
-  for (int j = 0; j < 9; ++j) {
+  for (int j = 0; j < CG_WIDE_W; ++j) {
     const int w = w0 + j;
     uint32_t x = blk[w <= w1 ? w : w1];
     if (j == 0) x &= 0xFFFFFFFFu << (a & 31);
@@ -103,12 +106,12 @@ __device__ __forceinline__ int range_select(const uint32_t* blk, int a, int b, b
 // callers only (block / unblock pools), see range_popc_wide
 __device__ __forceinline__ int range_select_wide(const uint32_t* blk, int a, int b, bool want, int r) {
   const int w0 = a >> 5, w1 = (b - 1) >> 5;
-  if (w1 - w0 >= 9) return range_select(blk, a, b, want, r);
+  if (w1 - w0 >= CG_WIDE_W) return range_select(blk, a, b, want, r);
   const uint32_t inv = want ? 0u : 0xFFFFFFFFu;
   const uint32_t m_lo = 0xFFFFFFFFu << (a & 31), m_hi = (b & 31) ? 0xFFFFFFFFu >> (32 - (b & 31)) : 0xFFFFFFFFu;
   int cum = 0, wsel = 0, rbase = 0;
 #pragma unroll
-  for (int j = 0; j < 9; ++j) {   // which word holds rank r: nine independent reads, values die in their popcount
+  for (int j = 0; j < CG_WIDE_W; ++j) {   // which word holds rank r: nine independent reads, values die in their popcount
     const int w = w0 + j;
     uint32_t v = blk[w <= w1 ? w : w1] ^ inv;
     if (j == 0) v &= m_lo;

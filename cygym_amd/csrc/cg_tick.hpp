@@ -78,11 +78,12 @@ template <int WPB, int MT, bool FUSED, bool XE, bool WIDE>
 #ifndef CG_LEAN_LB
 #define CG_LEAN_LB 6
 #endif
+// (a one-wave workgroup at a run-time size is only chosen when LDS, not registers, limits residency: 3 there.)
 // Register budget (second launch-bound = minimum waves per SIMD): the fused kernel and the WIDE per-tick kernel must keep 4 waves per SIMD (16 per CU: with one wave
 // per env and <= 16 envs per CU that is the whole batch in ONE residency round -- at 3 per SIMD a quarter of the
 // batch would wait for a second round).  The lean per-tick kernel at a compile-time size is capped for 6 waves per SIMD
 // (80 VGPRs, no spills): batches that oversubscribe the chip (16384 envs) step 9 % faster than at 5.
-__global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? CG_LB : (WIDE ? 4 : (MT && MT <= 256 ? (WPB <= 8 ? CG_LEAN_LB : CG_LEAN_LB - 1) : 1)))) void step_kernel(const KParams P0) {
+__global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 && MT == 0 ? 3 : CG_LB) : (WIDE ? 4 : (MT && MT <= 256 ? (WPB <= 8 ? CG_LEAN_LB : CG_LEAN_LB - 1) : 1)))) void step_kernel(const KParams P0) {
   extern __shared__ __align__(16) uint8_t smem[];
   // every use below goes through `P`: the by-value argument for the single-tick kernel; for the fused one a
   // pointer to the kernarg segment itself (the struct is the only argument, so it sits at offset 0), so that it
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? CG_LB : (WI
   } else pk = &P0;
 #define P (*pk)
   const int M = MT ? MT : P.t.M, MC = MT ? (MT + WAVE - 1) / WAVE : P.t.MC, Mp = MC * WAVE, MS = (M + 3) & ~3;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;   // (run-time-size rollout kernel: laundered per tick, below)
   const int env = uni(P.env_begin + blockIdx.x * WPB + wave);
   const bool live = env < P.env_end;
   const int G = P.a.max_groups, L = P.a.max_devs;
@@ -210,10 +211,29 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? CG_LB : (WI
   // ---- ticks of this launch: 1 for cygym_step, T for cygym_rollout (state stays in LDS / registers;
   // no cross-env synchronisation between ticks) ----
   const int n_ticks = FUSED ? P.n_ticks : 1;
+  // Rollout kernel: EVERY tick, the first one included, starts from the same point -- scalars parked in LDS, the
+  // env view re-derived through a laundered parameter pointer, the tick's header and device list loaded here.
+  // With tick 0 special-cased (its header prefetched with the state) every per-env value reached the loop as a
+  // phi of "prologue version" and "re-derived version" and stayed live across the whole body: the full-feature
+  // rollout kernels spilled 10-47 VGPRs at the 128 cap; now none does.  (Laundering the lane / wave ids per tick as
+  // well stops the hoisting of per-lane addresses and fits 96 VGPRs = 5 waves per SIMD, but the recomputation costs
+  // 3-4 % per tick: +6 % at 16384 envs, -3 % at 4096 and 65536 -- measured, not adopted.)
+  if constexpr (FUSED) {
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < CG_I_COUNT; ++i) park[i] = ie[i];
+#pragma unroll
+      for (int i = 0; i < CG_D_COUNT; ++i) ((double*)(park + CG_I_COUNT))[i] = fe[i];
+    }
+    wsync();
+  }
   for (int tk = 0; tk < n_ticks; ++tk) {
+  // run-time sizes only: also keep per-lane addresses and masks from being hoisted out of the tick loop (the chunk
+  // loops are not unrolled there, so the recomputation is cheap, and without it the kernel spilled 19-42 VGPRs)
+  if constexpr (FUSED && MT == 0) asm volatile("" : "+v"(lane), "+v"(wave));
   const size_t te = (size_t)tk * P.n_envs + env;   // row of this (tick, env) in the action / output arrays
   if (FUSED && tk > 0) STAMP(0);   // diagnostic builds: the stamps then describe the LAST tick of the rollout
-  if (FUSED && tk > 0) {   // tick 0's header and list were prefetched with the state
+  if (FUSED) {
     // Re-derive everything uniform from the device copy of the parameters: keeping ~200 loop-invariant
     // scalars alive across the tick body would spill SGPRs into VGPRs and halve the occupancy.
     {
@@ -245,15 +265,7 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? CG_LB : (WI
     wsync();
   }
   if (FUSED && tk > 0) STAMP(1);
-  if (ng < 0) {   // n_groups < 0: this env does not tick (per-env stepping inside a batch)
-    if (FUSED && tk == 0 && lane == 0) {
-#pragma unroll
-      for (int i = 0; i < CG_I_COUNT; ++i) park[i] = ie[i];
-#pragma unroll
-      for (int i = 0; i < CG_D_COUNT; ++i) ((double*)(park + CG_I_COUNT))[i] = fe[i];
-    }
-    continue;
-  }
+  if (ng < 0) continue;   // n_groups < 0: this env does not tick (per-env stepping inside a batch); its parked scalars stand
   const int16_t* devs = e.devl;
   uint32_t* const F = (uint32_t*)e.flags;
   uint32_t* const Bz = (uint32_t*)e.busy;

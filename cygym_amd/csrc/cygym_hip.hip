@@ -36,7 +36,7 @@
 #include "cygym_abi.h"
 
 #ifndef CG_FUSED_LB
-#define CG_FUSED_LB 4
+#define CG_FUSED_LB 4   // rollout kernels: 4 waves per SIMD (128 VGPRs); see the tick-loop note in cg_tick.hpp
 #endif
 #ifndef CG_LB
 // Full-feature per-tick kernels: 4 waves per SIMD (128 VGPRs).  At 6 (80 VGPRs) they spilled 5-11 VGPRs on top of
