@@ -42,10 +42,13 @@ class Config(C.Structure):
         ("workload_period_max", C.c_int32), ("scaling_vulnerability", C.c_int32), ("fast_scan", C.c_int32),
         ("n_att_actions", C.c_int32), ("n_def_actions", C.c_int32), ("zero_day", C.c_int32),
         ("zero_day_owned_mask", C.c_int32), ("default_high", C.c_int32), ("baseline", C.c_int32),
-        ("auto_reset", C.c_int32), ("episode_limit", C.c_int32), ("reserved1", C.c_int32),
+        ("auto_reset", C.c_int32), ("episode_limit", C.c_int32), ("turbo", C.c_int32),
         ("work_scale", C.c_double), ("comp_scale", C.c_double), ("def_scale", C.c_double), ("gamma", C.c_double),
         ("p_add_thr", C.c_uint64), ("p_attacker_thr", C.c_uint64),
         ("poisson_thr", C.c_uint64 * S.POISSON_TABLE), ("tri_thr", C.c_uint64 * S.TRI_TABLE),
+        ("turbo_fraction_clients", C.c_double), ("turbo_fraction_servers", C.c_double),
+        ("turbo_max_clients", C.c_int32), ("turbo_max_servers", C.c_int32), ("turbo_ramp_steps", C.c_int32),
+        ("turbo_train_max_logs", C.c_int32), ("turbo_train_stride", C.c_int32), ("reserved2", C.c_int32),
     ]
 
 
@@ -110,11 +113,19 @@ class EnvConfig:
     p_attacker: float = 0.0
     tri_mode: float = 2.0
     tri_high: float = 5.0
+    turbo: int = 0                          # volt_typhoon_env.py:92 and its knobs :97-109
+    turbo_fraction_clients: float = 0.05
+    turbo_fraction_servers: float = 0.02
+    turbo_max_clients: int = 200
+    turbo_max_servers: int = 40
+    turbo_ramp_steps: int = 200
+    turbo_train_max_logs: int = 256
+    turbo_train_stride: int = 2
 
     def to_c(self) -> Config:
         c = Config()
         for name, _ in Config._fields_:
-            if name in ("baseline", "p_add_thr", "p_attacker_thr", "poisson_thr", "tri_thr", "reserved1"):
+            if name in ("baseline", "p_add_thr", "p_attacker_thr", "poisson_thr", "tri_thr", "reserved2"):
                 continue
             setattr(c, name, getattr(self, name))
         c.baseline = BASELINES[self.baseline] if isinstance(self.baseline, str) else int(self.baseline)

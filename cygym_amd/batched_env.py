@@ -324,7 +324,7 @@ class BatchedCyberDefenseEnv:
                 raise _lib.CygymError(f"env {e}: the training window of tick {req_tick} has left the history ring "
                                       "(service_detectors() must run before 48 more log entries arrive)")
             hist = self.state["hist"][e].cpu().numpy().view(np.uint16)
-            rows = D.training_window(hist, req_total)
+            rows = D.training_window(hist, req_total, bool(self.cfg.turbo), self.cfg.turbo_train_max_logs, self.cfg.turbo_train_stride)
             self.install_forest(e, D.fit_forest(rows, D.fit_seed(self.cfg.seed, self.cfg.env_id_base + e, req_tick),
                                                 n_fits=int(hdr[6])))
         return len(pend)

@@ -5,10 +5,21 @@
 
 // ---------------- arrivals: CDSimulator.generate_workloads :244-348 ----------------
 template <class KP>
-__device__ __forceinline__ void gen_workloads(Env& e, const KP& P, int num, bool server, int n_active) {
+__device__ __forceinline__ void gen_workloads(Env& e, const KP& P, int num, bool server, int n_active, int step_num) {
   const int M = e.M, MC = e.MC;
   if (n_active <= 0) return;
   if (P.c.workload_cap >= 0 && num > P.c.workload_cap) num = P.c.workload_cap;
+  if (COLD(P.c.turbo)) {   // turbo throttling: cap + ramp, never zero (volt_typhoon_env.py:219-231), in the reference's own f64 steps
+    const double frac = server ? P.c.turbo_fraction_servers : P.c.turbo_fraction_clients;
+    int frac_cap = (int)(frac * (double)n_active);
+    if (frac_cap < 1) frac_cap = 1;
+    const int hard_cap = server ? P.c.turbo_max_servers : P.c.turbo_max_clients;
+    double alpha = (double)step_num / (double)(P.c.turbo_ramp_steps > 1 ? P.c.turbo_ramp_steps : 1);
+    alpha = alpha < 0.0 ? 0.0 : (alpha > 1.0 ? 1.0 : alpha);
+    int cap = (int)rint((double)(frac_cap < hard_cap ? frac_cap : hard_cap) * alpha);   // Python round(): half to even
+    if (cap < 1) cap = 1;
+    if (num > cap) num = cap;
+  }
   if (num > n_active) num = n_active;
   if (num <= 0) return;
   const uint32_t site = server ? CG_SITE_ARR_SERVER : CG_SITE_ARR_CLIENT;
@@ -113,8 +124,8 @@ __device__ __forceinline__ void arrivals(Env& e, const KP& P, int step_num, int 
       nS = (int)(nS * ratio); if (nS < 0) nS = 0;
     }
   }
-  gen_workloads(e, P, nC, false, n_active);
-  gen_workloads(e, P, nS, true, n_active);
+  gen_workloads(e, P, nC, false, n_active, step_num);
+  gen_workloads(e, P, nS, true, n_active, step_num);
 }
 
 #endif  // CG_ARRIVALS_HPP

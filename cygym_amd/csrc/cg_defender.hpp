@@ -429,7 +429,8 @@ __device__ __forceinline__ void def_per_device(Env& e, const KP& P, int at, cons
     if (w > 0 && n_mult > 0) {
       cost += -0.5 * n_mult * ds;
       fe[CG_D_DEF_COST] += 0.5 * n_mult * ds;
-      if (e.eflags & CG_E_DET_RANDOM) {  // Detector.batch_predict coin mode CDSimulator.py:715-716
+      if (COLD(P.c.turbo)) {   // turbo: predictions = [] (volt_typhoon_env.py:1055) -- the scan costs, nothing is flagged
+      } else if (e.eflags & CG_E_DET_RANDOM) {  // Detector.batch_predict coin mode CDSimulator.py:715-716
         const int majority = w / 2 + 1;
         for (int s = 0; s < n_mult; ++s) {
           bool anom = false;

@@ -158,9 +158,15 @@ def fit_forest(X, seed32: int, n_fits: int = 1) -> np.ndarray:
     return flatten_forest(model)
 
 
-def training_window(hist_row: np.ndarray, log_total: int) -> np.ndarray:
+def training_window(hist_row: np.ndarray, log_total: int, turbo: bool = False, turbo_max_logs: int = 256,
+                    turbo_stride: int = 2) -> np.ndarray:
     """The rows Detector.train sees: the last <= TRAIN_WINDOW entries of the env's history ring
-    ([HIST_RING][2] u16, entry i of the log lives at i % HIST_RING), oldest first."""
+    ([HIST_RING][2] u16, entry i of the log lives at i % HIST_RING), oldest first; in turbo mode clipped to the last
+    `turbo_max_logs` of them and down-sampled by `turbo_stride` (volt_typhoon_env.py:165-169)."""
     n = min(int(log_total), S.TRAIN_WINDOW)
     idx = (np.arange(int(log_total) - n, int(log_total)) % S.HIST_RING).astype(np.int64)
-    return np.asarray(hist_row).reshape(S.HIST_RING, 2)[idx].astype(np.int64)
+    rows = np.asarray(hist_row).reshape(S.HIST_RING, 2)[idx].astype(np.int64)
+    if turbo:
+        rows = rows[-int(turbo_max_logs):]
+        rows = rows[:: max(1, int(turbo_stride))]
+    return rows

@@ -120,8 +120,13 @@ def flatten_static(env):
 
 
 def flatten_config(env):
-    assert not env.turbo, "turbo=True (throttled workloads / skipped detector) is outside the restated path"
     return dict(
+        turbo=int(bool(getattr(env, "turbo", False))),
+        turbo_fraction_clients=float(getattr(env, "turbo_fraction_clients", 0.05)),
+        turbo_fraction_servers=float(getattr(env, "turbo_fraction_servers", 0.02)),
+        turbo_max_clients=int(getattr(env, "turbo_max_clients", 200)), turbo_max_servers=int(getattr(env, "turbo_max_servers", 40)),
+        turbo_ramp_steps=int(getattr(env, "turbo_ramp_steps", 200)),
+        turbo_train_max_logs=int(getattr(env, "turbo_train_max_logs", 256)), turbo_train_stride=int(getattr(env, "turbo_train_stride", 2)),
         num_of_device=int(env.numOfDevice), min_network_size=int(env.Min_network_size),
         max_exploits=int(env.MaxExploits), evolve_period=int(env._evolve_period),
         work_scale=float(env.work_scale), comp_scale=float(env.comp_scale), def_scale=float(env.def_scale),

@@ -90,12 +90,18 @@ typedef struct cygym_config {
   int32_t  baseline;             /* 0 Nash, 1 No Defense, 2 Preset, 3 No Attack */
   int32_t  auto_reset;           /* 1: reload snapshot when done (batched only) */
   int32_t  episode_limit;        /* done iff step_num > limit (1000) CyberDefenseEnv.py:549 */
-  int32_t  reserved1;
+  int32_t  turbo;                /* env.turbo (volt_typhoon_env.py:92): scans skip the detector (:1055), arrivals are
+                                    capped and ramped (:219-231), trainings see a clipped, strided log (:165-169) */
   double   work_scale, comp_scale, def_scale, gamma;
   uint64_t p_add_thr;            /* ceil(p_add * 2^32)      CyberDefenseEnv.py:679 */
   uint64_t p_attacker_thr;       /* ceil(p_attacker * 2^32) CyberDefenseEnv.py:690 */
   uint64_t poisson_thr[CG_POISSON_TABLE]; /* np.random.poisson(lambda_events) :668 */
   uint64_t tri_thr[CG_TRI_TABLE];         /* ceil(triangular(0,2,5)) CDSimulator.py:308 */
+  /* turbo throttling of _generate_workloads_timed (volt_typhoon_env.py:97-101, :219-231); used only when turbo != 0 */
+  double   turbo_fraction_clients, turbo_fraction_servers;
+  int32_t  turbo_max_clients, turbo_max_servers, turbo_ramp_steps;
+  int32_t  turbo_train_max_logs, turbo_train_stride;   /* host side of Detector.train in turbo mode (:108-109) */
+  int32_t  reserved2;
 } cygym_config;
 
 /* Per-env mutable state, struct-of-arrays, DEVICE pointers (caller-owned).

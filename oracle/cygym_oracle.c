@@ -31,6 +31,7 @@
  *   evolve_network  CyberDefenseEnv.py:583-875
  *   logger/detector CDSimulator.py:663-742
  */
+#include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -259,14 +260,15 @@ static void def_per_device(env_t* e, int at, const int16_t* dev, int L, int app,
           int anom[CG_SCAN_WINDOW];
           int n_anom = 0;
           int fl = e->ienv[CG_I_FLAGS];
-          int trained = (fl & CG_E_DET_TRAIN) && !(fl & CG_E_DET_RANDOM);
+          int trained = (fl & CG_E_DET_TRAIN) && !(fl & CG_E_DET_RANDOM) && !e->c->turbo;
           if (trained && (!e->forest || !e->t->det_apl || (fl & CG_E_DET_PENDING))) {
             e->ienv[CG_I_FLAGS] |= CG_E_UNPINNED; /* no current forest: all "D", flagged (cygym_spec.h) */
             trained = 0;
           }
           for (int j = 0; j < w; ++j) { /* Detector.batch_predict CDSimulator.py:714-723 */
             int a = 0;
-            if (fl & CG_E_DET_RANDOM) a = (cg_index(drw(e, CG_SITE_DET_COIN, (uint32_t)j, (uint32_t)ord), 2) == 0);
+            if (e->c->turbo) a = 0; /* predictions = [] in turbo mode (volt_typhoon_env.py:1055) */
+            else if (fl & CG_E_DET_RANDOM) a = (cg_index(drw(e, CG_SITE_DET_COIN, (uint32_t)j, (uint32_t)ord), 2) == 0);
             else if (trained) { /* IsolationForest.predict == -1 (:721-723) over the flat trees */
               uint32_t idx = total - (uint32_t)w + (uint32_t)j;
               const uint16_t* pt = e->ring + 2 * (idx % CG_LOG_RING);
@@ -436,6 +438,17 @@ static void gen_workloads(env_t* e, int num, int server, kid_t* tmp) {
   for (int d = 0; d < M; ++d) n_active += !(e->flags[d] & CG_F_NYA);
   if (n_active <= 0) return;
   if (e->c->workload_cap >= 0 && num > e->c->workload_cap) num = e->c->workload_cap;
+  if (e->c->turbo) { /* turbo throttling volt_typhoon_env.py:219-231 (bootstrap is never set on the step path) */
+    double frac = server ? e->c->turbo_fraction_servers : e->c->turbo_fraction_clients;
+    int frac_cap = (int)(frac * (double)n_active);
+    if (frac_cap < 1) frac_cap = 1;
+    int hard_cap = server ? e->c->turbo_max_servers : e->c->turbo_max_clients;
+    double alpha = (double)e->ienv[CG_I_STEP_NUM] / (double)(e->c->turbo_ramp_steps > 1 ? e->c->turbo_ramp_steps : 1);
+    alpha = alpha < 0.0 ? 0.0 : (alpha > 1.0 ? 1.0 : alpha);
+    int cap = (int)rint((double)(frac_cap < hard_cap ? frac_cap : hard_cap) * alpha); /* Python round(): half to even */
+    if (cap < 1) cap = 1;
+    if (num > cap) num = cap;
+  }
   if (num > n_active) num = n_active;
   if (num <= 0) return;
   uint32_t site = server ? CG_SITE_ARR_SERVER : CG_SITE_ARR_CLIENT;

@@ -25,7 +25,7 @@ def build(force: bool = False) -> str:
     deps = [src, os.path.join(HERE, "..", "include", "cygym_abi.h"), os.path.join(HERE, "..", "include", "cygym_spec.h")]
     if force or not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
         subprocess.check_call(["gcc", "-O2", "-fPIC", "-std=c11", "-I" + os.path.join(HERE, "..", "include"),
-                               "-shared", "-o", SO, src])
+                               "-shared", "-o", SO, src, "-lm"])
     return SO
 
 

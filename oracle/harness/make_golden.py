@@ -320,6 +320,17 @@ def s64_trained():
     return H.run_scenario(env0, 2, 220, trained_actions(M, 12, grouped=True), seed=42, env_id_base=300), 4
 
 
+@scenario("s64_turbo")
+def s64_turbo():
+    """env.turbo = True (volt_typhoon_env.py:92; no reference driver sets it): arrivals capped and ramped with step_num
+    (:219-231; a short arrival period so that many ticks hit it), scans skip the detector (:1055), trainings fit on
+    the clipped, strided log (:165-169)."""
+    M = 64
+    env0 = H.build_env(M, 56, init_seed=151, strip_vuln_frac=0.3, extra_reachable=2,
+                       overrides=dict(turbo=True, workload_period_base=3, turbo_ramp_steps=60, turbo_fraction_clients=0.13))
+    return H.run_scenario(env0, 2, 260, mixed_actions(M, ALL_DEF + [5, 5, 10], ALL_ATT, 8), seed=43, env_id_base=400), 1
+
+
 def outputs_of(name):
     """File stems a scenario writes."""
     if name == "s16_baselines":

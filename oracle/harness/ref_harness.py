@@ -503,6 +503,8 @@ def run_scenario(env0, n_envs, n_ticks, action_fn, *, seed=0, env_id_base=0, pre
             if det.trained and id(getattr(det.model, "estimators_", None)) != fit_id:   # refitted during this tick
                 fit_id = id(det.model.estimators_)
                 rows = [(int(l["from_device"]), int(l["to_device"])) for l in env.simulator.logger.logs[-S.TRAIN_WINDOW:]]
+                if env.turbo:    # _train_detector clips and down-samples in turbo mode (volt_typhoon_env.py:165-169)
+                    rows = rows[-int(env.turbo_train_max_logs):][:: max(1, int(env.turbo_train_stride))]
                 grouped = isinstance(action, (list, tuple)) and action and isinstance(action[0], (list, tuple))
                 n_fits = sum(1 for g in action if int(g[0]) == 10) if grouped else 1   # every action-10 group refits
                 det_events.append((t, rng_tick, export_forest(env), np.asarray(rows, np.int32).reshape(-1, 2), n_fits))

@@ -46,7 +46,11 @@ class Fixture:
             default_high=int(cfg["default_high"]), baseline=inv[int(cfg["baseline"])],
             work_scale=cfg["work_scale"], comp_scale=cfg["comp_scale"], def_scale=cfg["def_scale"],
             gamma=cfg["gamma"], lambda_events=cfg["lambda_events"], p_add=cfg["p_add"],
-            p_attacker=cfg["p_attacker"])
+            p_attacker=cfg["p_attacker"], turbo=int(cfg["turbo"]),
+            turbo_fraction_clients=cfg["turbo_fraction_clients"], turbo_fraction_servers=cfg["turbo_fraction_servers"],
+            turbo_max_clients=int(cfg["turbo_max_clients"]), turbo_max_servers=int(cfg["turbo_max_servers"]),
+            turbo_ramp_steps=int(cfg["turbo_ramp_steps"]), turbo_train_max_logs=int(cfg["turbo_train_max_logs"]),
+            turbo_train_stride=int(cfg["turbo_train_stride"]))
         self.N = z["init_flags"].shape[0]
         self.T = z["exp_flags"].shape[1]
         self.M = self.topo.M
@@ -166,7 +170,7 @@ class Fixture:
             lt = int(state["ienv"][e, S.I_LOG_TOTAL])
             assert hdr[3] == ev["rng_tick"] and hdr[4] == lt and hdr[6] == ev["n_fits"], \
                 f"{self.name} t={t} env {e}: request header {hdr[3:7]} vs ({ev['rng_tick']}, {lt}, {ev['n_fits']} fits)"
-            rows = D.training_window(np.asarray(state["hist"][e]), lt)
+            rows = D.training_window(np.asarray(state["hist"][e]), lt, bool(self.cfg.turbo), self.cfg.turbo_train_max_logs, self.cfg.turbo_train_stride)
             np.testing.assert_array_equal(rows, ev["rows"], err_msg=f"{self.name} t={t} env {e}: training rows")
             install(e, ev["forest"])
 

@@ -62,7 +62,9 @@ def main():
                        p_attacker=float(rs.choice([0.0, 0.05, 0.3])),
                        num_of_device=int(rs.randint(2, max(3, n_active))), min_network_size=2,
                        episode_limit=int(rs.choice([1000, 37])), auto_reset=int(rs.rand() < 0.5),
-                       zero_day=int(rs.rand() < 0.2), zero_day_owned_mask=int(rs.randint(0, 4))))
+                       zero_day=int(rs.rand() < 0.2), zero_day_owned_mask=int(rs.randint(0, 4)),
+                       turbo=int(rs.rand() < 0.2), turbo_ramp_steps=int(rs.choice([200, 40, 1])),
+                       turbo_fraction_clients=float(rs.choice([0.05, 0.13, 0.5])), workload_period_base=int(rs.choice([50, 50, 4]))))
         cfg = abi.EnvConfig(seed=int(rs.randint(1 << 30)), env_id_base=int(rs.randint(1 << 20)), baseline=baseline, **ck)
         det = rs.rand() < 0.3         # trained-detector mode: action 10 -> host fit -> scans walk the forest (full-feature kernels)
         env = BatchedCyberDefenseEnv(topo, cfg, N, init, device="cuda:0", max_groups=G, max_devs=L, detector=det)
