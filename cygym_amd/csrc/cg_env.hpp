@@ -25,7 +25,7 @@ struct Env {
   const uint16_t *optr, *ocol, *iptr_l;
   const uint8_t *dst, *vul, *nap;
   const float *osv, *ver, *ano;
-  // in-CSR columns + slot<->entry maps: global memory (L2-resident blob); read by block/unblock only
+  // in-CSR columns + slot<->entry maps: global memory (L2-resident blob), or LDS in the WIDE kernel; read by block/unblock only
   const uint16_t *icol_g, *ieid_g, *oeid_g;
   uint8_t* stash;    // global [4][M] of this env
   // misc

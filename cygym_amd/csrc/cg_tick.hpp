@@ -38,7 +38,8 @@ __device__ __forceinline__ void write_obs(const uint8_t* flags, const float* osv
 }
 
 struct WaveAux { uint64_t* srcb; int32_t* park; };
-template <class KP>
+// MAPS: the in-CSR columns and slot maps are staged in LDS too (the WIDE per-tick kernel, one 16-wave workgroup per CU)
+template <bool MAPS, class KP>
 __device__ __forceinline__ WaveAux env_setup(Env& e, uint8_t* smem, const KP& P, int M, int MC, int Mp, int MS,
                                              int wave, int lane, int env) {
   uint8_t* wb = smem + P.shared_lds + (size_t)wave * P.wave_lds;
@@ -61,8 +62,12 @@ __device__ __forceinline__ WaveAux env_setup(Env& e, uint8_t* smem, const KP& P,
   e.optr = (const uint16_t*)(smem + P.t.o_optr); e.ocol = (const uint16_t*)(smem + P.t.o_ocol);
   e.osv = (const float*)(smem + P.t.o_os); e.ver = (const float*)(smem + P.t.o_ver); e.ano = (const float*)(smem + P.t.o_ano);   // valid when P.t.in_lds
   e.dst = smem + P.t.o_dst; e.vul = smem + P.t.o_vul; e.nap = smem + P.t.o_nap;
-  e.iptr_l = (const uint16_t*)(smem + P.t.o_iptr); e.icol_g = (const uint16_t*)(P.t.blob + P.t.o_icol);
-  e.ieid_g = (const uint16_t*)(P.t.blob + P.t.o_ieid); e.oeid_g = (const uint16_t*)(P.t.blob + P.t.o_oeid);
+  e.iptr_l = (const uint16_t*)(smem + P.t.o_iptr);
+  if constexpr (MAPS) {   // LDS: block / unblock picks no longer pay a global-memory hop per pass
+    e.icol_g = (const uint16_t*)(smem + P.t.o_icol); e.ieid_g = (const uint16_t*)(smem + P.t.o_ieid); e.oeid_g = (const uint16_t*)(smem + P.t.o_oeid);
+  } else {
+    e.icol_g = (const uint16_t*)(P.t.blob + P.t.o_icol); e.ieid_g = (const uint16_t*)(P.t.blob + P.t.o_ieid); e.oeid_g = (const uint16_t*)(P.t.blob + P.t.o_oeid);
+  }
   e.M = M; e.MC = MC; e.MS = MS; e.lane = lane; e.env = env;
   e.cbits = 32 - __builtin_clz((unsigned)(4 * ((MS / 4 + WAVE - 1) / WAVE)));
   e.env_id = (uint32_t)(P.c.env_id_base + env);
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 &
   const int G = P.a.max_groups, L = P.a.max_devs;
 
   Env e;
-  WaveAux aux = env_setup(e, smem, P, M, MC, Mp, MS, wave, lane, live ? env : 0);
+  WaveAux aux = env_setup<WIDE>(e, smem, P, M, MC, Mp, MS, wave, lane, live ? env : 0);
   uint64_t* srcb = aux.srcb;
   int32_t* park = aux.park;
   e.env = env;
@@ -243,7 +248,7 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 &
       asm volatile("" : "+s"(plo), "+s"(phi));   // opaque: nothing derived from it is hoisted out of the tick loop
       pk = (KPT*)(((uint64_t)phi << 32) | plo);
     }
-    aux = env_setup(e, smem, P, M, MC, Mp, MS, wave, lane, env);
+    aux = env_setup<WIDE>(e, smem, P, M, MC, Mp, MS, wave, lane, env);
     srcb = aux.srcb; park = aux.park;
     // parked in LDS: an LDS load lands in a VGPR; readfirstlane tells the compiler the value is uniform, so the
     // 22 per-env scalars live in SGPRs across the tick body instead of 22 of the 128 VGPRs

@@ -74,6 +74,8 @@ struct cygym_handle {
   void* dev_blob;       // one allocation holding the topology copies (+ the detector's leaf-term table)
   int wpb, max_devs;
   bool few_waves;       // n_envs <= 16 per CU: one wave per env cannot use more than 4 waves per SIMD
+  bool wide;            // the WIDE per-tick kernel runs: one 16-wave workgroup per CU with the WHOLE blob (in-CSR maps too) in LDS
+  int o_maps_end;       // blob offset just past the in-CSR maps
   int wave_lds, shared_lds;
   hipEvent_t ev0, ev1;
   unsigned long long* dbg;
@@ -110,7 +112,9 @@ static int fail(cygym_handle* h, int code, const char* fmt, const char* detail) 
 template <int MT, bool FUSED, bool XE, bool WIDE>
 static const void* kernel_for(int wpb) {
   if constexpr (!CG_HAS_MT(MT)) return nullptr;
-  else
+  else if constexpr (WIDE) {   // the WIDE kernel only ever runs as one 16-wave workgroup per CU (choose_launch)
+    if constexpr (CG_HAS_WPB(16)) return wpb == 16 ? (const void*)step_kernel<16, MT, FUSED, XE, WIDE> : nullptr; else return nullptr;
+  } else
   switch (wpb) {
     case 16: if constexpr (CG_HAS_WPB(16)) return (const void*)step_kernel<16, MT, FUSED, XE, WIDE>; else return nullptr;
     case 8: if constexpr (CG_HAS_WPB(8)) return (const void*)step_kernel<8, MT, FUSED, XE, WIDE>; else return nullptr;
@@ -135,7 +139,7 @@ static const void* pick_kernel(const cygym_handle* h, bool fused, int full = -1)
   const bool xe = full < 0 ? full_feature(h) : full != 0;
   if (fused) return xe ? kernel_for_m<true, true, false>(h) : kernel_for_m<true, false, false>(h);
   if (xe) return kernel_for_m<false, true, false>(h);
-  return h->few_waves ? kernel_for_m<false, false, true>(h) : kernel_for_m<false, false, false>(h);
+  return h->wide ? kernel_for_m<false, false, true>(h) : kernel_for_m<false, false, false>(h);
 }
 static hipError_t set_lds_attr(cygym_handle* h) {   // every instantiation this handle may launch (lean and full-feature)
   const int lds = h->shared_lds + h->wave_lds * h->wpb;
@@ -193,6 +197,15 @@ static int choose_launch(cygym_handle* h, int max_devs) {
   h->wpb = best; h->wave_lds = (int)wave; h->shared_lds = (int)shared;
   t.lds_bytes = (int)shared; t.in_lds = best_floats;   // in_lds: the float columns are staged too
   h->max_devs = max_devs;
+  // Few envs per CU (<= 16: every env has its own resident wave and a launch lasts as long as its slowest env, which
+  // on defender ticks is a block / unblock list): one 16-wave workgroup per CU leaves room for the in-CSR columns and
+  // slot maps in LDS as well, so a speculation pass no longer waits on global memory.  Compile-time size 256, lean only.
+  h->wide = false;
+  if (h->few_waves && t.M == 256 && t.K == 0 && !forced && (size_t)h->o_maps_end + wave * 16 <= lds_cap) {
+    h->wide = true;
+    h->wpb = 16; h->shared_lds = h->o_maps_end;
+    t.lds_bytes = h->o_maps_end; t.in_lds = 1;
+  }
   return 0;
 }
 
@@ -266,6 +279,7 @@ int cygym_create(const cygym_topology* topo, const cygym_config* cfg, int32_t n_
   t.o_os = take((size_t)M * 4); t.o_ver = take((size_t)M * 4); t.o_ano = take((size_t)M * 4);   // LDS only when that is free
   t.o_icol = take((size_t)(E > 0 ? E : 1) * 2); t.o_ieid = take((size_t)(E > 0 ? E : 1) * 2);
   t.o_oeid = take((size_t)(E > 0 ? E : 1) * 2);
+  h->o_maps_end = (int)off;
   const int o_apl = take(topo->det_apl ? (size_t)CG_DET_APL_N * 8 : 0);   // global only: read by trained scans
   t.blob_bytes = (int)off;
   t.multi = 0;   // duplicate (u,v) out-entries? (env._blocked holds pairs, so duplicates share their state)

@@ -4,7 +4,8 @@
 
 Each case builds a reference environment with random size / activity / evolve parameters (events, additions,
 attacker-owned activations, extra-edge capacity), optionally reshuffles ownership, drives it with random
-reference-style actions (four mixes: plain, edge-heavy, repeated devices, and "wild": step_grouped calls,
+reference-style actions (five mixes: plain, edge-heavy, repeated devices, "trained": scans and detector (re)training,
+and "wild": step_grouped calls,
 action=None under a random base_line, partial ticks, out-of-range action types) under the injected Philox draws, and replays the
 recording through oracle/cygym_oracle.c with the same tick-by-tick comparison the golden tests use
 (tests/golden_io.check_oracle_against_fixture).  Nothing is written into the repository.
@@ -43,15 +44,20 @@ def main():
                     sv_attacker_fraction=float(rs.choice([0.05, 0.25])))
         if rs.rand() < 0.2:
             over.update(zero_day=True, k_known=1, j_private=1)
+        if rs.rand() < 0.2:    # env.turbo: capped / ramped arrivals (short period so they happen), scans without detector
+            over.update(turbo=True, workload_period_base=int(rs.choice([3, 50])), turbo_ramp_steps=int(rs.choice([200, 40, 1])),
+                        turbo_fraction_clients=float(rs.choice([0.05, 0.13, 0.5])))
         env0 = H.build_env(M, n_active, init_seed=int(rs.randint(1, 10000)), strip_vuln_frac=float(rs.choice([0.2, 0.5])),
                            extra_reachable=int(rs.randint(0, 3)), overrides=over)
         X = 3 if over.get("zero_day") else 2
-        kind = rs.choice(["mixed", "edges", "dups", "wild"])
+        kind = rs.choice(["mixed", "edges", "dups", "wild", "trained"])
         if kind == "edges":
             fn = G.edge_heavy_actions(M, max(2, M // 5), X=X)
+        elif kind == "trained":   # spread-heavy attacker, defender dominated by scans and detector (re)training
+            fn = G.trained_actions(M, max(2, M // 4), X=X, grouped=bool(rs.rand() < 0.5))
         else:
             fn = G.mixed_actions(M, G.ALL_DEF, G.ALL_ATT, max(2, M // 4), X=X, unique=(kind not in ("dups", "wild")))
-        groups_cap = 1
+        groups_cap = 4 if kind == "trained" else 1
         if kind == "wild":   # step_grouped calls, action=None, partial ticks, out-of-range action types
             base, groups_cap = fn, 4
 
@@ -88,7 +94,8 @@ def main():
             fx = gio.Fixture(f"fuzz{case}", path=path)
             n = gio.check_oracle_against_fixture(fx)
         nx = int((fx.exp["ienv"][:, :, S.I_FLAGS].astype(np.int64) >> S.E_NX_SHIFT).max())
-        print(f"case {case}: ok  M={M} active={n_active} {kind} shuffle={int(shuffle)} {over} ticks={n} max_extra_edges={nx} "
+        n_fit = sum(len(v) for v in fx.det_events.values())
+        print(f"case {case}: ok  M={M} active={n_active} {kind} shuffle={int(shuffle)} {over} ticks={n} max_extra_edges={nx} trainings={n_fit} "
               f"[{time.time() - t0:.0f}s]", flush=True)
     print("reference fuzz: the oracle agrees with the reference on every case")
 

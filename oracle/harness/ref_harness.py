@@ -475,7 +475,7 @@ def run_scenario(env0, n_envs, n_ticks, action_fn, *, seed=0, env_id_base=0, pre
         init_dyn["forest"] = np.zeros(S.FOREST_WORDS, np.uint32)
         if det.trained:
             init_dyn["forest"] = export_forest(env)
-        fit_id = id(getattr(det.model, "estimators_", None))
+        fit_obj = getattr(det.model, "estimators_", None)   # held, not just its id(): a freed list's address gets reused
         det_events = []     # (tick, forest words, training rows) of every Detector.train(non-empty) of this env
         ticks = []
         acts = []
@@ -500,8 +500,8 @@ def run_scenario(env0, n_envs, n_ticks, action_fn, *, seed=0, env_id_base=0, pre
             if err is not None:
                 raise RuntimeError(f"scenario produced a reference exception at env {e} tick {t}: {err}")
             det = env.simulator.detector
-            if det.trained and id(getattr(det.model, "estimators_", None)) != fit_id:   # refitted during this tick
-                fit_id = id(det.model.estimators_)
+            if det.trained and getattr(det.model, "estimators_", None) is not fit_obj:   # refitted during this tick
+                fit_obj = det.model.estimators_
                 rows = [(int(l["from_device"]), int(l["to_device"])) for l in env.simulator.logger.logs[-S.TRAIN_WINDOW:]]
                 if env.turbo:    # _train_detector clips and down-samples in turbo mode (volt_typhoon_env.py:165-169)
                     rows = rows[-int(env.turbo_train_max_logs):][:: max(1, int(env.turbo_train_stride))]
