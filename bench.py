@@ -189,11 +189,9 @@ def run_workload(D: Dist, name, n_per_gpu, K, W, reps, sub, fused_T, seed, max_e
     def pipelined():
         graph.replay()
 
-    graph = None
-    if sub > 1:   # capture the S x K launches once (fork / join of the side streams inside the capture)
+    graph, cap = None, None
+    if sub > 1:   # the S x K launches are captured once, below (fork / join of the side streams inside the capture)
         cap = torch.cuda.Stream(device=dev)
-        with torch.cuda.stream(cap):
-            pass
         graph = torch.cuda.CUDAGraph()
 
     def leg(issue, launches_per_tick, what):
