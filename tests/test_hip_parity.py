@@ -347,3 +347,41 @@ def test_differential_fuzz_sample(monkeypatch):
     spec.loader.exec_module(fuzz)
     monkeypatch.setattr(sys, "argv", ["tools/fuzz.py", "--cases", "16", "--seed0", "5000", "--ticks", "150"])
     fuzz.main()   # exits non-zero (SystemExit) on the first mismatch
+
+
+def test_long_device_lists_replan_the_launch():
+    """Device lists as long as the network (max_devs = M, longer than the M/8 the handle was created for): the library
+    re-plans its LDS layout at the first step (cygym_step: max_devs > planned) -- also for the WIDE per-tick kernel, which
+    keeps the in-CSR maps in LDS -- and block / unblock / clean over whole-network lists match the oracle."""
+    from oracle import driver as od
+    M, N = 256, 128
+    topo, init, ck = make_topology(M, 1, seed=4, n_active=240)
+    cfg = abi.EnvConfig(seed=4, **ck)
+    small = _env(topo, cfg, N, init, max_groups=1, max_devs=M // 8)
+    small.gen_actions(0)
+    small.step()                                   # planned for lists of M/8 ...
+    env = _env(topo, cfg, N, init, max_groups=1, max_devs=M)
+    ob = od.OracleBatch(topo, cfg, N)
+    ob.load_state(init)
+    act = od.alloc_actions(N, 1, M)
+    rs = np.random.RandomState(5)
+    for t in range(24):
+        act["mode"][:] = S.MODE_DEFENDER if t % 2 == 0 else S.MODE_ATTACKER
+        act["atype"][:, 0] = rs.choice([6, 9, 1, 6, 7], size=N) if t % 2 == 0 else 1
+        act["n_exploit"][:] = 1
+        act["exploit"][:, 0, 0] = 0
+        for e in range(N):
+            k = int(rs.randint(M // 2, M + 1))
+            act["dev_cnt"][e, 0] = k
+            act["dev_idx"][e, :k] = rs.permutation(M)[:k]
+        env.set_actions_numpy(act)
+        obs, raw, shaped, done = env.step()
+        o_obs, o_raw, _, _ = ob.step(act)
+        got = env.state_numpy()
+        got["ienv"] = got["ienv"].copy()
+        got["ienv"][:, S.I_FLAGS] &= ~0x80
+        bad = gio.compare_state(got, ob.state, f"t={t}")
+        assert not bad, "\n".join(bad[:6])
+        np.testing.assert_allclose(raw.cpu().numpy(), o_raw, rtol=0, atol=1e-9)
+        np.testing.assert_array_equal(obs.cpu().numpy(), o_obs)
+    small.close(); env.close()
