@@ -119,7 +119,9 @@ __device__ __forceinline__ int spread_x_counts(Env& e, const uint16_t* cur, cons
   return total;
 }
 
-template <bool XE, class KP>
+// CR: long rows scanned per cooperative step (4 where the registers allow it: run-time sizes in workgroups of <= 8 waves)
+// GS: chunks per staged group of a chunk loop (4, or the whole env at a compile-time size)
+template <bool XE, int CR, int GS, class KP>
 __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32_t* expl, int ex0, int n_expl,
                                                 uint64_t* srcb) {
   const int M = e.M, MC = e.MC, Mp = MC * WAVE;
@@ -129,11 +131,16 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
   uint16_t* slist = e.lsrc;                     // [Mp] the sources in id order (snapshot :1127)
   uint64_t* cand = (uint64_t*)e.marks;          // [MC] candidate-device bitmask for full rows
   int n_src = 0;
+#pragma nounroll
+  for (int c0 = 0; c0 < MC; c0 += GS) {   // the sources in id order (compact list); staged like every chunk loop
+    uint64_t smj[GS];
 #pragma unroll
-  for (int c = 0; c < MC; ++c) {   // the sources in id order (compact list)
-    const uint64_t sm = srcb[c];
-    if ((sm >> e.lane) & 1ull) slist[n_src + below(sm)] = (uint16_t)(c * WAVE + e.lane);
-    n_src += __popcll(sm);
+    for (int j = 0; j < GS; ++j) smj[j] = c0 + j < MC ? srcb[c0 + j] : 0ull;
+#pragma unroll
+    for (int j = 0; j < GS; ++j) {
+      if ((smj[j] >> e.lane) & 1ull) slist[n_src + below(smj[j])] = (uint16_t)((c0 + j) * WAVE + e.lane);
+      n_src += __popcll(smj[j]);
+    }
   }
   wsync();
   const bool xany = XE && x_cnt(e) > 0;   // this env has added edges: their sources walk merged rows
@@ -152,15 +159,26 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
     }
     if (raw < 0 || raw >= P.t.X) continue;
     const uint8_t ebit = (uint8_t)(1u << raw);
+#pragma nounroll
+    for (int c0 = 0; c0 < MC; c0 += GS) {
+      uint32_t fj[GS], vj[GS], oj[GS];   // (32-bit scalars: byte arrays were left in scratch by one instantiation)
 #pragma unroll
-    for (int c = 0; c < MC; ++c) {
-      int d = c * WAVE + e.lane;
-      uint8_t f = d < M ? e.flags[d] : 0;
-      uint8_t x = (uint8_t)(((f & CG_F_REACH) ? 1 : 0) | (((f & CG_F_KNOWN) && d < M && (e.vul[d] & ebit)) ? 2 : 0));
-      T[d] = (((f & CG_F_COMP) ? 0u : T_TIME_INF) << 2) | x;
-      cur[d] = d < M ? e.optr[d] : 0;
-      uint64_t cm = ballot((x & 1) || ((x & 2) && !(f & CG_F_COMP)));
-      if (e.lane == 0) cand[c] = cm;
+      for (int j = 0; j < GS; ++j) {
+        const int d = (c0 + j) * WAVE + e.lane, dc = d < M ? d : 0;
+        fj[j] = e.flags[dc]; vj[j] = e.vul[dc]; oj[j] = e.optr[dc];
+      }
+#pragma unroll
+      for (int j = 0; j < GS; ++j) {
+        const int d = (c0 + j) * WAVE + e.lane;
+        const uint8_t f = d < M ? (uint8_t)fj[j] : (uint8_t)0;
+        const uint8_t x = (uint8_t)(((f & CG_F_REACH) ? 1 : 0) | (((f & CG_F_KNOWN) && (vj[j] & ebit)) ? 2 : 0));
+        const uint64_t cm = ballot((x & 1) || ((x & 2) && !(f & CG_F_COMP)));
+        if (c0 + j < MC) {
+          T[d] = (((f & CG_F_COMP) ? 0u : T_TIME_INF) << 2) | x;
+          cur[d] = d < M ? (uint16_t)oj[j] : (uint16_t)0;
+          if (e.lane == 0) cand[c0 + j] = cm;
+        }
+      }
     }
     wsync();
     SUBSTAMP(10);
@@ -210,16 +228,59 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
           }
         }
         uint64_t nm = ballot(coop);   // long rows that are not "full": wave-cooperative (re)scan
+        // Up to CR (four) rows per step: the first 64 slots of each are scanned by one ballot, and the four scans are
+        // independent LDS chains that overlap (one row at a time paid ~700 cycles of dependent latency per row:
+        // at 2048 devices ~100 such rows per sweep were half of the spread).  Rows of one step do not see each
+        // other's takes -- like the lanes of the per-lane path, the verification sweeps settle that.
         while (nm) {
-          const int src_lane = __builtin_ctzll(nm);
-          nm &= nm - 1;
-          const int ls = __builtin_amdgcn_readlane(s, src_lane), lo1 = __builtin_amdgcn_readlane(o1, src_lane), lk0 = __builtin_amdgcn_readlane(k0, src_lane);
-          const int lst = __builtin_amdgcn_readlane((int)st, src_lane);
-          const int k = spread_scan_coop(e, T, ls, lst & CG_D_DC, sweep == 0 ? lk0 : lk0 + 1, lo1);
+          int rs[CR], ro1[CR], rfrom[CR], rk[CR];
+          bool rdc[CR], rhave[CR];
+#pragma unroll
+          for (int j = 0; j < CR; ++j) {
+            rhave[j] = nm != 0;
+            const int src_lane = rhave[j] ? __builtin_ctzll(nm) : 0;
+            nm &= nm - 1;   // (0 stays 0)
+            rs[j] = __builtin_amdgcn_readlane(s, src_lane);
+            ro1[j] = rhave[j] ? __builtin_amdgcn_readlane(o1, src_lane) : 0;
+            const int lk0 = __builtin_amdgcn_readlane(k0, src_lane);
+            rfrom[j] = sweep == 0 ? lk0 : lk0 + 1;
+            rdc[j] = __builtin_amdgcn_readlane((int)st, src_lane) & CG_D_DC;
+          }
+          // staged and branch-free: the loads of one stage (blocked word + neighbour, then its T word) are issued for
+          // all four rows before the first is used (clamped slots; a short-circuit chain would serialise them)
+          uint64_t rm[CR];
+          uint32_t rbw[CR], rtv[CR];
+          int rkc[CR], rv[CR];
+#pragma unroll
+          for (int j = 0; j < CR; ++j) {
+            const int k = rfrom[j] + e.lane;
+            rkc[j] = k < ro1[j] ? k : (ro1[j] > 0 ? ro1[j] - 1 : 0);
+            rbw[j] = e.blk[rkc[j] >> 5];
+            rv[j] = e.ocol[rkc[j]];
+          }
+#pragma unroll
+          for (int j = 0; j < CR; ++j) rtv[j] = T[rv[j]];
+#pragma unroll
+          for (int j = 0; j < CR; ++j) {
+            const int k = rfrom[j] + e.lane;
+            const bool okv = (rtv[j] & 1u) || ((rtv[j] & 2u) && ((rtv[j] >> 2) >= (uint32_t)(rs[j] + 1)));
+            rm[j] = ballot(k < ro1[j] && !((rbw[j] >> (rkc[j] & 31)) & 1u) && (rdc[j] || okv));
+          }
+#pragma unroll
+          for (int j = 0; j < CR; ++j) {
+            if (rm[j]) rk[j] = rfrom[j] + __builtin_ctzll(rm[j]);
+            else rk[j] = rfrom[j] + WAVE < ro1[j] ? spread_scan_coop(e, T, rs[j], rdc[j], rfrom[j] + WAVE, ro1[j]) : ro1[j];
+          }
           if (sweep > 0) lost_any = true;
-          if (e.lane == 0) {
-            cur[ls] = (uint16_t)k;
-            if (k < lo1) spread_take(T, e.ocol[k], ls);
+          if (e.lane < CR) {   // lane j records the pick of row j
+            const int j = e.lane;
+            bool hv = rhave[0]; int ls = rs[0], k = rk[0], lo1 = ro1[0];
+#pragma unroll
+            for (int q = 1; q < CR; ++q) if (j == q) { hv = rhave[q]; ls = rs[q]; k = rk[q]; lo1 = ro1[q]; }
+            if (hv) {
+              cur[ls] = (uint16_t)k;
+              if (k < lo1) spread_take(T, e.ocol[k], ls);
+            }
           }
         }
         if (sweep > 0) wsync();   // the next block must see this block's takes
@@ -326,8 +387,17 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
     wsync();
     SUBSTAMP(13);
     // apply: compromise flags + DC attribution (:1163-1185)
-    for (int d = e.lane; d < M; d += WAVE)
-      if ((T[d] >> 2) != T_TIME_INF && (T[d] >> 2) != 0u) e.flags[d] |= CG_F_COMP;
+#pragma nounroll
+    for (int c0 = 0; c0 < MC; c0 += GS) {
+      uint32_t tj[GS], fj[GS];
+#pragma unroll
+      for (int j = 0; j < GS; ++j) { const int d = (c0 + j) * WAVE + e.lane, dc = d < M ? d : 0; tj[j] = T[dc]; fj[j] = e.flags[dc]; }
+#pragma unroll
+      for (int j = 0; j < GS; ++j) {
+        const int d = (c0 + j) * WAVE + e.lane;
+        if (d < M && (tj[j] >> 2) != T_TIME_INF && (tj[j] >> 2) != 0u) e.flags[d] = (uint8_t)(fj[j] | CG_F_COMP);
+      }
+    }
     for (int i = e.lane; i < n_src; i += WAVE) {
       int s = slist[i];
       if (!(e.dst[s] & CG_D_DC)) continue;

@@ -280,6 +280,7 @@ __device__ __forceinline__ void def_per_device(Env& e, const KP& P, int at, cons
     q.blk = e.blk; q.bin = e.bin; q.optr = e.optr; q.ocol = e.ocol; q.icol = e.icol_g; q.ieid = e.ieid_g; q.oeid = e.oeid_g;
     const bool multi = e.multi;
     int n_act = 0, n_hit = 0;
+    [[maybe_unused]] int n_pass_all = 0;   // diagnostic builds
     bool seq = false;
     if (COLD(XE && x_cnt(e) > 0)) {   // does the list touch an endpoint of an added edge?
       for (int p0 = 0; p0 < L; p0 += WAVE) {
@@ -301,7 +302,7 @@ __device__ __forceinline__ void def_per_device(Env& e, const KP& P, int at, cons
       }
       uint64_t am = ballot(d >= 0);
       n_act += __popcll(am);
-      SUBSTAMP(10);
+      if (p0 == 0) SUBSTAMP(10);
       [[maybe_unused]] int n_pass = 0;   // read by the stamps of diagnostic builds
       // Speculate: every remaining entry picks on the bitmasks as they stand.  An entry is exact unless an
       // EARLIER remaining entry flips an edge ending at its device (or is the same device); apply the exact
@@ -340,9 +341,11 @@ __device__ __forceinline__ void def_per_device(Env& e, const KP& P, int at, cons
         am &= q0 < WAVE ? (~0ull << q0) : 0ull;
         ++n_pass;
       }
+      n_pass_all += n_pass;
       SUBSTAMP(11);
-      SUBVAL(15, n_pass);
+      SUBVAL(15, n_pass_all);
       SUBVAL(14, n_act);
+      SUBVAL(13, (simple ? 0 : 1) | (seq ? 2 : 0));
     }
     cost += -0.5 * n_act * ds;
     fe[CG_D_DEF_COST] += 0.5 * n_act * ds;

@@ -11,6 +11,8 @@
 // instantiation (none of those buffers bound) carries none of that code.
 // Per-wave LDS carve + pointer table of one env (must match wave_lds_bytes on the host).
 // One lane per device PAIR: 12 floats = three 16-byte stores; static columns read as float2.
+#define PIN(x) asm volatile("" :: "v"(x))   // the value is complete here: its load cannot be sunk towards a later conditional use
+template <int GP>   // pairs per lane and step
 __device__ __forceinline__ void write_obs(const uint8_t* flags, const float* osv, const float* ver, const float* ano,
                                           float* obs, int M, int lane) {
   if (!(M & 1)) {
@@ -20,13 +22,29 @@ __device__ __forceinline__ void write_obs(const uint8_t* flags, const float* osv
     const float2* os2 = (const float2*)osv;
     const float2* ve2 = (const float2*)ver;
     const float2* an2 = (const float2*)ano;
-    for (int p = lane; p < npairs; p += WAVE) {
-      const uint32_t f2 = F2[p];
-      const float2 o = os2[p], v = ve2[p], a = an2[p];
-      const uint32_t fa = f2 & 0xFFu, fb = f2 >> 8;
-      out4[3 * p + 0] = make_float4(o.x, v.x, (float)(fa & 1u), a.x);
-      out4[3 * p + 1] = make_float4((float)((fa >> 2) & 1u), (float)((fa >> 4) & 1u), o.y, v.y);
-      out4[3 * p + 2] = make_float4((float)(fb & 1u), a.y, (float)((fb >> 2) & 1u), (float)((fb >> 4) & 1u));
+    // GP pairs per step, loads first: one round trip per step for the static columns (L2 at the sizes that keep
+    // them out of LDS), not one per pair -- the compiler will not move a load above the stores of the previous pair
+    for (int p0 = lane; p0 < npairs; p0 += GP * WAVE) {
+      uint32_t f2[GP];
+      float2 o[GP], v[GP], a[GP];
+#pragma unroll
+      for (int j = 0; j < GP; ++j) {
+        const int p = p0 + j * WAVE, pc = p < npairs ? p : npairs - 1;
+        f2[j] = F2[pc]; o[j] = os2[pc]; v[j] = ve2[pc]; a[j] = an2[pc];
+      }
+      if constexpr (GP > 1) {
+#pragma unroll
+        for (int j = 0; j < GP; ++j) { PIN(f2[j]); PIN(o[j].x); PIN(o[j].y); PIN(v[j].x); PIN(v[j].y); PIN(a[j].x); PIN(a[j].y); }
+      }
+#pragma unroll
+      for (int j = 0; j < GP; ++j) {
+        const int p = p0 + j * WAVE;
+        if (p >= npairs) break;
+        const uint32_t fa = f2[j] & 0xFFu, fb = f2[j] >> 8;
+        out4[3 * p + 0] = make_float4(o[j].x, v[j].x, (float)(fa & 1u), a[j].x);
+        out4[3 * p + 1] = make_float4((float)((fa >> 2) & 1u), (float)((fa >> 4) & 1u), o[j].y, v[j].y);
+        out4[3 * p + 2] = make_float4((float)(fb & 1u), a[j].y, (float)((fb >> 2) & 1u), (float)((fb >> 4) & 1u));
+      }
     }
   } else {   // odd M: rows are not 16-byte aligned across envs
     for (int d = lane; d < M; d += WAVE) {
@@ -80,6 +98,15 @@ __device__ __forceinline__ WaveAux env_setup(Env& e, uint8_t* smem, const KP& P,
 // FUSED: cygym_rollout (n_ticks > 1).  The per-env scalars are parked in LDS between ticks so that they are
 // not loop-carried registers; the single-tick instantiation has a compile-time trip count of 1.
 template <int WPB, int MT, bool FUSED, bool XE, bool WIDE>
+#ifndef CG_WGP0
+#define CG_WGP0 4   // run-time sizes: words / observation pairs per lane and staged step
+#endif
+#ifndef CG_OBS_GP0
+#define CG_OBS_GP0 4
+#endif
+#ifndef CG_PIN0
+#define CG_PIN0 1
+#endif
 #ifndef CG_LEAN_LB
 #define CG_LEAN_LB 6
 #endif
@@ -88,8 +115,12 @@ template <int WPB, int MT, bool FUSED, bool XE, bool WIDE>
 // per env and <= 16 envs per CU that is the whole batch in ONE residency round -- at 3 per SIMD a quarter of the
 // batch would wait for a second round).  The lean per-tick kernel at a compile-time size is capped for 6 waves per SIMD
 // (80 VGPRs, no spills): batches that oversubscribe the chip (16384 envs) step 9 % faster than at 5.
-__global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 && MT == 0 ? 3 : CG_LB) : (WIDE ? 4 : (MT && MT <= 256 ? (WPB <= 8 ? CG_LEAN_LB : CG_LEAN_LB - 1) : 1)))) void step_kernel(const KParams P0) {
+__global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 && MT == 0 ? 3 : CG_LB) : (WIDE ? 4 : (MT && MT <= 256 ? (WPB > 1 && WPB <= 8 ? CG_LEAN_LB : CG_LEAN_LB - 1) : 1)))) void step_kernel(const KParams P0) {
   extern __shared__ __align__(16) uint8_t smem[];
+#ifdef CG_STAMPS
+  unsigned long long t_entry;   // before the first parameter load: stamp 0 - t_entry = the cold kernarg round trip
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_entry) :: "memory");
+#endif
   // every use below goes through `P`: the by-value argument for the single-tick kernel; for the fused one a
   // pointer to the kernarg segment itself (the struct is the only argument, so it sits at offset 0), so that it
   // can be re-read, opaquely, at the top of every tick.  That pointer is in the CONSTANT address space: LLVM then
@@ -147,6 +178,19 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 &
   int16_t dv[PF_DEV];
   const bool vec = (M & 3) == 0;
   const int items = M >> 2;   // uint4 items of the [4][M] live block when M % 4 == 0
+  // Run-time sizes (up to 2048 devices, where one wave per SIMD is resident and nothing hides a round trip): every
+  // prologue load is pinned before the first LDS store.  A load whose only use sits in a conditional block is
+  // otherwise SUNK into that block, next to its s_waitcnt, and the staging runs as a chain of 8-16 dependent
+  // round trips.  (At the compile-time sizes, with 4+ waves per SIMD, the pinned form measured +-2 % and costs
+  // registers: not applied there.)
+#define KEEP4(r) asm volatile("" :: "v"((r).x), "v"((r).y), "v"((r).z), "v"((r).w))
+  constexpr int PF_BLOB = MT ? 4 : (WPB >= 16 ? 2 : WPB >= 8 ? 4 : 8);   // 16-byte items per lane: 32 KB per workgroup in the pinned round
+  const uint4* blob_src = (const uint4*)P.t.blob;
+  const int n16 = P.t.lds_bytes >> 4;
+  constexpr int stride = WPB * WAVE;
+  uint4 br[PF_BLOB];
+#pragma unroll
+  for (int j = 0; j < PF_BLOB; ++j) { const int i = threadIdx.x + j * stride; br[j] = blob_src[i < n16 ? i : n16 - 1]; }
   if (live) {
     const int32_t* g = P.b.ienv + (size_t)env * CG_I_COUNT;
 #pragma unroll
@@ -174,20 +218,26 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 &
     }
 #pragma unroll
     for (int j = 0; j < PF_DEV; ++j) { int q = lane + j * WAVE; dv[j] = q < L ? P.a.dev_idx[(size_t)env * L + q] : (int16_t)0; }
-  }
-  // ---- workgroup-shared topology blob -> LDS: every 16-byte load is issued before the first store ----
-  {
-    const uint4* src = (const uint4*)P.t.blob;
-    uint4* dstp = (uint4*)smem;
-    const int n16 = P.t.lds_bytes >> 4, stride = WPB * WAVE;
-    constexpr int PF_BLOB = MT ? 4 : 8;
-    uint4 br[PF_BLOB];
+    if constexpr (MT == 0 && CG_PIN0) {
 #pragma unroll
-    for (int j = 0; j < PF_BLOB; ++j) { const int i = threadIdx.x + j * stride; br[j] = src[i < n16 ? i : n16 - 1]; }   // unconditional: stays in registers
+      for (int j = 0; j < PF_LIVE; ++j) KEEP4(rl[j]);
+#pragma unroll
+      for (int j = 0; j < PF_BLK; ++j) asm volatile("" :: "v"(bw[j]), "v"(bwi[j]));
+      asm volatile("" :: "v"(ringw), "v"((int)dv[0]));
+    }
+  }
+  // ---- workgroup-shared topology blob -> LDS ----
+  {
+    if constexpr (MT == 0 && CG_PIN0) {
+#pragma unroll
+      for (int j = 0; j < PF_BLOB; ++j) KEEP4(br[j]);
+    }
+    uint4* dstp = (uint4*)smem;
 #pragma unroll
     for (int j = 0; j < PF_BLOB; ++j) { const int i = threadIdx.x + j * stride; if (i < n16) dstp[i] = br[j]; }
-    for (int i = threadIdx.x + PF_BLOB * stride; i < n16; i += stride) dstp[i] = src[i];
+    for (int i = threadIdx.x + PF_BLOB * stride; i < n16; i += stride) dstp[i] = blob_src[i];
   }
+#undef KEEP4
   if (live) {
     if (vec) {
 #pragma unroll
@@ -212,6 +262,10 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 &
   STAMP(1);
 
   const int NW = MS >> 2;
+  // word loops run in groups of WGP words per lane, loads first (see the chunk loops of the spread): one LDS round trip
+  // per group instead of one per word; a single word per lane at the compile-time sizes
+  constexpr int CGP = MT ? ((MT + WAVE - 1) / WAVE < 4 ? (MT + WAVE - 1) / WAVE : 4) : 4;   // chunks per staged group
+  constexpr int WGP = MT ? (((MT + 3) / 4 + WAVE - 1) / WAVE < 4 ? ((MT + 3) / 4 + WAVE - 1) / WAVE : 4) : CG_WGP0;
 
   // ---- ticks of this launch: 1 for cygym_step, T for cygym_rollout (state stays in LDS / registers;
   // no cross-env synchronisation between ticks) ----
@@ -300,9 +354,16 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 &
     if (Ld < 0) Ld = 0;
     if (mode == CG_MODE_DEFENDER) { if (!(at >= 0 && at < P.c.n_def_actions)) at = 8; }
     else                          { if (!(at >= 0 && at < P.c.n_att_actions)) at = 3; }
-    for (int w = lane; w < NW; w += WAVE) {   // :904-908 decay of the cached busy set
-      uint32_t b = Bz[w];
-      Bz[w] = b - (((F[w] >> 6) & ONES) & nz01(b));
+    for (int w0 = lane; w0 < NW; w0 += WGP * WAVE) {   // :904-908 decay of the cached busy set
+      uint32_t bj[WGP], fj[WGP];
+#pragma unroll
+      for (int j = 0; j < WGP; ++j) { const int w = w0 + j * WAVE, wc = w < NW ? w : w0; bj[j] = Bz[wc]; fj[j] = F[wc]; }
+      if constexpr (WGP > 1) {
+#pragma unroll
+        for (int j = 0; j < WGP; ++j) { PIN(bj[j]); PIN(fj[j]); }
+      }
+#pragma unroll
+      for (int j = 0; j < WGP; ++j) { const int w = w0 + j * WAVE; if (w < NW) Bz[w] = bj[j] - (((fj[j] >> 6) & ONES) & nz01(bj[j])); }
     }
     wsync();
     if (mode == CG_MODE_DEFENDER) {
@@ -311,18 +372,26 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 &
       if (at == 1 || at == 4 || at == 5 || at == 6 || at == 7 || at == 9 || at == 12 || at == 13)
         if (Ld > 0) def_per_device<XE, WIDE>(e, P, at, devs, Ld, app0, cost, dirty, ie, fe);
     } else if (P.c.baseline != 3 && (at == 1 || at == 2)) {
+      // :1127 snapshot of the sources.  Chunk loops are STAGED in groups of four: the LDS reads of a group are issued
+      // before its first store (the compiler cannot reorder an LDS load over an LDS store it cannot disambiguate, so a
+      // plain chunk loop pays one LDS round trip per chunk, one after the other)
+#pragma nounroll
+      for (int c0 = 0; c0 < MC; c0 += CGP) {
+        uint32_t fj[CGP];
 #pragma unroll
-      for (int c = 0; c < MC; ++c) {   // :1127 snapshot of the sources
-        int d = c * WAVE + lane;
-        uint64_t m = ballot(d < M && (e.flags[d] & (CG_F_COMP | CG_F_OWNED)));
-        if (lane == 0) srcb[c] = m;
+        for (int j = 0; j < CGP; ++j) { const int d = (c0 + j) * WAVE + lane; fj[j] = d < M ? e.flags[d] : 0u; }
+#pragma unroll
+        for (int j = 0; j < CGP; ++j) {
+          const uint64_t m = ballot(fj[j] & (CG_F_COMP | CG_F_OWNED));
+          if (lane == 0 && c0 + j < MC) srcb[c0 + j] = m;
+        }
       }
       wsync();
       if (at == 1) {
         int ne = nexp0;
         if (ne > CG_MAX_EXPLOITS) ne = CG_MAX_EXPLOITS;
         __builtin_amdgcn_s_setprio(3);   // the spread bounds the launch: win issue arbitration over short envs
-        attacker_spread<XE>(e, P, P.a.exploit + te * G * CG_MAX_EXPLOITS, ex0, ne, srcb);
+        attacker_spread<XE, (MT == 0 && WPB <= 8) ? 4 : 1, CGP>(e, P, P.a.exploit + te * G * CG_MAX_EXPLOITS, ex0, ne, srcb);
         __builtin_amdgcn_s_setprio(0);
       } else {
         attacker_probe<XE>(e, srcb, cost);
@@ -356,8 +425,19 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 &
   STAMP(2);
   // ---- fused word pass: workload advance (:1242-1261 / :705-725) + every per-tick count ----
   int c_fin = 0, c_act = 0, c_idle = 0, c_fsrv = 0, c_comp = 0, c_cdc = 0;
-  for (int w = lane; w < NW; w += WAVE) {
-    uint32_t f = F[w], b = Bz[w], l = Wl[w], st = Ds[w];
+  for (int w0 = lane; w0 < NW; w0 += WGP * WAVE) {
+    uint32_t fj[WGP], bj[WGP], lj[WGP], sj[WGP];
+#pragma unroll
+    for (int j = 0; j < WGP; ++j) { const int w = w0 + j * WAVE, wc = w < NW ? w : w0; fj[j] = F[wc]; bj[j] = Bz[wc]; lj[j] = Wl[wc]; sj[j] = Ds[wc]; }
+    if constexpr (WGP > 1) {
+#pragma unroll
+      for (int j = 0; j < WGP; ++j) { PIN(fj[j]); PIN(bj[j]); PIN(lj[j]); PIN(sj[j]); }
+    }
+#pragma unroll
+    for (int j = 0; j < WGP; ++j) {
+    const int w = w0 + j * WAVE;
+    if (w >= NW) break;
+    uint32_t f = fj[j], b = bj[j], l = lj[j], st = sj[j];
     const uint32_t nya = (f >> 4) & ONES;
     const uint32_t step = partial ? 0u : (~nz01(b) & ~nya & nz01(l) & ONES);   // idle-of-stall, active, has a job
     l -= step;
@@ -374,6 +454,7 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 &
     c_fsrv += __popc(idl & (st >> 1));
     c_comp += __popc(cmp);
     c_cdc += __popc(cmp & st);
+    }
   }
   // six per-lane counts (each <= 32, sums <= 2048) as three packed 16 + 16-bit wave reductions on the DPP path
   const uint32_t s_fa = (uint32_t)wave_sum(c_fin | (c_act << 16));
@@ -411,9 +492,10 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 &
   STAMP(4);
   // ---- observation (_get_state CyberDefenseEnv.py:146-191), before evolve.  The static float columns come from
   // LDS, or (large M, where leaving them out of LDS buys resident waves) from the L2-resident blob.
-  if (P.t.in_lds) write_obs(e.flags, e.osv, e.ver, e.ano, P.o.obs + te * M * 6, M, lane);
-  else write_obs(e.flags, (const float*)(P.t.blob + P.t.o_os), (const float*)(P.t.blob + P.t.o_ver),
-                 (const float*)(P.t.blob + P.t.o_ano), P.o.obs + te * M * 6, M, lane);
+  constexpr int OBS_GP = MT ? ((MT / 2 + WAVE - 1) / WAVE < 4 ? (MT / 2 + WAVE - 1) / WAVE : 4) : CG_OBS_GP0;
+  if (P.t.in_lds) write_obs<OBS_GP>(e.flags, e.osv, e.ver, e.ano, P.o.obs + te * M * 6, M, lane);
+  else write_obs<OBS_GP>(e.flags, (const float*)(P.t.blob + P.t.o_os), (const float*)(P.t.blob + P.t.o_ver),
+                         (const float*)(P.t.blob + P.t.o_ano), P.o.obs + te * M * 6, M, lane);
 
   STAMP(5);
   if (!partial) {   // :1307-1312
@@ -423,7 +505,17 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 &
   const bool done = ie[CG_I_STEP_NUM] > P.c.episode_limit;
   if (dirty || umod(ie[CG_I_STEP_NUM], P.c.evolve_period) == 0) evolve<XE>(e, P);
   if (ng == 0) {   // :1330 rebuild of the cached busy set
-    for (int w = lane; w < NW; w += WAVE) F[w] = (F[w] & ~(ONES * CG_F_BUSYC)) | (nz01(Bz[w]) << 6);
+    for (int w0 = lane; w0 < NW; w0 += WGP * WAVE) {
+      uint32_t fj[WGP], bj[WGP];
+#pragma unroll
+      for (int j = 0; j < WGP; ++j) { const int w = w0 + j * WAVE, wc = w < NW ? w : w0; fj[j] = F[wc]; bj[j] = Bz[wc]; }
+      if constexpr (WGP > 1) {
+#pragma unroll
+        for (int j = 0; j < WGP; ++j) { PIN(fj[j]); PIN(bj[j]); }
+      }
+#pragma unroll
+      for (int j = 0; j < WGP; ++j) { const int w = w0 + j * WAVE; if (w < NW) F[w] = (fj[j] & ~(ONES * CG_F_BUSYC)) | (nz01(bj[j]) << 6); }
+    }
   }
   wsync();
   ie[CG_I_RNG_TICK] += 1;
@@ -532,7 +624,10 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 &
   }
   STAMP(7);
 #ifdef CG_STAMPS
-  if (P.dbg && lane == 0) { P.dbg[(size_t)env * 16 + 8] = (unsigned long long)(long long)ie[CG_I_LAST_ATYPE]; P.dbg[(size_t)env * 16 + 9] = (unsigned long long)mode; }
+  if (P.dbg && lane == 0) {
+    P.dbg[(size_t)env * 16 + 8] = (unsigned long long)(long long)ie[CG_I_LAST_ATYPE];
+    P.dbg[(size_t)env * 16 + 9] = (unsigned long long)mode | ((P.dbg[(size_t)env * 16] - t_entry) << 8);
+  }
 #endif
 #undef P
 }
