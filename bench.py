@@ -53,6 +53,9 @@ WORKLOADS = {
 # oversubscribes the chip (more envs than resident waves: cfg3 / cfg4 +16 %, cfg5 +19 %); at 4096 envs every env has
 # its own resident wave and a second stream only adds launches (-7 %), so those workloads step with one launch per tick.
 DEFAULT_SUB = {"target": 1, "cfg2": 1, "cfg3": 2, "cfg4": 2, "cfg5": 4}
+# Extra-edge capacity per workload (--max-extra overrides): 0 = fixed topology, lean kernels; -1 = the generator's default
+# capacity, full-feature kernels.  Only cfg5's topology can ask for an edge with lambda_events = 0 (see --max-extra).
+DEFAULT_MAX_EXTRA = {"target": 0, "cfg2": 0, "cfg3": 0, "cfg4": 0, "cfg5": -1}
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 PMC_SUMMARY = "r02_pmc_summary.json"   # profiles/: per workload and kernel class, bytes per launch from the --pmc passes
@@ -241,7 +244,9 @@ def run_workload(D: Dist, name, n_per_gpu, K, W, reps, sub, fused_T, seed, max_e
                    "last_raw_reward_sum": float(chunks[-1][1]["raw"][-1].sum())}
         del chunks
 
+    x_used = (env.state["ienv"][:, S.I_FLAGS].to(torch.int64) & 0xFFFFFFFF) >> 16   # live entries of the extra-edge lists
     rec = {"workload": f"{name}: {desc}", "envs_per_gpu": N, "devices": M, "edges": topo.E, "exploits": topo.X,
+           "max_extra_edges": topo.max_extra, "envs_with_added_edges": int((x_used > 0).sum()),
            "bytes_per_env_step": B, "layout_bytes_per_env_step": layout_bytes(M, topo.E),
            "per_tick_stepping": per_tick, "fused_rollout": rollout,
            "check": {"last_raw_reward_sum": per_tick["last_raw_reward_sum"],
@@ -383,6 +388,7 @@ def cpu_baseline(topo, init, cfg, M, L, scripts, W, budget_s):
 def brief(rec):
     """The sub-record of a secondary workload in the `configs` block."""
     out = {"workload": rec["workload"], "envs_per_gpu": rec["envs_per_gpu"], "devices": rec["devices"],
+           "max_extra_edges": rec.get("max_extra_edges"), "envs_with_added_edges": rec.get("envs_with_added_edges"),
            "bytes_per_env_step": rec["bytes_per_env_step"], "check": rec["check"]}
     for key in ("per_tick_stepping", "fused_rollout"):
         leg = rec[key]
@@ -415,11 +421,13 @@ def main():
                          "1 = one full-batch launch per tick only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the short runs of the other single-GPU BASELINE configs")
-    ap.add_argument("--max-extra", type=int, default=0,
-                    help="capacity of the per-env list of edges evolve_network may add.  0 (default): no list -- this is the "
-                         "fixed-topology run of SURVEY.md 8d (lambda_events = 0 can never add an edge; bench.py checks that "
-                         "no env wanted one), lean kernels; -1: the topology generator's default (room for two attacker "
-                         "stars), i.e. the full-feature kernels")
+    ap.add_argument("--max-extra", type=int, default=None,
+                    help="capacity of the per-env list of edges evolve_network may add.  0: no list -- the fixed-topology run "
+                         "of SURVEY.md 8d (with lambda_events = 0 only the attacker-star check can want an edge; bench.py "
+                         "reports how many envs did), lean kernels; -1: the topology generator's default (room for two "
+                         "attacker stars), i.e. the full-feature kernels.  Default: 0, except for cfg5 (2048 devices), "
+                         "whose sparse topology has ONE star hub: once a defender takes it out the next evolve re-links "
+                         "the star with added edges, so that workload runs with the list (-1)")
     ap.add_argument("--cpu-seconds", type=float, default=16.0)
     ap.add_argument("--fused", type=int, default=-1,
                     help="ticks per cygym_rollout launch (-1 = all K steps in one launch, 0 = skip the rollout leg)")
@@ -434,8 +442,9 @@ def main():
     name = args.workload
     n_per_gpu = args.envs or WORKLOADS[name][0]
     sub = args.sub_batches or DEFAULT_SUB[name]
+    max_extra_of = lambda w: DEFAULT_MAX_EXTRA[w] if args.max_extra is None else args.max_extra
     rec, (env, topo, init, cfg, M, L, scripts) = run_workload(D, name, n_per_gpu, K, W, args.reps, sub, args.fused, args.seed,
-                                                               args.max_extra)
+                                                               max_extra_of(name))
     per_tick, rollout = rec["per_tick_stepping"], rec["fused_rollout"]
     head = rollout if (rollout is not None and args.headline == "rollout") else per_tick
     other_key, other = ("per_tick_stepping", per_tick) if head is rollout else ("fused_rollout", rollout)
@@ -481,7 +490,7 @@ def main():
         out["configs"] = {}
         for w in others:
             kk = min(K, 20 if w != "cfg5" else 10)
-            r, objs = run_workload(D, w, WORKLOADS[w][0], kk, min(W, 5), min(args.reps, 5), DEFAULT_SUB[w], -1, args.seed, args.max_extra)
+            r, objs = run_workload(D, w, WORKLOADS[w][0], kk, min(W, 5), min(args.reps, 5), DEFAULT_SUB[w], -1, args.seed, max_extra_of(w))
             objs[0].close()
             del objs
             b = brief(r)

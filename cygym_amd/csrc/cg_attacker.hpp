@@ -33,6 +33,40 @@ __device__ __forceinline__ int spread_scan_lane(const Env& e, const uint32_t* T,
   }
   return o1;
 }
+// The same with v / low = the device and the constant low bits of T[v], STAGED (run-time sizes, where one resident wave
+// per SIMD leaves every LDS round trip exposed; at 256 devices with 4 waves per SIMD it measured -1 %): the row's blocked words and its first four neighbours are read together, then the four T words -- two LDS
+// round trips for the usual two- or three-slot row instead of two per slot.
+__device__ __forceinline__ int spread_scan_lane_st(const Env& e, const uint32_t* T, int s, bool dc,
+                                                int from, int o1, int& v, uint32_t& low) {
+  if (from >= o1) return o1;
+  // the row (<= LONG_ROW slots) spans at most two words of the blocked bitmask
+  const int w0 = from >> 5;
+  const bool two = ((o1 - 1) >> 5) != w0;
+  const uint32_t b_lo = e.blk[w0], b_hi = e.blk[two ? w0 + 1 : w0];
+  int vv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) vv[j] = e.ocol[from + j < o1 ? from + j : o1 - 1];
+  uint32_t tt[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) tt[j] = T[vv[j]];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) PIN(tt[j]);
+  uint64_t bits = (uint64_t)b_lo | (two ? (uint64_t)b_hi << 32 : 0ull);
+  bits >>= (from & 31);   // bit i <-> slot from + i
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const bool okv = (tt[j] & 1u) || ((tt[j] & 2u) && ((tt[j] >> 2) >= (uint32_t)(s + 1)));
+    if (from + j < o1 && !((bits >> j) & 1ull) && (dc || okv)) { v = vv[j]; low = tt[j] & 3u; return from + j; }
+  }
+  bits >>= 4;
+  for (int k = from + 4; k < o1; ++k, bits >>= 1) {
+    if (bits & 1ull) continue;
+    const int vk = e.ocol[k];
+    const uint32_t tk = T[vk];
+    if (dc || (tk & 1u) || ((tk & 2u) && ((tk >> 2) >= (uint32_t)(s + 1)))) { v = vk; low = tk & 3u; return k; }
+  }
+  return o1;
+}
 // same for a FULL row (slot k <-> device v = k - o0 + (k - o0 >= s)): walk the candidate-device bitmask
 // instead of the row; `cand` holds reach | (known & vulnerable & not compromised at the start)
 __device__ __forceinline__ int spread_scan_full(const Env& e, const uint32_t* T, const uint64_t* cand,
@@ -119,7 +153,8 @@ __device__ __forceinline__ int spread_x_counts(Env& e, const uint16_t* cur, cons
   return total;
 }
 
-// CR: long rows scanned per cooperative step (4 where the registers allow it: run-time sizes in workgroups of <= 8 waves)
+// CR: long rows scanned per cooperative step (4 where the registers allow it: run-time sizes in workgroups of <= 8 waves;
+// CR > 1 also selects the staged per-lane scan)
 // GS: chunks per staged group of a chunk loop (4, or the whole env at a compile-time size)
 template <bool XE, int CR, int GS, class KP>
 __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32_t* expl, int ex0, int n_expl,
@@ -214,7 +249,10 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
               const int from = sweep == 0 ? o0 : k0 + 1;
               uint32_t low = 0;
               int k, v = 0;
-              if (shortrow) { k = spread_scan_lane(e, T, s, dc, from, o1); if (k < o1) { v = e.ocol[k]; low = T[v] & 3u; } }
+              if (shortrow) {
+                if constexpr (CR > 1) k = spread_scan_lane_st(e, T, s, dc, from, o1, v, low);
+                else { k = spread_scan_lane(e, T, s, dc, from, o1); if (k < o1) { v = e.ocol[k]; low = T[v] & 3u; } }
+              }
               else {
                 k = spread_scan_full(e, T, cand, s, from, o0, o1);
                 if (k < o1) { v = (k - o0) + ((k - o0) >= s ? 1 : 0); low = T[v] & 3u; }

@@ -174,89 +174,79 @@ __device__ __forceinline__ void pool_flip(const PoolPtrs q, bool multi, const Pi
   }
 }
 
-// Block / unblock on an env whose device list touches an endpoint of an ADDED edge: the incident pools are the
-// merged rows (:502-511).  Sequential over the list (the reference's own order), every step wave-cooperative.
+// Block / unblock of ONE list entry whose device is an endpoint of an ADDED edge: its pools are the merged rows
+// (:502-511).  Wave-cooperative, uniform arguments; runs at the entry's turn in list order (every earlier entry has
+// been applied), so it reads the bitmasks as the reference would.
 // Element r of a merged pool: walk the added-edge candidates in row order; candidate j has rank
 // (#added candidates before it) + (#base candidates with a smaller neighbour id).
-__device__ __forceinline__ void block_seq(Env& e, const PoolPtrs q, const int16_t* dev, int L, bool want, uint32_t site,
-                                          int& n_act, int& n_hit) {
-  const int M = e.M;
-  uint8_t* occ = (uint8_t*)(e.scr + e.MC * WAVE);
-#pragma nounroll
-  for (int i = e.lane; i < (e.MC * WAVE) / 4; i += WAVE) ((uint32_t*)occ)[i] = 0;
-  wsync();
+// occ: occurrence numbers per device (nullptr: the list holds no device twice).
+__device__ __forceinline__ void block_one(Env& e, const PoolPtrs q, int d, bool want, uint32_t site, uint8_t* occ, int& n_hit) {
   const int n = x_cnt(e);
+  const int o0 = e.optr[d], o1 = e.optr[d + 1], i0 = e.iptr(d), i1 = e.iptr(d + 1);
+  const int nbo = range_popc(q.blk, o0, o1), nbi = range_popc(q.bin, i0, i1);
+  const int b_out = want ? nbo : (o1 - o0) - nbo, b_in = want ? nbi : (i1 - i0) - nbi;
+  int x_out = 0, x_in = 0;
 #pragma nounroll
-  for (int p = 0; p < L; ++p) {
-    const int d = dev[p];
-    if (d < 0 || d >= M || (e.flags[d] & CG_F_NYA)) continue;
-    ++n_act;
-    const int o0 = e.optr[d], o1 = e.optr[d + 1], i0 = e.iptr(d), i1 = e.iptr(d + 1);
-    const int nbo = range_popc(q.blk, o0, o1), nbi = range_popc(q.bin, i0, i1);
-    const int b_out = want ? nbo : (o1 - o0) - nbo, b_in = want ? nbi : (i1 - i0) - nbi;
-    int x_out = 0, x_in = 0;
-#pragma nounroll
-    for (int j0 = 0; j0 < n; j0 += WAVE) {
-      const int j = j0 + e.lane;
-      const uint32_t k = j < n ? e.xk[j] : 0u;
-      const bool c = j < n && x_blocked(e, j) == want;
-      x_out += __popcll(ballot(c && (int)(k >> 16) == d));
-      x_in += __popcll(ballot(c && (int)(k & 0xFFFFu) == d));
-    }
-    const int total = b_out + x_out + b_in + x_in;
-    if (total == 0) continue;
-    const int occ_d = occ[d];
-    int r = (int)cg_index(e.draw(site, d, occ_d), (uint32_t)total);
-    const bool from_out = r < b_out + x_out;
-    if (!from_out) r -= b_out + x_out;
-    int pick_x = -1, x_before = 0;   // chosen added edge, or the number of added candidates ahead of element r
-#pragma nounroll
-    for (int j0 = 0; j0 < n && pick_x < 0; j0 += WAVE) {
-      const int j = j0 + e.lane;
-      const uint32_t kk = j < n ? e.xk[j] : 0u;
-      uint64_t xm = ballot(j < n && x_blocked(e, j) == want && (from_out ? (int)(kk >> 16) == d : (int)(kk & 0xFFFFu) == d));
-#pragma nounroll
-      while (xm) {
-        const int jj = j0 + __builtin_ctzll(xm);
-        xm &= xm - 1;
-        const uint32_t key = e.xk[jj];
-        const int other = from_out ? (int)(key & 0xFFFFu) : (int)(key >> 16);
-        int cb = 0;   // base candidates ahead of this added edge
-        if (from_out) {
-#pragma nounroll
-          for (int k0 = o0; k0 < o1; k0 += WAVE) {
-            const int k = k0 + e.lane;
-            cb += __popcll(ballot(k < o1 && (((q.blk[k >> 5] >> (k & 31)) & 1u) != 0) == want && (int)q.ocol[k] < other));
-          }
-        } else {
-#pragma nounroll
-          for (int k0 = i0; k0 < i1; k0 += WAVE) {
-            const int k = k0 + e.lane;
-            cb += __popcll(ballot(k < i1 && (((q.bin[k >> 5] >> (k & 31)) & 1u) != 0) == want && (int)q.icol[k] <= other));
-          }
-        }
-        if (r == x_before + cb) { pick_x = jj; break; }
-        if (r < x_before + cb) { xm = 0; j0 = n; break; }   // element r is a base candidate
-        ++x_before;
-      }
-    }
-    if (pick_x >= 0) {
-      if (e.lane == 0) {
-        if (!want) e.xb[pick_x >> 5] |= 1u << (pick_x & 31); else e.xb[pick_x >> 5] &= ~(1u << (pick_x & 31));
-      }
-      e.x_dirty = true;
-    } else {
-      Pick pk;
-      const int t = r - x_before;
-      if (from_out) { pk.slot = range_select(q.blk, o0, o1, want, t); pk.j = q.oeid[pk.slot]; pk.x = q.ocol[pk.slot]; }
-      else          { pk.j = range_select(q.bin, i0, i1, want, t); pk.slot = q.ieid[pk.j]; pk.x = q.icol[pk.j]; }
-      if (e.lane == 0) pool_flip(q, e.multi, pk, d, o0, o1, want);
-      e.blk_dirty = true;
-    }
-    if (e.lane == 0) occ[d] = (uint8_t)(occ_d + 1);
-    ++n_hit;
-    wsync();
+  for (int j0 = 0; j0 < n; j0 += WAVE) {
+    const int j = j0 + e.lane;
+    const uint32_t k = j < n ? e.xk[j] : 0u;
+    const bool c = j < n && x_blocked(e, j) == want;
+    x_out += __popcll(ballot(c && (int)(k >> 16) == d));
+    x_in += __popcll(ballot(c && (int)(k & 0xFFFFu) == d));
   }
+  const int total = b_out + x_out + b_in + x_in;
+  if (total == 0) return;
+  const int occ_d = occ ? (int)occ[d] : 0;
+  int r = (int)cg_index(e.draw(site, d, occ_d), (uint32_t)total);
+  const bool from_out = r < b_out + x_out;
+  if (!from_out) r -= b_out + x_out;
+  int pick_x = -1, x_before = 0;   // chosen added edge, or the number of added candidates ahead of element r
+#pragma nounroll
+  for (int j0 = 0; j0 < n && pick_x < 0; j0 += WAVE) {
+    const int j = j0 + e.lane;
+    const uint32_t kk = j < n ? e.xk[j] : 0u;
+    uint64_t xm = ballot(j < n && x_blocked(e, j) == want && (from_out ? (int)(kk >> 16) == d : (int)(kk & 0xFFFFu) == d));
+#pragma nounroll
+    while (xm) {
+      const int jj = j0 + __builtin_ctzll(xm);
+      xm &= xm - 1;
+      const uint32_t key = e.xk[jj];
+      const int other = from_out ? (int)(key & 0xFFFFu) : (int)(key >> 16);
+      int cb = 0;   // base candidates ahead of this added edge
+      if (from_out) {
+#pragma nounroll
+        for (int k0 = o0; k0 < o1; k0 += WAVE) {
+          const int k = k0 + e.lane;
+          cb += __popcll(ballot(k < o1 && (((q.blk[k >> 5] >> (k & 31)) & 1u) != 0) == want && (int)q.ocol[k] < other));
+        }
+      } else {
+#pragma nounroll
+        for (int k0 = i0; k0 < i1; k0 += WAVE) {
+          const int k = k0 + e.lane;
+          cb += __popcll(ballot(k < i1 && (((q.bin[k >> 5] >> (k & 31)) & 1u) != 0) == want && (int)q.icol[k] <= other));
+        }
+      }
+      if (r == x_before + cb) { pick_x = jj; break; }
+      if (r < x_before + cb) { xm = 0; j0 = n; break; }   // element r is a base candidate
+      ++x_before;
+    }
+  }
+  if (pick_x >= 0) {
+    if (e.lane == 0) {
+      if (!want) e.xb[pick_x >> 5] |= 1u << (pick_x & 31); else e.xb[pick_x >> 5] &= ~(1u << (pick_x & 31));
+    }
+    e.x_dirty = true;
+  } else {
+    Pick pk;
+    const int t = r - x_before;
+    if (from_out) { pk.slot = range_select(q.blk, o0, o1, want, t); pk.j = q.oeid[pk.slot]; pk.x = q.ocol[pk.slot]; }
+    else          { pk.j = range_select(q.bin, i0, i1, want, t); pk.slot = q.ieid[pk.j]; pk.x = q.icol[pk.j]; }
+    if (e.lane == 0) pool_flip(q, e.multi, pk, d, o0, o1, want);
+    e.blk_dirty = true;
+  }
+  if (occ && e.lane == 0) occ[d] = (uint8_t)(occ_d + 1);
+  ++n_hit;
+  wsync();
 }
 
 template <bool XE, bool WIDE, class KP>
@@ -281,16 +271,8 @@ __device__ __forceinline__ void def_per_device(Env& e, const KP& P, int at, cons
     const bool multi = e.multi;
     int n_act = 0, n_hit = 0;
     [[maybe_unused]] int n_pass_all = 0;   // diagnostic builds
-    bool seq = false;
-    if (COLD(XE && x_cnt(e) > 0)) {   // does the list touch an endpoint of an added edge?
-      for (int p0 = 0; p0 < L; p0 += WAVE) {
-        const int p = p0 + e.lane;
-        const int d = p < L ? dev[p] : -1;
-        if (__any(d >= 0 && d < M && x_isinc(e, d))) seq = true;
-      }
-    }
-    if constexpr (XE) { if (COLD(seq)) block_seq(e, q, dev, L, want, site, n_act, n_hit); }
-    for (int p0 = 0; p0 < L && !seq; p0 += WAVE) {
+    const bool xany = XE && x_cnt(e) > 0;   // this env carries added edges: entries on their endpoints take block_one
+    for (int p0 = 0; p0 < L; p0 += WAVE) {
       // one lane per list entry: device, row bounds and the (occurrence 0) draw
       const int p = p0 + e.lane;
       int d = -1, o0 = 0, o1 = 0, i0 = 0, i1 = 0;
@@ -302,6 +284,8 @@ __device__ __forceinline__ void def_per_device(Env& e, const KP& P, int at, cons
       }
       uint64_t am = ballot(d >= 0);
       n_act += __popcll(am);
+      uint64_t xm = 0ull;   // remaining entries whose device is an endpoint of an added edge
+      if constexpr (XE) { if (COLD(xany)) xm = ballot(d >= 0 && x_isinc(e, d)); }
       if (p0 == 0) SUBSTAMP(10);
       [[maybe_unused]] int n_pass = 0;   // read by the stamps of diagnostic builds
       // Speculate: every remaining entry picks on the bitmasks as they stand.  An entry is exact unless an
@@ -313,8 +297,20 @@ __device__ __forceinline__ void def_per_device(Env& e, const KP& P, int at, cons
       wsync();
       uint32_t epoch = 0;
       while (am) {
+        int lim = WAVE;   // speculate only ahead of the next merged-pool entry
+        if constexpr (XE) {
+          if (COLD(xm != 0ull)) {
+            const int first = __builtin_ctzll(am);
+            if ((xm >> first) & 1ull) {   // next in list order: alone, on the bitmasks every earlier entry has left
+              block_one(e, q, __builtin_amdgcn_readlane(d, first), want, site, simple ? nullptr : occ, n_hit);
+              am &= am - 1; xm &= xm - 1;
+              continue;
+            }
+            lim = __builtin_ctzll(xm);
+          }
+        }
         epoch += 0x100u;   // (pass + 1) << 8, above the 6 lane bits
-        const bool mine = (am >> e.lane) & 1ull;
+        const bool mine = ((am >> e.lane) & 1ull) && e.lane < lim;
         Pick pk; pk.slot = -1; pk.j = -1; pk.x = -1;
         if (mine) {
           uint32_t uu = u;
@@ -328,7 +324,8 @@ __device__ __forceinline__ void def_per_device(Env& e, const KP& P, int at, cons
         const uint32_t ft = mine ? fh[d] : 0u;
         const bool taint = mine && (ft & ~0xFFu) == epoch && (63u - (ft & 0x3Fu)) < (uint32_t)e.lane;
         const uint64_t tm = ballot(taint);
-        const int q0 = tm ? __builtin_ctzll(tm) : WAVE;
+        int q0 = tm ? __builtin_ctzll(tm) : WAVE;
+        if (q0 > lim) q0 = lim;
         const bool apply = mine && pk.slot >= 0 && e.lane < q0;
         if (apply) {
           pool_flip(q, multi, pk, d, o0, o1, want);
@@ -345,7 +342,7 @@ __device__ __forceinline__ void def_per_device(Env& e, const KP& P, int at, cons
       SUBSTAMP(11);
       SUBVAL(15, n_pass_all);
       SUBVAL(14, n_act);
-      SUBVAL(13, (simple ? 0 : 1) | (seq ? 2 : 0));
+      SUBVAL(13, (simple ? 0 : 1) | (xany ? 2 : 0));
     }
     cost += -0.5 * n_act * ds;
     fe[CG_D_DEF_COST] += 0.5 * n_act * ds;

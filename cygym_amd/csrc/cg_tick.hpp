@@ -11,7 +11,6 @@
 // instantiation (none of those buffers bound) carries none of that code.
 // Per-wave LDS carve + pointer table of one env (must match wave_lds_bytes on the host).
 // One lane per device PAIR: 12 floats = three 16-byte stores; static columns read as float2.
-#define PIN(x) asm volatile("" :: "v"(x))   // the value is complete here: its load cannot be sunk towards a later conditional use
 template <int GP>   // pairs per lane and step
 __device__ __forceinline__ void write_obs(const uint8_t* flags, const float* osv, const float* ver, const float* ano,
                                           float* obs, int M, int lane) {
@@ -104,9 +103,6 @@ template <int WPB, int MT, bool FUSED, bool XE, bool WIDE>
 #ifndef CG_OBS_GP0
 #define CG_OBS_GP0 4
 #endif
-#ifndef CG_PIN0
-#define CG_PIN0 1
-#endif
 #ifndef CG_LEAN_LB
 #define CG_LEAN_LB 6
 #endif
@@ -191,7 +187,45 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 &
   uint4 br[PF_BLOB];
 #pragma unroll
   for (int j = 0; j < PF_BLOB; ++j) { const int i = threadIdx.x + j * stride; br[j] = blob_src[i < n16 ? i : n16 - 1]; }
-  if (live) {
+  if constexpr (MT == 0) {
+    // straight-line: every load unconditional at a clamped (always valid) address, the per-lane state before the
+    // per-env scalars (loads return in order: the header's readfirstlane then waits for everything at once), the
+    // first exploit id fetched whether or not the action is a spread.  Waves past the end of the batch read env 0.
+    const int envc = live ? env : 0;
+    const int EW = P.t.EW;   // >= 1 (cygym_create)
+#pragma unroll
+    for (int j = 0; j < PF_LIVE; ++j) {
+      const int i = lane + j * WAVE;
+      if (vec) rl[j] = ((const uint4*)g_live)[i < items ? i : items - 1];   // (uniform condition; items >= 1 when vec)
+    }
+    ringw = ((const uint32_t*)(P.b.ring + (size_t)envc * CG_LOG_RING * 2))[lane < CG_LOG_RING ? lane : CG_LOG_RING - 1];
+    const uint32_t* gb0 = P.b.blocked + (size_t)envc * EW;
+    const uint32_t* gbi0 = P.b.blocked_in + (size_t)envc * EW;
+#pragma unroll
+    for (int j = 0; j < PF_BLK; ++j) { int w = lane + j * WAVE; w = w < EW ? w : EW - 1; bw[j] = gb0[w]; bwi[j] = gbi0[w]; }
+#pragma unroll
+    for (int j = 0; j < PF_DEV; ++j) { const int q = lane + j * WAVE; dv[j] = P.a.dev_idx[(size_t)envc * L + (q < L ? q : L - 1)]; }
+    if constexpr (!FUSED) {   // (the rollout kernel loads each tick's header at the top of its tick loop)
+      mode = P.a.mode[envc];
+      ng = P.a.n_groups[envc];
+      at0 = P.a.atype[(size_t)envc * G];
+      cnt0 = P.a.dev_cnt[(size_t)envc * G];
+      nexp0 = P.a.n_exploit[(size_t)envc * G];
+      app0 = P.a.app[(size_t)envc * G];
+      ex0 = P.a.exploit[(size_t)envc * G * CG_MAX_EXPLOITS];
+    }
+    const int32_t* g = P.b.ienv + (size_t)envc * CG_I_COUNT;
+#pragma unroll
+    for (int i = 0; i < CG_I_COUNT; ++i) ie[i] = g[i];
+    const double* gf = P.b.fenv + (size_t)envc * CG_D_COUNT;
+#pragma unroll
+    for (int i = 0; i < CG_D_COUNT; ++i) fe[i] = gf[i];
+#pragma unroll
+    for (int j = 0; j < PF_LIVE; ++j) KEEP4(rl[j]);
+#pragma unroll
+    for (int j = 0; j < PF_BLK; ++j) asm volatile("" :: "v"(bw[j]), "v"(bwi[j]));
+    asm volatile("" :: "v"(ringw), "v"((int)dv[0]));
+  } else if (live) {
     const int32_t* g = P.b.ienv + (size_t)env * CG_I_COUNT;
 #pragma unroll
     for (int i = 0; i < CG_I_COUNT; ++i) ie[i] = g[i];
@@ -218,17 +252,10 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 &
     }
 #pragma unroll
     for (int j = 0; j < PF_DEV; ++j) { int q = lane + j * WAVE; dv[j] = q < L ? P.a.dev_idx[(size_t)env * L + q] : (int16_t)0; }
-    if constexpr (MT == 0 && CG_PIN0) {
-#pragma unroll
-      for (int j = 0; j < PF_LIVE; ++j) KEEP4(rl[j]);
-#pragma unroll
-      for (int j = 0; j < PF_BLK; ++j) asm volatile("" :: "v"(bw[j]), "v"(bwi[j]));
-      asm volatile("" :: "v"(ringw), "v"((int)dv[0]));
-    }
   }
   // ---- workgroup-shared topology blob -> LDS ----
   {
-    if constexpr (MT == 0 && CG_PIN0) {
+    if constexpr (MT == 0) {
 #pragma unroll
       for (int j = 0; j < PF_BLOB; ++j) KEEP4(br[j]);
     }

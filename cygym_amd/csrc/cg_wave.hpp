@@ -4,6 +4,10 @@
 #define CG_WAVE_HPP
 
 // ---------------- wave-level helpers ----------------
+// The value is complete here: a load feeding it cannot be sunk towards a later conditional use.  Staged code (the
+// loads of a group first, then the work on them) relies on it: without the pin the compiler moves a load whose only
+// use is conditional into that branch, next to its s_waitcnt, and a group of independent LDS reads turns into a chain.
+#define PIN(x) asm volatile("" :: "v"(x))
 __device__ __forceinline__ void wsync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();

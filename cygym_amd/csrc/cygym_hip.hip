@@ -120,7 +120,14 @@ static const void* kernel_for(int wpb) {
     case 8: if constexpr (CG_HAS_WPB(8)) return (const void*)step_kernel<8, MT, FUSED, XE, WIDE>; else return nullptr;
     case 4: if constexpr (CG_HAS_WPB(4)) return (const void*)step_kernel<4, MT, FUSED, XE, WIDE>; else return nullptr;
     case 2: if constexpr (CG_HAS_WPB(2)) return (const void*)step_kernel<2, MT, FUSED, XE, WIDE>; else return nullptr;
-    default: if constexpr (CG_HAS_WPB(1)) return (const void*)step_kernel<1, MT, FUSED, XE, WIDE>; else return nullptr;
+    case 1: if constexpr (CG_HAS_WPB(1)) return (const void*)step_kernel<1, MT, FUSED, XE, WIDE>; else return nullptr;
+    // run-time sizes only: the shapes in between, for networks whose LDS footprint leaves room for 3, 5, 6 or 12 waves
+    // per CU but not the next power of two (2048 devices with an extra-edge list: 3 instead of 2)
+    case 12: if constexpr (MT == 0 && CG_HAS_WPB(12)) return (const void*)step_kernel<12, MT, FUSED, XE, WIDE>; else return nullptr;
+    case 6: if constexpr (MT == 0 && CG_HAS_WPB(6)) return (const void*)step_kernel<6, MT, FUSED, XE, WIDE>; else return nullptr;
+    case 5: if constexpr (MT == 0 && CG_HAS_WPB(5)) return (const void*)step_kernel<5, MT, FUSED, XE, WIDE>; else return nullptr;
+    case 3: if constexpr (MT == 0 && CG_HAS_WPB(3)) return (const void*)step_kernel<3, MT, FUSED, XE, WIDE>; else return nullptr;
+    default: return nullptr;
   }
 }
 template <bool FUSED, bool XE, bool WIDE>
@@ -181,8 +188,10 @@ static int choose_launch(cygym_handle* h, int max_devs) {
   // writer: they ride in LDS unless leaving them in the L2-resident blob buys more resident waves (M >= 1024).
   for (int floats = 1; floats >= 0; --floats) {
     const size_t shared = (size_t)(floats ? t.o_icol : t.o_os);
-    for (int wpb = 16; wpb >= 1; wpb >>= 1) {
+    static const int shapes[] = {16, 12, 8, 6, 5, 4, 3, 2, 1};
+    for (int wpb : shapes) {
       if (forced && wpb != forced) continue;
+      if ((wpb & (wpb - 1)) != 0 && (t.M == 64 || t.M == 256)) continue;   // the compile-time sizes come in powers of two only
       const size_t per_wg = shared + wave * wpb;
       if (per_wg > lds_cap) continue;
       int waves = (int)(lds_cap / per_wg) * wpb;

@@ -46,7 +46,8 @@ def parity(max_extra, detector, n=192, ticks=120, lam=0.0):
 
 def timing():
     dev = torch.device("cuda:0")
-    topo, init, ck = make_topology(M, blocks, seed=0, max_extra=0)
+    mx = int(os.environ.get("QUICK_MAX_EXTRA", "0"))   # -1: room for two attacker stars (the full-feature kernels)
+    topo, init, ck = make_topology(M, blocks, seed=0, max_extra=None if mx < 0 else mx)
     cfg = abi.EnvConfig(seed=0, auto_reset=1, lambda_events=0.0, **ck)
     env = BatchedCyberDefenseEnv(topo, cfg, N, init, device=dev, max_groups=1, max_devs=max(1, M // 8))
     W = 10
