@@ -18,7 +18,7 @@ def needs_build() -> bool:
     t = os.path.getmtime(SO)
     import glob
     deps = [SRC, os.path.join(INC, "cygym_abi.h"), os.path.join(INC, "cygym_spec.h")]
-    deps += glob.glob(os.path.join(os.path.dirname(SRC), "*.hpp"))   # the kernel sources included by SRC
+    deps += glob.glob(os.path.join(os.path.dirname(SRC), "*.hpp")) + glob.glob(os.path.join(os.path.dirname(SRC), "*.hip"))
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -44,21 +44,60 @@ def _parse_resources(text: str) -> dict:
     return out
 
 
+INST = os.path.join(HERE, "csrc", "cg_inst.hip")
+N_GROUPS = 8   # CG_INST_GROUPS of csrc/cg_device.hpp
+GROUP_MT = {0: 256, 1: 256, 2: 64, 3: 64, 4: 0, 5: 0, 6: 0, 7: 0}   # device-count class each instantiation group holds
+
+
+def build_to(so: str, resources: str | None = None, flags: list[str] | None = None, dev_mt: int | None = None,
+             verbose: bool = False, jobs: int | None = None) -> str:
+    """Compile the C-ABI unit and the instantiation units (csrc/cg_inst.hip, one per group of step_kernel variants)
+    in parallel, then link `so`.  dev_mt (development): only the groups of that device-count class (0, 64 or 256),
+    with -DCG_DEV_MT so that handles of the other classes fail at cygym_create."""
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    flags = list(flags or []) + os.environ.get("CYGYM_BUILD_FLAGS", "").split()
+    if dev_mt is not None:
+        flags.append(f"-DCG_DEV_MT={dev_mt}")
+    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INC, "-Rpass-analysis=kernel-resource-usage"] + flags
+    groups = [g for g in range(N_GROUPS) if dev_mt is None or GROUP_MT[g] == dev_mt]
+    jobs = jobs or int(os.environ.get("CYGYM_BUILD_JOBS", "0")) or min(len(groups) + 1, os.cpu_count() or 4)
+    with tempfile.TemporaryDirectory(prefix="cygym_build_") as tmp:
+        units = [("main", base + ["-c", SRC, "-o", os.path.join(tmp, "main.o")])]
+        units += [(f"inst{g}", base + [f"-DCG_INST_GROUP={g}", "-c", INST, "-o", os.path.join(tmp, f"inst{g}.o")]) for g in groups]
+
+        def run(unit):
+            name, cmd = unit
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if p.returncode != 0:
+                raise RuntimeError(f"hipcc failed on unit {name}:\n" + p.stdout[-4000:])
+            return p.stdout
+
+        with ThreadPoolExecutor(max_workers=jobs) as ex:
+            logs = list(ex.map(run, units))
+        objs = [u[1][-1] for u in units]
+        link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs
+        if verbose:
+            print(" ".join(link), flush=True)
+        p = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if p.returncode != 0:
+            raise RuntimeError("link failed:\n" + p.stdout[-4000:])
+    if resources:
+        res = {}
+        for text in logs:
+            res.update(_parse_resources(text))
+        with open(resources, "w") as f:
+            json.dump(res, f, indent=1, sort_keys=True)
+    return so
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return SO
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I" + INC, "-o", SO, SRC,
-           "-Rpass-analysis=kernel-resource-usage"]
-    cmd += os.environ.get("CYGYM_BUILD_FLAGS", "").split()   # development: e.g. -DCG_DEV_MT=256 -DCG_DEV_WPB=8
-    if verbose:
-        print(" ".join(cmd))
-    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    if p.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + p.stdout[-4000:])
-    with open(RESOURCES, "w") as f:
-        json.dump(_parse_resources(p.stdout), f, indent=1, sort_keys=True)
-    return SO
+    return build_to(SO, RESOURCES, verbose=verbose)
 
 
 if __name__ == "__main__":

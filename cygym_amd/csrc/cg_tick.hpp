@@ -566,7 +566,16 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 &
       for (int pl = 0; pl < 4; ++pl)
         for (int i = lane; i < M; i += WAVE) e.flags[pl * MS + i] = P.snap.live[ss + pl * M + i];
     }
-    for (int i = lane; i < 4 * M; i += WAVE) P.b.stash[so + i] = P.snap.stash[ss + i];
+    if (vec) {   // 16 bytes per lane and trip (byte by byte this copy was 128 dependent round trips at 2048 devices)
+      for (int i = lane; i < items; i += WAVE) ((uint4*)(P.b.stash + so))[i] = ((const uint4*)(P.snap.stash + ss))[i];
+    } else {
+      if (vec) {   // 16 bytes per lane and trip (byte by byte this copy was 128 dependent round trips at 2048 devices)
+#pragma nounroll
+      for (int i = lane; i < items; i += WAVE) ((uint4*)(P.b.stash + so))[i] = ((const uint4*)(P.snap.stash + ss))[i];
+    } else {
+      for (int i = lane; i < 4 * M; i += WAVE) P.b.stash[so + i] = P.snap.stash[ss + i];
+    }
+    }
     for (int w = lane; w < P.t.EW; w += WAVE) {
       e.blk[w] = P.snap.blocked[(size_t)si * P.t.EW + w];
       e.bin[w] = P.snap.blocked_in[(size_t)si * P.t.EW + w];

@@ -27,38 +27,16 @@
 //
 // Layout of the sources: this file holds the C ABI (host side); the device code lives in the cg_*.hpp
 // files next to it, included below inside one anonymous namespace, one file per phase of the tick.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <stdio.h>
-#include <string.h>
-#include <stdlib.h>
-#include <new>
-#include "cygym_abi.h"
+#define CG_MAIN_UNIT 1
+#include "cg_device.hpp"
+using namespace cygym_k;
 
-#ifndef CG_FUSED_LB
-#define CG_FUSED_LB 4   // rollout kernels: 4 waves per SIMD (128 VGPRs); see the tick-loop note in cg_tick.hpp
-#endif
-#ifndef CG_LB
-// Full-feature per-tick kernels: 4 waves per SIMD (128 VGPRs).  At 6 (80 VGPRs) they spilled 5-11 VGPRs on top of
-// ~150 SGPRs kept in VGPR lanes, and with the parameter block read through the laundered kernarg pointer that
-// combination miscompiled: a spilled SGPR pair (an f64 env accumulator) came back clobbered after the divergent
-// block / unblock code at run-time sizes (caught by every full-feature fixture test).  No VGPR spills, no problem.
-#define CG_LB 4
-#endif
-#define CG_E_STAR_OK 0x80  // kernel-private: star edges verified for the current owned set
-
-namespace {
-#include "cg_params.hpp"
-#include "cg_wave.hpp"
-#include "cg_env.hpp"
-#include "cg_extra_edges.hpp"
-#include "cg_defender.hpp"
-#include "cg_attacker.hpp"
-#include "cg_arrivals.hpp"
-#include "cg_evolve.hpp"
-#include "cg_tick.hpp"
-#include "cg_aux_kernels.hpp"
-}  // namespace
+// every step_kernel variant lives in one of the instantiation units (cg_inst.hip): declared, not instantiated, here
+namespace cygym_k {
+#define CG_DECL(W, M, F, X, WD, G) extern template __global__ void step_kernel<W, M, F, X, WD>(const KParams);
+CG_STEP_KERNELS(CG_DECL)
+#undef CG_DECL
+}  // namespace cygym_k
 
 // =====================================================================
 // C ABI
@@ -96,19 +74,6 @@ static int fail(cygym_handle* h, int code, const char* fmt, const char* detail) 
     if (_e != hipSuccess) return fail(h, CYGYM_EHIP, #call ": %s", hipGetErrorString(_e)); \
   } while (0)
 
-// Development aid (never set by cygym_amd/build.py's default build): -DCG_DEV_MT=<0|64|256> compiles only the
-// instantiations of that size (and -DCG_DEV_WPB=<n> only that workgroup shape) -- a 10x shorter edit-compile-measure
-// loop.  Handles of any other shape fail at cygym_create.
-#ifdef CG_DEV_MT
-#define CG_HAS_MT(m) ((m) == CG_DEV_MT)
-#else
-#define CG_HAS_MT(m) 1
-#endif
-#ifdef CG_DEV_WPB
-#define CG_HAS_WPB(w) ((w) == CG_DEV_WPB)
-#else
-#define CG_HAS_WPB(w) 1
-#endif
 template <int MT, bool FUSED, bool XE, bool WIDE>
 static const void* kernel_for(int wpb) {
   if constexpr (!CG_HAS_MT(MT)) return nullptr;
