@@ -163,6 +163,15 @@ def run_workload(D: Dist, name, n_per_gpu, K, W, reps, sub, fused_T, seed, max_e
         act = {k: torch.empty_like(v) for k, v in env.act.items()}
         env.gen_actions(t, act)
         scripts.append(act)
+    # clock ramp: a quarter of a second of untimed stepping first (a workload that follows an idle stretch -- the CPU
+    # baseline, a process start -- otherwise runs its few hundred microseconds of timed region at idle clocks: the
+    # short cfg2 legs came out up to 2x low), then back to the initial state
+    t_end = time.perf_counter() + 0.25
+    while time.perf_counter() < t_end:
+        for t in range(W + K):
+            env.step(scripts[t])
+        torch.cuda.synchronize(dev)
+    env.load_state(init)
     for t in range(W):
         env.step(scripts[t])
     torch.cuda.synchronize(dev)
@@ -266,7 +275,8 @@ def attach_traffic(rec, name, n_envs):
         return
     try:
         c = json.load(open(pmc)).get(name)
-        if not c or c.get("envs_per_launch") != n_envs:
+        # (the summary counts WAVES per launch: the env count rounded up to whole workgroups of up to 16 waves)
+        if not c or not (n_envs <= c.get("envs_per_launch", -1) < n_envs + 16):
             return
         for leg, key in ((rec["per_tick_stepping"], "per_tick"), (rec["fused_rollout"], "fused")):
             if leg is None or key not in c:

@@ -1,5 +1,5 @@
 // cg_arrivals.hpp -- Workload arrivals (volt_typhoon_env.py:575-596, CDSimulator.py:244-348).
-// Part of cygym_hip.hip (included inside its anonymous namespace, in order); not a standalone header.
+// Part of the device code gathered by cg_device.hpp (included inside namespace cygym_k, in order); not a standalone header.
 #ifndef CG_ARRIVALS_HPP
 #define CG_ARRIVALS_HPP
 

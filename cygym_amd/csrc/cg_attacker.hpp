@@ -1,5 +1,5 @@
 // cg_attacker.hpp -- Attacker actions: spread fix point and probe (volt_typhoon_env.py:1126-1202).
-// Part of cygym_hip.hip (included inside its anonymous namespace, in order); not a standalone header.
+// Part of the device code gathered by cg_device.hpp (included inside namespace cygym_k, in order); not a standalone header.
 #ifndef CG_ATTACKER_HPP
 #define CG_ATTACKER_HPP
 

@@ -1,5 +1,5 @@
 // cg_aux_kernels.hpp -- reset / randomize / derive / observe kernels and the synthetic action script of bench.py.
-// Part of cygym_hip.hip (included inside its anonymous namespace, in order); not a standalone header.
+// Part of the device code gathered by cg_device.hpp (included inside namespace cygym_k, in order); not a standalone header.
 #ifndef CG_AUX_KERNELS_HPP
 #define CG_AUX_KERNELS_HPP
 

@@ -1,5 +1,5 @@
 // cg_defender.hpp -- Defender actions (volt_typhoon_env.py:918-1123).
-// Part of cygym_hip.hip (included inside its anonymous namespace, in order); not a standalone header.
+// Part of the device code gathered by cg_device.hpp (included inside namespace cygym_k, in order); not a standalone header.
 #ifndef CG_DEFENDER_HPP
 #define CG_DEFENDER_HPP
 

@@ -1,5 +1,5 @@
 // cg_env.hpp -- Per-wave view of one environment in LDS and the list / bit-range helpers shared by the actions.
-// Part of cygym_hip.hip (included inside its anonymous namespace, in order); not a standalone header.
+// Part of the device code gathered by cg_device.hpp (included inside namespace cygym_k, in order); not a standalone header.
 #ifndef CG_ENV_HPP
 #define CG_ENV_HPP
 

@@ -1,5 +1,5 @@
 // cg_evolve.hpp -- evolve_network (CyberDefenseEnv.py:583-875).
-// Part of cygym_hip.hip (included inside its anonymous namespace, in order); not a standalone header.
+// Part of the device code gathered by cg_device.hpp (included inside namespace cygym_k, in order); not a standalone header.
 #ifndef CG_EVOLVE_HPP
 #define CG_EVOLVE_HPP
 

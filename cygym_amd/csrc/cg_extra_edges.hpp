@@ -1,5 +1,5 @@
 // cg_extra_edges.hpp -- Edges added by evolve_network: the per-env extra-edge list and the merged-row walk.
-// Part of cygym_hip.hip (included inside its anonymous namespace, in order); not a standalone header.
+// Part of the device code gathered by cg_device.hpp (included inside namespace cygym_k, in order); not a standalone header.
 #ifndef CG_EXTRA_EDGES_HPP
 #define CG_EXTRA_EDGES_HPP
 

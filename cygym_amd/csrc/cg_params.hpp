@@ -1,5 +1,5 @@
 // cg_params.hpp -- Device-side parameter blocks (topology blob layout, kernel parameters) and the diagnostic stamp macros.
-// Part of cygym_hip.hip (included inside its anonymous namespace, in order); not a standalone header.
+// Part of the device code gathered by cg_device.hpp (included inside namespace cygym_k, in order); not a standalone header.
 #ifndef CG_PARAMS_HPP
 #define CG_PARAMS_HPP
 

@@ -1,5 +1,5 @@
 // cg_tick.hpp -- The tick kernel: step_kernel<WPB, MT, FUSED, XE> (volt_typhoon_env.py:818-1333, 612-779).
-// Part of cygym_hip.hip (included inside its anonymous namespace, in order); not a standalone header.
+// Part of the device code gathered by cg_device.hpp (included inside namespace cygym_k, in order); not a standalone header.
 #ifndef CG_TICK_HPP
 #define CG_TICK_HPP
 

@@ -1,5 +1,5 @@
 // cg_wave.hpp -- Wave-level helpers: wave-scope sync, ballots, small reductions, SWAR on byte planes.
-// Part of cygym_hip.hip (included inside its anonymous namespace, in order); not a standalone header.
+// Part of the device code gathered by cg_device.hpp (included inside namespace cygym_k, in order); not a standalone header.
 #ifndef CG_WAVE_HPP
 #define CG_WAVE_HPP
 

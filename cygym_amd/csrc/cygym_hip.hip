@@ -25,8 +25,10 @@
 //
 // Reference citations are relative to the reference checkout.
 //
-// Layout of the sources: this file holds the C ABI (host side); the device code lives in the cg_*.hpp
-// files next to it, included below inside one anonymous namespace, one file per phase of the tick.
+// Layout of the sources: this file holds the C ABI (host side) and the small auxiliary kernels; the device code lives
+// in the cg_*.hpp files next to it (one file per phase of the tick), gathered by cg_device.hpp in namespace cygym_k.
+// The step_kernel variants are compiled in the instantiation units (cg_inst.hip, one object per CG_INST_GROUP) and
+// only declared here.
 #define CG_MAIN_UNIT 1
 #include "cg_device.hpp"
 using namespace cygym_k;
