@@ -162,7 +162,8 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
   const int M = e.M, MC = e.MC, Mp = MC * WAVE;
   uint32_t* T = e.scr;                          // [Mp] first-compromise time (source id + 1)
   uint16_t* cur = (uint16_t*)(e.scr + Mp);      // [Mp] current pick (slot) per source DEVICE, row end = none
-  uint16_t* cntv = cur + Mp;                    // [Mp] log entries per COMPACT source index
+  uint16_t* cntv = (uint16_t*)T;                // [Mp] log entries per COMPACT source index: reuses T, which is applied
+                                                //      to the flags right after the sweeps (4 KB less LDS per 2048-device env)
   uint16_t* slist = e.lsrc;                     // [Mp] the sources in id order (snapshot :1127)
   uint64_t* cand = (uint64_t*)e.marks;          // [MC] candidate-device bitmask for full rows
   int n_src = 0;
@@ -329,6 +330,19 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
     }
     SUBSTAMP(11);
     SUBVAL(15, n_rounds);
+    // apply the compromise flags (:1163-1185) now: T is dead from here on (cntv reuses its storage)
+#pragma nounroll
+    for (int c0 = 0; c0 < MC; c0 += GS) {
+      uint32_t tj[GS], fj[GS];
+#pragma unroll
+      for (int j = 0; j < GS; ++j) { const int d = (c0 + j) * WAVE + e.lane, dc = d < M ? d : 0; tj[j] = T[dc]; fj[j] = e.flags[dc]; }
+#pragma unroll
+      for (int j = 0; j < GS; ++j) {
+        const int d = (c0 + j) * WAVE + e.lane;
+        if (d < M && (tj[j] >> 2) != T_TIME_INF && (tj[j] >> 2) != 0u) e.flags[d] = (uint8_t)(fj[j] | CG_F_COMP);
+      }
+    }
+    wsync();
     // log entries of every source: unblocked out-entries up to and including its pick
     int total_new = 0;
     for (int b0 = 0; b0 < n_src; b0 += WAVE) {
@@ -424,18 +438,7 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
     }
     wsync();
     SUBSTAMP(13);
-    // apply: compromise flags + DC attribution (:1163-1185)
-#pragma nounroll
-    for (int c0 = 0; c0 < MC; c0 += GS) {
-      uint32_t tj[GS], fj[GS];
-#pragma unroll
-      for (int j = 0; j < GS; ++j) { const int d = (c0 + j) * WAVE + e.lane, dc = d < M ? d : 0; tj[j] = T[dc]; fj[j] = e.flags[dc]; }
-#pragma unroll
-      for (int j = 0; j < GS; ++j) {
-        const int d = (c0 + j) * WAVE + e.lane;
-        if (d < M && (tj[j] >> 2) != T_TIME_INF && (tj[j] >> 2) != 0u) e.flags[d] = (uint8_t)(fj[j] | CG_F_COMP);
-      }
-    }
+    // DC attribution (:1163-1185)
     for (int i = e.lane; i < n_src; i += WAVE) {
       int s = slist[i];
       if (!(e.dst[s] & CG_D_DC)) continue;

@@ -62,7 +62,7 @@ __device__ __forceinline__ WaveAux env_setup(Env& e, uint8_t* smem, const KP& P,
   uint8_t* wb = smem + P.shared_lds + (size_t)wave * P.wave_lds;
   e.flags = wb; e.busy = wb + MS; e.wl = wb + 2 * MS; e.cby = wb + 3 * MS;
   e.scr = (uint32_t*)(wb + ((4 * MS + 15) & ~15));
-  e.blk = e.scr + 2 * Mp;
+  e.blk = e.scr + Mp + Mp / 2;   // scratch: [Mp] words + [Mp] halfwords (must match wave_lds_bytes on the host)
   e.bin = e.blk + ((P.t.EW + 3) & ~3);
   e.ring = (uint16_t*)(e.bin + ((P.t.EW + 3) & ~3));
   e.marks = (uint32_t*)(e.ring + 2 * CG_LOG_RING);
