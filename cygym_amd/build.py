@@ -79,7 +79,8 @@ def build_to(so: str, resources: str | None = None, flags: list[str] | None = No
         with ThreadPoolExecutor(max_workers=jobs) as ex:
             logs = list(ex.map(run, units))
         objs = [u[1][-1] for u in units]
-        link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs
+        link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-z,defs", "-o", so] + objs   # -z defs: a kernel variant
+        # declared in the C-ABI unit but missing from every instantiation group fails the build, not the first dlopen
         if verbose:
             print(" ".join(link), flush=True)
         p = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

@@ -163,6 +163,13 @@ static int choose_launch(cygym_handle* h, int max_devs) {
       if (per_wg > lds_cap) continue;
       int waves = (int)(lds_cap / per_wg) * wpb;
       if (waves > 32) waves = 32;
+      // ... of which the register file keeps this many resident (whole workgroups): the lean per-tick kernel at a
+      // compile-time size is built for 6 waves per SIMD in workgroups of 2-8 waves and 5 otherwise, everything else
+      // for 4 (launch bounds of step_kernel).  Without this a 16-wave shape that LDS would hold twice won over three
+      // 8-wave workgroups although only one of the two ever runs (16384 x 256: -11 %).
+      const bool ct_lean = (t.M == 64 || t.M == 256) && t.K == 0;
+      const int reg_cap = ct_lean ? ((wpb > 1 && wpb <= 8) ? 24 : 20) : 16;
+      if (waves > reg_cap / wpb * wpb) waves = reg_cap / wpb * wpb;
       // ties: two 8-wave workgroups per CU beat one 16-wave workgroup (their phases interleave)
       const bool better = waves > best_waves || (waves == best_waves && floats == best_floats && wpb == 8);
       if (better) { best_waves = waves; best = wpb; best_floats = floats; }
