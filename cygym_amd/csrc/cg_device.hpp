@@ -39,18 +39,13 @@ namespace cygym_k {
 #endif
 }  // namespace cygym_k
 
-// Development aid (never set by cygym_amd/build.py's default build): -DCG_DEV_MT=<0|64|256> compiles only the
-// instantiations of that size (and -DCG_DEV_WPB=<n> only that workgroup shape) -- a 10x shorter edit-compile-measure
-// loop.  Handles of any other shape fail at cygym_create.
+// Development aid (cygym_amd/build.py build_to(dev_mt=...), tools/devbuild.py): -DCG_DEV_MT=<0|64|256> keeps only the
+// kernels of that device-count class (build.py then compiles only their instantiation groups).  Handles of any other
+// class fail at cygym_create.
 #ifdef CG_DEV_MT
 #define CG_HAS_MT(m) ((m) == CG_DEV_MT)
 #else
 #define CG_HAS_MT(m) 1
-#endif
-#ifdef CG_DEV_WPB
-#define CG_HAS_WPB(w) ((w) == CG_DEV_WPB)
-#else
-#define CG_HAS_WPB(w) 1
 #endif
 
 // The instantiation table: CG_STEP_KERNELS(X) expands X(WPB, MT, FUSED, XE, WIDE, GROUP) for every variant the library

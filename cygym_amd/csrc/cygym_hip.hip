@@ -80,20 +80,20 @@ template <int MT, bool FUSED, bool XE, bool WIDE>
 static const void* kernel_for(int wpb) {
   if constexpr (!CG_HAS_MT(MT)) return nullptr;
   else if constexpr (WIDE) {   // the WIDE kernel only ever runs as one 16-wave workgroup per CU (choose_launch)
-    if constexpr (CG_HAS_WPB(16)) return wpb == 16 ? (const void*)step_kernel<16, MT, FUSED, XE, WIDE> : nullptr; else return nullptr;
+    return wpb == 16 ? (const void*)step_kernel<16, MT, FUSED, XE, WIDE> : nullptr;
   } else
   switch (wpb) {
-    case 16: if constexpr (CG_HAS_WPB(16)) return (const void*)step_kernel<16, MT, FUSED, XE, WIDE>; else return nullptr;
-    case 8: if constexpr (CG_HAS_WPB(8)) return (const void*)step_kernel<8, MT, FUSED, XE, WIDE>; else return nullptr;
-    case 4: if constexpr (CG_HAS_WPB(4)) return (const void*)step_kernel<4, MT, FUSED, XE, WIDE>; else return nullptr;
-    case 2: if constexpr (CG_HAS_WPB(2)) return (const void*)step_kernel<2, MT, FUSED, XE, WIDE>; else return nullptr;
-    case 1: if constexpr (CG_HAS_WPB(1)) return (const void*)step_kernel<1, MT, FUSED, XE, WIDE>; else return nullptr;
+    case 16: return (const void*)step_kernel<16, MT, FUSED, XE, WIDE>;
+    case 8: return (const void*)step_kernel<8, MT, FUSED, XE, WIDE>;
+    case 4: return (const void*)step_kernel<4, MT, FUSED, XE, WIDE>;
+    case 2: return (const void*)step_kernel<2, MT, FUSED, XE, WIDE>;
+    case 1: return (const void*)step_kernel<1, MT, FUSED, XE, WIDE>;
     // run-time sizes only: the shapes in between, for networks whose LDS footprint leaves room for 3, 5, 6 or 12 waves
     // per CU but not the next power of two (2048 devices with an extra-edge list: 3 instead of 2)
-    case 12: if constexpr (MT == 0 && CG_HAS_WPB(12)) return (const void*)step_kernel<12, MT, FUSED, XE, WIDE>; else return nullptr;
-    case 6: if constexpr (MT == 0 && CG_HAS_WPB(6)) return (const void*)step_kernel<6, MT, FUSED, XE, WIDE>; else return nullptr;
-    case 5: if constexpr (MT == 0 && CG_HAS_WPB(5)) return (const void*)step_kernel<5, MT, FUSED, XE, WIDE>; else return nullptr;
-    case 3: if constexpr (MT == 0 && CG_HAS_WPB(3)) return (const void*)step_kernel<3, MT, FUSED, XE, WIDE>; else return nullptr;
+    case 12: if constexpr (MT == 0) return (const void*)step_kernel<12, MT, FUSED, XE, WIDE>; else return nullptr;
+    case 6: if constexpr (MT == 0) return (const void*)step_kernel<6, MT, FUSED, XE, WIDE>; else return nullptr;
+    case 5: if constexpr (MT == 0) return (const void*)step_kernel<5, MT, FUSED, XE, WIDE>; else return nullptr;
+    case 3: if constexpr (MT == 0) return (const void*)step_kernel<3, MT, FUSED, XE, WIDE>; else return nullptr;
     default: return nullptr;
   }
 }
@@ -120,7 +120,7 @@ static hipError_t set_lds_attr(cygym_handle* h) {   // every instantiation this 
   for (int full = (h->t.K > 0 ? 1 : 0); full < 2; ++full)
     for (int fused = 0; fused < 2; ++fused) {
       const void* k = pick_kernel(h, fused != 0, full);
-      if (!k) return hipErrorInvalidDeviceFunction;   // development subset build (CG_DEV_MT / CG_DEV_WPB)
+      if (!k) return hipErrorInvalidDeviceFunction;   // development subset build (CG_DEV_MT)
       hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       if (e != hipSuccess) return e;
     }

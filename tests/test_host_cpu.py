@@ -247,8 +247,8 @@ def test_profile_summary_parser(tmp_path):
     d = tmp_path / "w" / "pmc_write" / "run"
     d.mkdir(parents=True)
     rows = ['"Correlation_Id","Dispatch_Id","Kernel_Name","Grid_Size","Counter_Name","Counter_Value"']
-    tick = "void (anonymous namespace)::step_kernel<8, 256, false, false, true>((anonymous namespace)::KParams)"
-    roll = "void (anonymous namespace)::step_kernel<8, 256, true, false, false>((anonymous namespace)::KParams)"
+    tick = "void cygym_k::step_kernel<8, 256, false, false, true>(cygym_k::KParams)"
+    roll = "void cygym_k::step_kernel<8, 256, true, false, false>(cygym_k::KParams)"
     for disp, name, grid, vals in ((1, tick, 4096 * 64, (10.0, 30.0)), (2, tick, 4096 * 64, (20.0, 20.0)), (5, tick, 1024 * 64, (1.0, 1.0)),
                                    (3, roll, 4096 * 64, (1000.0, 1000.0)), (4, "other_kernel", 64, (5.0, 5.0))):
         for v in vals:   # two rows per dispatch (e.g. per XCD): summed
