@@ -304,6 +304,9 @@ __device__ __forceinline__ void def_per_device(Env& e, const KP& P, int at, cons
             if ((xm >> first) & 1ull) {   // next in list order: alone, on the bitmasks every earlier entry has left
               block_one(e, q, __builtin_amdgcn_readlane(d, first), want, site, simple ? nullptr : occ, n_hit);
               am &= am - 1; xm &= xm - 1;
+              // (the per-lane row bounds are re-read rather than kept in registers across the cooperative pick)
+              asm volatile("" : "+v"(d));
+              if (d >= 0) { o0 = e.optr[d]; o1 = e.optr[d + 1]; i0 = e.iptr(d); i1 = e.iptr(d + 1); }
               continue;
             }
             lim = __builtin_ctzll(xm);
