@@ -349,6 +349,50 @@ def test_differential_fuzz_sample(monkeypatch):
     fuzz.main()   # exits non-zero (SystemExit) on the first mismatch
 
 
+@pytest.mark.parametrize("wpb", [1, 2, 3, 4, 5, 6, 8, 12, 16])
+def test_every_workgroup_shape_at_a_run_time_size(wpb, monkeypatch):
+    """cygym_create picks the waves-per-workgroup shape from the LDS and register budgets, so a given network only ever
+    exercises one of the nine shapes compiled for run-time sizes: force each (CYGYM_WPB, the tuning hook of
+    choose_launch) and check lean and full-feature kernels, per tick and as a rollout, against the oracle."""
+    from oracle import driver as od
+    monkeypatch.setenv("CYGYM_WPB", str(wpb))
+    M, N, T = 100, 50, 36   # N is no multiple of any shape above 2: the last workgroup carries idle waves
+    for max_extra, lam in ((0, 0.0), (48, 1.4)):
+        topo, init, ck = make_topology(M, 2, seed=11, n_active=90, max_extra=max_extra)
+        if lam:
+            ck.update(dict(lambda_events=lam, p_add=0.45, p_attacker=0.1, num_of_device=30, min_network_size=2))
+        cfg = abi.EnvConfig(seed=11, env_id_base=5, **ck)
+        L = 12
+        env = _env(topo, cfg, N, init, max_groups=1, max_devs=L)
+        ob = od.OracleBatch(topo, cfg, N)
+        ob.load_state(init)
+        if lam:
+            env.randomize(); ob.randomize()
+        start = {k: v.clone() for k, v in env.state.items()}
+        for t in range(T):
+            env.gen_actions(t)
+            act = gen_actions_numpy(cfg.seed, cfg.env_id_base, N, M, topo.X, t, L)
+            obs, raw, shaped, done = env.step()
+            o = ob.step(act)
+            np.testing.assert_array_equal(obs.cpu().numpy(), o[0], err_msg=f"obs wpb={wpb} t={t}")
+            np.testing.assert_allclose(raw.cpu().numpy(), o[1], rtol=0, atol=1e-9, err_msg=f"raw wpb={wpb} t={t}")
+        got = env.state_numpy()
+        got["ienv"] = got["ienv"].copy(); got["ienv"][:, S.I_FLAGS] &= ~0x80
+        bad = gio.compare_state(got, ob.state, f"wpb={wpb} K={max_extra}")
+        assert not bad, "\n".join(bad[:8])
+        # the same script as ONE rollout launch from the same start
+        for k, v in start.items():
+            env.state[k].copy_(v)
+        a, out = env.alloc_rollout(T)
+        env.gen_actions_rollout(0, a)
+        env.rollout(a, out)
+        got = env.state_numpy()
+        got["ienv"] = got["ienv"].copy(); got["ienv"][:, S.I_FLAGS] &= ~0x80
+        bad = gio.compare_state(got, ob.state, f"rollout wpb={wpb} K={max_extra}")
+        assert not bad, "\n".join(bad[:8])
+        env.close()
+
+
 def test_long_device_lists_replan_the_launch():
     """Device lists as long as the network (max_devs = M, longer than the M/8 the handle was created for): the library
     re-plans its LDS layout at the first step (cygym_step: max_devs > planned) -- also for the WIDE per-tick kernel, which
