@@ -349,18 +349,19 @@ def test_differential_fuzz_sample(monkeypatch):
     fuzz.main()   # exits non-zero (SystemExit) on the first mismatch
 
 
-@pytest.mark.parametrize("wpb", [1, 2, 3, 4, 5, 6, 8, 12, 16])
-def test_every_workgroup_shape_at_a_run_time_size(wpb, monkeypatch):
+@pytest.mark.parametrize("M,wpb", [(100, w) for w in (1, 2, 3, 4, 5, 6, 8, 12, 16)] + [(m, w) for m in (64, 256) for w in (1, 2, 4, 8, 16)])
+def test_every_workgroup_shape(M, wpb, monkeypatch):
     """cygym_create picks the waves-per-workgroup shape from the LDS and register budgets, so a given network only ever
-    exercises one of the nine shapes compiled for run-time sizes: force each (CYGYM_WPB, the tuning hook of
-    choose_launch) and check lean and full-feature kernels, per tick and as a rollout, against the oracle."""
+    exercises one of the shapes compiled for its size class (nine at run-time sizes, five at 64 and 256 devices): force
+    each (CYGYM_WPB, the tuning hook of choose_launch) and check lean and full-feature kernels, per tick and as a
+    rollout, against the oracle."""
     from oracle import driver as od
     monkeypatch.setenv("CYGYM_WPB", str(wpb))
-    M, N, T = 100, 50, 36   # N is no multiple of any shape above 2: the last workgroup carries idle waves
+    N, T = 50, 36   # N is no multiple of any shape above 2: the last workgroup carries idle waves
     for max_extra, lam in ((0, 0.0), (48, 1.4)):
-        topo, init, ck = make_topology(M, 2, seed=11, n_active=90, max_extra=max_extra)
+        topo, init, ck = make_topology(M, 2 if M != 256 else 1, seed=11, n_active=(M * 9) // 10, max_extra=max_extra)
         if lam:
-            ck.update(dict(lambda_events=lam, p_add=0.45, p_attacker=0.1, num_of_device=30, min_network_size=2))
+            ck.update(dict(lambda_events=lam, p_add=0.45, p_attacker=0.1, num_of_device=max(2, M // 3), min_network_size=2))
         cfg = abi.EnvConfig(seed=11, env_id_base=5, **ck)
         L = 12
         env = _env(topo, cfg, N, init, max_groups=1, max_devs=L)
