@@ -53,6 +53,7 @@ struct cygym_handle {
   bool bound, has_snap;
   void* dev_blob;       // one allocation holding the topology copies (+ the detector's leaf-term table)
   int wpb, max_devs;
+  int wpb_fused;        // shape of the rollout kernels (register-capped at 16 waves per CU: a single 16-wave workgroup where it fits)
   bool few_waves;       // n_envs <= 16 per CU: one wave per env cannot use more than 4 waves per SIMD
   bool wide;            // the WIDE per-tick kernel runs: one 16-wave workgroup per CU with the WHOLE blob (in-CSR maps too) in LDS
   int o_maps_end;       // blob offset just past the in-CSR maps
@@ -99,9 +100,10 @@ static const void* kernel_for(int wpb) {
 }
 template <bool FUSED, bool XE, bool WIDE>
 static const void* kernel_for_m(const cygym_handle* h) {
-  if (h->t.M == 256) return kernel_for<256, FUSED, XE, WIDE>(h->wpb);
-  if (h->t.M == 64) return kernel_for<64, FUSED, XE, false>(h->wpb);   // rows of <= 3 words: nothing to gain (measured: -9 %)
-  return kernel_for<0, FUSED, XE, false>(h->wpb);   // run-time M: the wide variant would spill
+  const int wpb = FUSED ? h->wpb_fused : h->wpb;
+  if (h->t.M == 256) return kernel_for<256, FUSED, XE, WIDE>(wpb);
+  if (h->t.M == 64) return kernel_for<64, FUSED, XE, false>(wpb);   // rows of <= 3 words: nothing to gain (measured: -9 %)
+  return kernel_for<0, FUSED, XE, false>(wpb);   // run-time M: the wide variant would spill
 }
 // XE: the kernel that follows the edges evolve_network adds (max_extra_edges > 0).  With no extra-edge list
 // the lean instantiation runs: none of that code is in it.
@@ -116,9 +118,9 @@ static const void* pick_kernel(const cygym_handle* h, bool fused, int full = -1)
   return h->wide ? kernel_for_m<false, false, true>(h) : kernel_for_m<false, false, false>(h);
 }
 static hipError_t set_lds_attr(cygym_handle* h) {   // every instantiation this handle may launch (lean and full-feature)
-  const int lds = h->shared_lds + h->wave_lds * h->wpb;
   for (int full = (h->t.K > 0 ? 1 : 0); full < 2; ++full)
     for (int fused = 0; fused < 2; ++fused) {
+      const int lds = h->shared_lds + h->wave_lds * (fused ? h->wpb_fused : h->wpb);
       const void* k = pick_kernel(h, fused != 0, full);
       if (!k) return hipErrorInvalidDeviceFunction;   // development subset build (CG_DEV_MT)
       hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -178,6 +180,10 @@ static int choose_launch(cygym_handle* h, int max_devs) {
   if (!best) return -1;
   const size_t shared = (size_t)(best_floats ? t.o_icol : t.o_os);
   h->wpb = best; h->wave_lds = (int)wave; h->shared_lds = (int)shared;
+  // The rollout kernels are built for 4 waves per SIMD whatever the size: 16 resident waves per CU at most, and one
+  // 16-wave workgroup measured 4 % faster than two of 8 (16384 x 256).  Otherwise they share the per-tick shape.
+  h->wpb_fused = best;
+  if (!forced && (t.M == 64 || t.M == 256) && best < 16 && shared + wave * 16 <= lds_cap) h->wpb_fused = 16;
   t.lds_bytes = (int)shared; t.in_lds = best_floats;   // in_lds: the float columns are staged too
   h->max_devs = max_devs;
   // Few envs per CU (<= 16: every env has its own resident wave and a launch lasts as long as its slowest env, which
@@ -186,7 +192,7 @@ static int choose_launch(cygym_handle* h, int max_devs) {
   h->wide = false;
   if (h->few_waves && t.M == 256 && t.K == 0 && !forced && (size_t)h->o_maps_end + wave * 16 <= lds_cap) {
     h->wide = true;
-    h->wpb = 16; h->shared_lds = h->o_maps_end;
+    h->wpb = 16; h->wpb_fused = 16; h->shared_lds = h->o_maps_end;
     t.lds_bytes = h->o_maps_end; t.in_lds = 1;
   }
   return 0;
@@ -439,8 +445,9 @@ static int launch_ticks(cygym_handle* h, int32_t n_ticks, int32_t env_begin, int
   // segment): nothing is uploaded or shared between launches, so launches of one handle on different streams
   // are independent as long as their env ranges are disjoint.  hipGetLastError below reports launch-time errors;
   // a fault inside the kernel surfaces at the caller's next synchronisation.
-  const int lds = h->shared_lds + h->wave_lds * h->wpb;
-  const dim3 grid((n + h->wpb - 1) / h->wpb), block(h->wpb * WAVE);
+  const int wpb = n_ticks > 1 ? h->wpb_fused : h->wpb;
+  const int lds = h->shared_lds + h->wave_lds * wpb;
+  const dim3 grid((n + wpb - 1) / wpb), block(wpb * WAVE);
   hipStream_t s = (hipStream_t)stream;
   {
     void* args[] = {(void*)&P};
