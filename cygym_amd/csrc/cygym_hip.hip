@@ -169,8 +169,10 @@ static int choose_launch(cygym_handle* h, int max_devs) {
       // compile-time size is built for 6 waves per SIMD in workgroups of 2-8 waves and 5 otherwise, everything else
       // for 4 (launch bounds of step_kernel).  Without this a 16-wave shape that LDS would hold twice won over three
       // 8-wave workgroups although only one of the two ever runs (16384 x 256: -11 %).
-      const bool ct_lean = (t.M == 64 || t.M == 256) && t.K == 0;
-      const int reg_cap = ct_lean ? ((wpb > 1 && wpb <= 8) ? 24 : 20) : 16;
+      const bool ct = t.M == 64 || t.M == 256, ct_lean = ct && t.K == 0;
+      // (the full-feature per-tick kernels at a compile-time size need <= 102 VGPRs: 5 waves per SIMD;
+      // tests/test_host_cpu.py holds them to that)
+      const int reg_cap = ct_lean ? ((wpb > 1 && wpb <= 8) ? 24 : 20) : (ct ? 20 : 16);
       if (waves > reg_cap / wpb * wpb) waves = reg_cap / wpb * wpb;
       // ties: two 8-wave workgroups per CU beat one 16-wave workgroup (their phases interleave)
       const bool better = waves > best_waves || (waves == best_waves && floats == best_floats && wpb == 8);

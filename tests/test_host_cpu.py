@@ -163,6 +163,8 @@ def test_tick_kernels_do_not_spill():
         # instructions), so the size alone is not a spill.
         assert r.get("vgpr_spill", 0) == 0 and r["scratch"] <= 64, (name, r)
         assert r["vgprs"] <= (132 if mt == 0 and not fused and not xe else 128), (name, r)
+        if mt and xe and not fused:       # choose_launch counts on 5 resident waves per SIMD for these
+            assert r["vgprs"] <= 102, (name, r)
         if mt and not fused and not xe:   # lean per-tick kernel at a compile-time size: parameters are read next to
             assert r["sgpr_spill"] <= 128, (name, r)   # their uses (laundered kernarg pointer), few SGPRs spill
     assert seen == {(False, False), (False, True), (True, False), (True, True)}
