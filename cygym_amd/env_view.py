@@ -249,13 +249,20 @@ class CyberDefenseEnvView:
         return info
 
     def _logs(self):
+        """The tail of `simulator.logger.logs` (CDSimulator.py:667-676): the last 32 entries, or the last 2048 when the
+        batch keeps the long history (detector=True).  `time_step` is `simulator.system_time`, which only the base
+        class's `step` advances (CyberDefenseEnv.py:408) -- on this path it stays 0; every entry is of kind 'A'
+        (volt_typhoon_env.py:1161)."""
         ie = self._b.state["ienv"][self._i]
         total = int(ie[S.I_LOG_TOTAL].item())
-        ring = self._b.state["ring"][self._i].cpu().numpy().view(np.uint16).reshape(S.LOG_RING, 2)
-        n = min(total, S.LOG_RING)
+        if getattr(self._b, "detector", False) and self._b.state["hist"].numel() > 0:
+            cap, ring = S.HIST_RING, self._b.state["hist"][self._i].cpu().numpy().view(np.uint16).reshape(S.HIST_RING, 2)
+        else:
+            cap, ring = S.LOG_RING, self._b.state["ring"][self._i].cpu().numpy().view(np.uint16).reshape(S.LOG_RING, 2)
+        n = min(total, cap)
         out = []
         for j in range(total - n, total):
-            f, t = ring[j % S.LOG_RING]
+            f, t = ring[j % cap]
             out.append({"time_step": 0, "from_device": int(f), "to_device": int(t), "kind": "A"})
         return out
 

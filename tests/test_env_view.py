@@ -171,3 +171,29 @@ def test_visibility_mask_on_device_matches_the_object_walk():
             np.testing.assert_array_equal(got[e], np.asarray(exp, np.float32), err_msg=f"{role} env {e}")
         assert got.sum() > 0
     env.close()
+
+
+def test_logs_come_from_the_long_history_when_the_batch_keeps_one():
+    """detector=True keeps the last 2048 comm-log entries per env (cygym_buffers.hist): the view's `logs` return value
+    then holds min(total, 2048) entries whose tail equals the 32-entry ring the scans read."""
+    from cygym_amd.batched_env import BatchedCyberDefenseEnv
+    from cygym_amd.env_view import CyberDefenseEnvView
+    from cygym_amd.topology import make_topology
+    from cygym_amd import abi
+    topo, init, ck = make_topology(64, 4, seed=5, n_active=56)
+    cfg = abi.EnvConfig(seed=5, **ck)
+    batch = BatchedCyberDefenseEnv(topo, cfg, 8, init, device="cuda:0", max_groups=1, max_devs=8, detector=True)
+    env = CyberDefenseEnvView(batch, 3)
+    env.mode = "attacker"
+    logs = []
+    for _ in range(12):
+        logs = env.step((1, [0], [], 0))[5]
+    total = int(batch.state["ienv"][3, S.I_LOG_TOTAL].item())
+    assert total > S.LOG_RING, "the spread must have logged more than one ring's worth"
+    assert len(logs) == min(total, S.HIST_RING)
+    ring = batch.state["ring"][3].cpu().numpy().view(np.uint16).reshape(S.LOG_RING, 2)
+    for j in range(total - S.LOG_RING, total):
+        f, t = ring[j % S.LOG_RING]
+        rec = logs[j - (total - len(logs))]
+        assert (rec["from_device"], rec["to_device"], rec["kind"], rec["time_step"]) == (int(f), int(t), "A", 0)
+    batch.close()
