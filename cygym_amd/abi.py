@@ -13,7 +13,7 @@ import numpy as np
 from . import rng as R
 from . import spec as S
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 u8p = C.POINTER(C.c_uint8)
 u16p = C.POINTER(C.c_uint16)
@@ -70,7 +70,14 @@ class Actions(C.Structure):
 
 
 class Outputs(C.Structure):
-    _fields_ = [("obs", C.c_void_p), ("raw", C.c_void_p), ("shaped", C.c_void_p), ("done", C.c_void_p)]
+    _fields_ = [("obs", C.c_void_p), ("raw", C.c_void_p), ("shaped", C.c_void_p), ("done", C.c_void_p),
+                ("obs_def", C.c_void_p), ("obs_att", C.c_void_p), ("status", C.c_void_p)]
+
+
+class ActionRows(C.Structure):
+    _fields_ = [("rows", C.c_void_p), ("atype", C.c_void_p), ("exploit", C.c_void_p), ("app", C.c_void_p),
+                ("dev_mask", C.c_void_p), ("dev_idx", C.c_void_p), ("dev_cnt", C.c_void_p),
+                ("n", C.c_int32), ("reserved", C.c_int32)]
 
 
 BASELINES = {"Nash": 0, "No Defense": 1, "Preset": 2, "No Attack": 3}

@@ -132,9 +132,12 @@ class BatchedCyberDefenseEnv:
         self.raw = torch.zeros(self.N, dtype=torch.float64, device=dev)
         self.shaped = torch.zeros(self.N, dtype=torch.float64, device=dev)
         self.done = torch.zeros(self.N, dtype=torch.uint8, device=dev)
-        self._out = abi.Outputs()
-        self._out.obs, self._out.raw = self.obs.data_ptr(), self.raw.data_ptr()
-        self._out.shaped, self._out.done = self.shaped.data_ptr(), self.done.data_ptr()
+        # one status word per batch: the kernels OR in the sticky / pending bits of the envs they tick
+        # (cygym_outputs.status); take_status() reads and clears it
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.role_obs = {}     # "defender" / "attacker" -> [N, W] float32 role view written by step(view=...)
+        self._outs = {}        # (view, full_obs) -> abi.Outputs
+        self._out = self._outputs(None, True)
         # first load is a verbatim copy of the snapshot (reset() keeps the live RNG tick)
         for k in abi.BUFFER_FIELDS:
             self.state[k].copy_(self.snapshot[k].expand_as(self.state[k]))
@@ -274,12 +277,93 @@ class BatchedCyberDefenseEnv:
         self._act_cache[id(act)] = (ptrs, sig, a)
         return a
 
-    def step(self, act=None):
+    def role_width(self, role: str) -> int:
+        if role == "defender":
+            return 6 * self.M
+        if role == "attacker":
+            return 4 * self.M + self.cfg.max_exploits
+        raise ValueError("role must be 'attacker' or 'defender'")
+
+    def _outputs(self, view, full_obs) -> abi.Outputs:
+        """The cygym_outputs struct for one (role view, full observation) combination; cached."""
+        key = (view, bool(full_obs))
+        o = self._outs.get(key)
+        if o is None:
+            o = abi.Outputs()
+            o.obs = self.obs.data_ptr() if full_obs else None
+            o.raw, o.shaped, o.done = self.raw.data_ptr(), self.shaped.data_ptr(), self.done.data_ptr()
+            o.status = self.status.data_ptr()
+            if view is not None:
+                if view not in self.role_obs:
+                    self.role_obs[view] = torch.zeros((self.N, self.role_width(view)), dtype=torch.float32, device=self.device)
+                setattr(o, "obs_def" if view == "defender" else "obs_att", self.role_obs[view].data_ptr())
+            self._outs[key] = o
+        return o
+
+    def step(self, act=None, view: str | None = None, full_obs: bool = True):
         """One tick for every env.  `act`: dict of device tensors shaped like self.act (default: self.act).
-        Returns (obs [N,M,6] f32, raw [N] f64, shaped [N] f64, done [N] u8) -- views of reused buffers."""
+        Returns (obs [N,M,6] f32, raw [N] f64, shaped [N] f64, done [N] u8) -- views of reused buffers.
+
+        view = "defender" / "attacker": the tick also writes that role's view of the state it leaves behind into
+        self.role_obs[view] ([N, 6M] / [N, 4M + MaxExploits]) -- what `_get_defender_state()` / `_get_attacker_state()`
+        return before the role's next action -- so a closed loop needs no observe() launch between ticks.
+        full_obs=False: the [N, M, 6] full observation is not written (`obs` then holds an older tick's)."""
         a = self.actions_struct(act)
-        _lib.check(self.lib.cygym_step(self._h, C.byref(a), C.byref(self._out), self._stream()), self._h, "cygym_step")
+        o = self._out if (view is None and full_obs) else self._outputs(view, full_obs)
+        _lib.check(self.lib.cygym_step(self._h, C.byref(a), C.byref(o), self._stream()), self._h, "cygym_step")
         return self.obs, self.raw, self.shaped, self.done
+
+    def write_actions(self, rows, a: dict, act=None):
+        """Scatter one strategy's chosen actions into rows `rows` (int env ids, device tensor; None = all rows in order)
+        of the action tensors `act` (default self.act), group 0: ONE launch (cygym_write_actions).  `a`: device
+        tensors atype [n], exploit [n] (one index, -1 = none), app [n], and either dev_mask [n, M] (bool / uint8,
+        compacted in the kernel to the ascending id list, first max_devs) or dev_idx [n, L] + dev_cnt [n]."""
+        act = self.act if act is None else act
+        dst = self.actions_struct(act)
+        i32 = lambda t: t if (t.dtype == torch.int32 and t.is_contiguous()) else t.to(torch.int32).contiguous()  # noqa: E731
+        keep = [i32(a["atype"]), i32(a["exploit"]), i32(a["app"])]
+        n = int(keep[0].shape[0])
+        src = abi.ActionRows()
+        src.atype, src.exploit, src.app = (t.data_ptr() for t in keep)
+        if rows is not None:
+            r = i32(rows)
+            if int(r.shape[0]) != n:
+                raise ValueError("rows and action tensors differ in length")
+            keep.append(r)
+            src.rows = r.data_ptr()
+        elif n > self.N:
+            raise ValueError("more action rows than envs")
+        if "dev_mask" in a:
+            m = a["dev_mask"]
+            if m.dtype not in (torch.bool, torch.uint8):
+                m = m != 0
+            m = m.contiguous()
+            if tuple(m.shape) != (n, self.M):
+                raise ValueError(f"dev_mask must have shape {(n, self.M)}")
+            keep.append(m)
+            src.dev_mask = m.data_ptr()
+        else:
+            di = a["dev_idx"]
+            di = di if (di.dtype == torch.int16 and di.is_contiguous()) else di.to(torch.int16).contiguous()
+            if tuple(di.shape) != (n, dst.max_devs):
+                raise ValueError(f"dev_idx must have shape {(n, dst.max_devs)}")
+            dc = i32(a["dev_cnt"])
+            keep += [di, dc]
+            src.dev_idx, src.dev_cnt = di.data_ptr(), dc.data_ptr()
+        for t in keep:
+            if t.device != self.device:
+                raise ValueError("action rows must live on the batch's device")
+        src.n = n
+        _lib.check(self.lib.cygym_write_actions(self._h, C.byref(src), C.byref(dst), self._stream()), self._h, "cygym_write_actions")
+        # (`keep` may die here: the caching allocator only reuses the blocks for work enqueued later on this stream)
+
+    def take_status(self) -> int:
+        """Read and clear the batch's status word: the OR of CG_E_TOPO_OVF | CG_E_BUSY_SAT | CG_E_DET_PENDING |
+        CG_E_UNPINNED over the envs ticked since the last call (one 4-byte device-to-host copy; synchronises)."""
+        v = int(self.status.item()) & 0xFFFFFFFF
+        if v:
+            self.status.zero_()
+        return v
 
     def step_range(self, begin: int, n: int, act=None):
         """One tick for the envs [begin, begin + n) only, on the current stream (cygym_step_range).  The action and
@@ -304,30 +388,66 @@ class BatchedCyberDefenseEnv:
         f[S.FOREST_HDR:] = w[S.FOREST_HDR:]
         self.state["ienv"][env, S.I_FLAGS] &= ~S.E_DET_PENDING
 
-    def service_detectors(self) -> int:
+    def pending_detectors(self, env_ids=None) -> torch.Tensor:
+        """Env ids (int64 device tensor, ascending) whose Detector.train request is still unanswered
+        (CG_E_DET_PENDING), optionally among `env_ids` only."""
+        flags = self.state["ienv"][:, S.I_FLAGS]
+        if env_ids is None:
+            return torch.nonzero(flags & S.E_DET_PENDING).flatten()
+        ids = torch.as_tensor(env_ids, dtype=torch.int64, device=self.device).flatten()
+        if ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= self.N):
+            raise IndexError("env id out of range")
+        return ids[(flags[ids] & S.E_DET_PENDING) != 0]
+
+    def service_detectors(self, env_ids=None) -> int:
         """Answer every pending Detector.train (defender action 10 on a non-empty log, volt_typhoon_env.py:945-962):
         fit scikit-learn's IsolationForest on the last <= 2000 entries of the env's history ring -- the numpy stream
         it draws from seeded by the Philox draw addressed (env, request tick, CG_SITE_DET_FIT) -- and install the
         flattened trees.  Call it after a tick that may have carried action 10 and before the next scan (a scan
-        that finds the request still pending answers all-"D" and raises CG_E_UNPINNED).  Synchronises; returns the
+        that finds the request still pending answers all-"D" and raises CG_E_UNPINNED).  `env_ids`: only these envs
+        (a per-env view services its own request, not the whole batch's).
+
+        ONE gather of the pending envs' request headers, log totals and history rings (three device-to-host copies
+        whatever the number of requests), the fits, ONE scatter of the forests back.  Synchronises; returns the
         number of forests fitted."""
         if not self.detector:
             return 0
         from . import detector as D
-        flags = self.state["ienv"][:, S.I_FLAGS]
-        pend = torch.nonzero(flags & S.E_DET_PENDING).flatten().tolist()
-        for e in pend:
-            hdr = self.state["forest"][e, :S.FOREST_HDR].cpu().numpy().view(np.uint32)
-            req_tick, req_total = int(hdr[3]), int(hdr[4])
-            total = int(self.state["ienv"][e, S.I_LOG_TOTAL])
-            if total - max(0, req_total - S.TRAIN_WINDOW) > S.HIST_RING:
-                raise _lib.CygymError(f"env {e}: the training window of tick {req_tick} has left the history ring "
-                                      "(service_detectors() must run before 48 more log entries arrive)")
-            hist = self.state["hist"][e].cpu().numpy().view(np.uint16)
-            rows = D.training_window(hist, req_total, bool(self.cfg.turbo), self.cfg.turbo_train_max_logs, self.cfg.turbo_train_stride)
-            self.install_forest(e, D.fit_forest(rows, D.fit_seed(self.cfg.seed, self.cfg.env_id_base + e, req_tick),
-                                                n_fits=int(hdr[6])))
-        return len(pend)
+        pend = self.pending_detectors(env_ids)
+        n = int(pend.numel())                      # (the one synchronisation of a call that finds nothing to do)
+        if n == 0:
+            return 0
+        st = self.state
+        ids = pend.cpu().numpy()
+        hdr = st["forest"][pend, :S.FOREST_HDR].cpu().numpy().view(np.uint32)
+        total = st["ienv"][pend, S.I_LOG_TOTAL].cpu().numpy().astype(np.int64)
+        hist = st["hist"][pend].cpu().numpy().view(np.uint16)
+        req_tick, req_total, n_fits = hdr[:, 3].astype(np.int64), hdr[:, 4].astype(np.int64), hdr[:, 6].astype(np.int64)
+        gone = total - np.maximum(0, req_total - S.TRAIN_WINDOW) > S.HIST_RING
+        if gone.any():
+            e = int(ids[np.argmax(gone)])
+            raise _lib.CygymError(f"env {e}: the training window of its request has left the history ring "
+                                  "(service_detectors() must run before 48 more log entries arrive)")
+        cfg = self.cfg
+        words = D.fit_forests(
+            [D.training_window(hist[j], int(req_total[j]), bool(cfg.turbo), cfg.turbo_train_max_logs, cfg.turbo_train_stride)
+             for j in range(n)],
+            [D.fit_seed(cfg.seed, cfg.env_id_base + int(ids[j]), int(req_tick[j])) for j in range(n)],
+            [int(v) for v in n_fits])
+        w = torch.from_numpy(np.ascontiguousarray(words).view(np.int32)).to(self.device)
+        f = st["forest"]
+        cur = f[pend]                                # [n, FOREST_WORDS]: keep the request the tick recorded (words 3, 4, 6)
+        cur[:, 0:3] = w[:, 0:3]
+        cur[:, 5] = cur[:, 3]
+        cur[:, S.FOREST_HDR:] = w[:, S.FOREST_HDR:]
+        f[pend] = cur
+        st["ienv"][pend, S.I_FLAGS] &= ~S.E_DET_PENDING
+        return n
+
+    def unpinned_envs(self) -> int:
+        """How many envs carry the sticky CG_E_UNPINNED bit: a scan ran in trained-detector mode without a current
+        forest (action 10 never serviced, or no forest buffer bound), so their results are not the reference's."""
+        return int(((self.state["ienv"][:, S.I_FLAGS] & S.E_UNPINNED) != 0).sum())
 
     def alloc_rollout(self, n_ticks: int):
         """Action and output tensors with a leading tick dimension for rollout()."""
@@ -341,24 +461,61 @@ class BatchedCyberDefenseEnv:
                    done=torch.zeros((T, self.N), dtype=torch.uint8, device=self.device))
         return act, out
 
-    def rollout(self, act: dict, out: dict):
+    def _training_ticks(self, act: dict) -> list:
+        """Ticks of a [T, N, ...] script in which some env carries defender action 10 (Detector.train,
+        volt_typhoon_env.py:945-962) in a group the tick will read.  One small reduction + one device-to-host copy."""
+        G = act["atype"].shape[2]
+        ng = act["n_groups"]
+        used = torch.arange(G, device=self.device)[None, None, :] < ng.clamp(min=1)[:, :, None]   # step(): group 0 only
+        hit = ((act["atype"] == 10) & used).any(dim=2) & ((act["mode"] & 0xFF) == S.MODE_DEFENDER) & (ng >= 0)
+        return torch.nonzero(hit.any(dim=1)).flatten().tolist()
+
+    def rollout(self, act: dict, out: dict, check: bool = True):
         """T consecutive ticks in ONE launch (cygym_rollout): `act` / `out` carry a leading tick dimension
         (see alloc_rollout).  Open-loop: every tick's action is staged beforehand.  Same results as T step()
-        calls; an env's state stays on chip between its ticks and envs never wait for each other."""
+        calls; an env's state stays on chip between its ticks and envs never wait for each other.
+
+        `out` may also hold "obs_def" / "obs_att" ([T, N, 6M] / [T, N, 4M + MaxExploits] float32): the role views of
+        the state each tick leaves behind (cygym_outputs); "obs" may be None (not written).
+
+        Detector.train is a host callback, and the reference trains synchronously inside the tick (:961): on a batch
+        created with detector=True a script that carries defender action 10 is therefore CUT after every such tick --
+        launch, service_detectors(), next launch -- so that later scans see the forests the reference would have.
+        On a batch without detector buffers nothing can be fitted: the launch runs, and if a scan then ran in
+        trained mode without a forest (CG_E_UNPINNED) this raises instead of returning all-"D" results silently.
+        check=False skips that final status read (the call then stays asynchronous; poll take_status() yourself)."""
         T = int(act["mode"].shape[0])
         G, L = self._check_actions(act, (T, self.N))
-        a = abi.Actions()
-        for k in self._ACT_DTYPES:
-            setattr(a, k, act[k].data_ptr())
-        a.max_groups, a.max_devs = G, L
-        o = abi.Outputs()
-        odt = {"obs": (torch.float32, (self.M, 6)), "raw": (torch.float64, ()), "shaped": (torch.float64, ()), "done": (torch.uint8, ())}
+        odt = {"obs": (torch.float32, (self.M, 6)), "raw": (torch.float64, ()), "shaped": (torch.float64, ()), "done": (torch.uint8, ()),
+               "obs_def": (torch.float32, (6 * self.M,)), "obs_att": (torch.float32, (4 * self.M + self.cfg.max_exploits,))}
+        optional = ("obs", "obs_def", "obs_att")
         for k, (dt, tail) in odt.items():
-            t = out[k]
-            if t.dtype != dt or t.device != self.device or not t.is_contiguous() or tuple(t.shape) != (T, self.N) + tail:
+            t = out.get(k)
+            if t is None and k in optional:
+                continue
+            if t is None or t.dtype != dt or t.device != self.device or not t.is_contiguous() or tuple(t.shape) != (T, self.N) + tail:
                 raise ValueError(f"rollout output {k} must be a contiguous {dt} tensor of shape {(T, self.N) + tail} on {self.device}")
-            setattr(o, k, t.data_ptr())
-        _lib.check(self.lib.cygym_rollout(self._h, T, C.byref(a), C.byref(o), self._stream()), self._h, "cygym_rollout")
+        cuts = [t + 1 for t in self._training_ticks(act)] if self.detector else []
+        bounds = sorted(set(c for c in cuts if c < T) | {T})
+        t0 = 0
+        for t1 in bounds:
+            a = abi.Actions()
+            for k in self._ACT_DTYPES:
+                setattr(a, k, act[k][t0:t1].data_ptr())
+            a.max_groups, a.max_devs = G, L
+            o = abi.Outputs()
+            for k in odt:
+                if out.get(k) is not None:
+                    setattr(o, k, out[k][t0:t1].data_ptr())
+            o.status = self.status.data_ptr()
+            _lib.check(self.lib.cygym_rollout(self._h, t1 - t0, C.byref(a), C.byref(o), self._stream()), self._h, "cygym_rollout")
+            if t1 in cuts:
+                self.service_detectors()
+            t0 = t1
+        if check and (self.take_status() & S.E_UNPINNED):
+            raise _lib.CygymError(
+                f"{self.unpinned_envs()} env(s) ran a scan in trained-detector mode without a current forest (defender action 10 "
+                "earlier in the script): create the batch with detector=True so that the trainings can be serviced")
         return out
 
     def gen_actions_rollout(self, tick0: int, act: dict):

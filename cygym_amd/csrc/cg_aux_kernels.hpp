@@ -141,6 +141,46 @@ __global__ void observe_kernel(KParams P, int role, float* out) {
   }
 }
 
+// cygym_write_actions: one wave per source row.  A device mask is compacted to the ascending id list with ballots
+// (rank of a chosen device = chosen devices below it), the first max_devs of them; entries past the count are zeroed.
+__global__ void write_actions_kernel(cygym_action_rows src, cygym_actions dst, int M, int n_envs) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= src.n) return;
+  const int row = src.rows ? src.rows[wave] : wave;
+  if (row < 0 || row >= n_envs) return;
+  const int G = dst.max_groups, L = dst.max_devs;
+  int16_t* out = const_cast<int16_t*>(dst.dev_idx) + (size_t)row * L;
+  int cnt;
+  if (src.dev_mask) {
+    const uint8_t* mk = src.dev_mask + (size_t)wave * M;
+    int base = 0;
+    for (int d0 = 0; d0 < M; d0 += WAVE) {
+      const int d = d0 + lane;
+      const bool on = d < M && mk[d] != 0;
+      const uint64_t m = __ballot(on);
+      const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      if (on && pos < L) out[pos] = (int16_t)d;
+      base += __popcll(m);
+    }
+    cnt = base < L ? base : L;
+  } else {
+    cnt = src.dev_cnt[wave];
+    if (cnt > L) cnt = L;
+    if (cnt < 0) cnt = 0;
+    const int16_t* in = src.dev_idx + (size_t)wave * L;
+    for (int q = lane; q < cnt; q += WAVE) out[q] = in[q];
+  }
+  for (int q = cnt + lane; q < L; q += WAVE) out[q] = 0;
+  if (lane == 0) {
+    const int ex = src.exploit[wave];
+    const_cast<int32_t*>(dst.atype)[(size_t)row * G] = src.atype[wave];
+    const_cast<int32_t*>(dst.exploit)[(size_t)row * G * CG_MAX_EXPLOITS] = ex;
+    const_cast<int32_t*>(dst.n_exploit)[(size_t)row * G] = ex >= 0 ? 1 : 0;
+    const_cast<int32_t*>(dst.app)[(size_t)row * G] = src.app[wave];
+    const_cast<int32_t*>(dst.dev_cnt)[(size_t)row * G] = cnt;
+  }
+}
+
 // Synthetic action script of bench.py: alternating defender / attacker turns.
 // Mirrored in numpy by cygym_amd/actions.py (tests check equality).
 __global__ void gen_actions_kernel(KParams P, int tick, int32_t* mode, int32_t* n_groups, int32_t* atype,

@@ -454,7 +454,7 @@ __device__ __forceinline__ void def_per_device(Env& e, const KP& P, int at, cons
         const uint32_t* fo = nullptr;
         const double* apl = nullptr;
         if constexpr (XE) { if (P.b.forest) fo = P.b.forest + (size_t)e.env * CG_FOREST_WORDS; apl = P.t.apl; }
-        if (!fo || !apl || (e.eflags & CG_E_DET_PENDING)) {
+        if (!fo || !apl || (e.eflags & CG_E_DET_PENDING) || fo[2] == 0u) {   // (node-count word 0: no trees were ever installed)
           e.eflags |= CG_E_UNPINNED;   // no current forest: all "D", flagged (cygym_spec.h)
         } else {
           // The window, the forest and hence the predictions are the same for every scan of this tick; a flagged
@@ -481,10 +481,10 @@ __device__ __forceinline__ void def_per_device(Env& e, const KP& P, int at, cons
               depths += ((double)CG_FN_DEPTH(nd) + apl[ns]) - 1.0;
             }
             const double sstar = __hiloint2double((int)fo[1], (int)fo[0]);
-            anom = depths < sstar && snd < M;   // (a ring loaded from the host with ids >= M never reaches LDS)
-          }
+            anom = depths < sstar;   // foreign sender ids (>= M, a ring loaded from the host) count towards the majority
+          }                          // like in the coin path and the oracle; only the write skips them
           const uint64_t m = ballot(anom);
-          if (__popcll(m) >= w / 2 + 1 && anom) {
+          if (__popcll(m) >= w / 2 + 1 && anom && snd < M) {
             atomicAnd((unsigned int*)(e.flags + (snd & ~3)), ~((uint32_t)CG_F_COMP << ((snd & 3) * 8)));
             e.busy[snd] = (uint8_t)cg_randint(e.draw(CG_SITE_STALL_SCAN, snd, n_mult - 1), 0, P.c.default_high);
           }

@@ -54,6 +54,61 @@ __device__ __forceinline__ void write_obs(const uint8_t* flags, const float* osv
   }
 }
 
+// Role views of the state the tick leaves behind (cygym_outputs.obs_def / obs_att), straight from the env's flag plane
+// in LDS -- what cygym_observe computes from global memory in a launch of its own.
+// _get_defender_state (CyberDefenseEnv.py:243-257): rows of not-yet-added or non-attacker-owned devices are all -1,
+// column 2 (isCompromised) is -1 everywhere.  One lane per device PAIR, three 16-byte stores (even M).
+__device__ __forceinline__ void write_obs_def(const uint8_t* flags, const float* osv, const float* ver, const float* ano,
+                                              float* out, int M, int lane) {
+  if (!(M & 1)) {
+    float4* out4 = (float4*)out;
+    const int npairs = M >> 1;
+    const uint16_t* F2 = (const uint16_t*)flags;
+    for (int p = lane; p < npairs; p += WAVE) {
+      const uint32_t f2 = F2[p];
+      const float2 o = ((const float2*)osv)[p], v = ((const float2*)ver)[p], a = ((const float2*)ano)[p];
+      const uint32_t fa = f2 & 0xFFu, fb = f2 >> 8;
+      const bool ha = (fa & CG_F_NYA) || !(fa & CG_F_OWNED), hb = (fb & CG_F_NYA) || !(fb & CG_F_OWNED);
+      const float ka = (float)((fa >> 2) & 1u), kb = (float)((fb >> 2) & 1u);
+      out4[3 * p + 0] = ha ? make_float4(-1.f, -1.f, -1.f, -1.f) : make_float4(o.x, v.x, -1.f, a.x);
+      out4[3 * p + 1] = make_float4(ha ? -1.f : ka, ha ? -1.f : 0.f, hb ? -1.f : o.y, hb ? -1.f : v.y);
+      out4[3 * p + 2] = hb ? make_float4(-1.f, -1.f, -1.f, -1.f) : make_float4(-1.f, a.y, kb, 0.f);
+    }
+  } else {
+    for (int d = lane; d < M; d += WAVE) {
+      const uint32_t f = flags[d];
+      const bool h = (f & CG_F_NYA) || !(f & CG_F_OWNED);
+      out[6 * d + 0] = h ? -1.f : osv[d]; out[6 * d + 1] = h ? -1.f : ver[d]; out[6 * d + 2] = -1.f;
+      out[6 * d + 3] = h ? -1.f : ano[d]; out[6 * d + 4] = h ? -1.f : (float)((f >> 2) & 1u); out[6 * d + 5] = h ? -1.f : 0.f;
+    }
+  }
+}
+// _get_attacker_state (CyberDefenseEnv.py:194-241): per device (os, version, compromised, known) when the attacker sees
+// it (known, added, attacker-owned), else -1; then MaxExploits availability bits.  Rows are 8-byte aligned when the
+// row width is even: two 8-byte stores per device.
+__device__ __forceinline__ void write_obs_att(const uint8_t* flags, const float* osv, const float* ver, float* out,
+                                              int M, int X, int max_exploits, int lane) {
+  const int W = 4 * M + max_exploits;
+  if (!(W & 1)) {
+    float2* out2 = (float2*)out;
+    for (int d = lane; d < M; d += WAVE) {
+      const uint32_t f = flags[d];
+      const bool vis = (f & CG_F_KNOWN) && !(f & CG_F_NYA) && (f & CG_F_OWNED);
+      const float o = osv[d], v = ver[d];
+      out2[2 * d + 0] = vis ? make_float2(o, v) : make_float2(-1.f, -1.f);
+      out2[2 * d + 1] = vis ? make_float2((float)(f & 1u), 1.f) : make_float2(-1.f, -1.f);
+    }
+  } else {
+    for (int d = lane; d < M; d += WAVE) {
+      const uint32_t f = flags[d];
+      const bool vis = (f & CG_F_KNOWN) && !(f & CG_F_NYA) && (f & CG_F_OWNED);
+      out[4 * d + 0] = vis ? osv[d] : -1.f; out[4 * d + 1] = vis ? ver[d] : -1.f;
+      out[4 * d + 2] = vis ? (float)(f & 1u) : -1.f; out[4 * d + 3] = vis ? 1.f : -1.f;
+    }
+  }
+  if (lane < max_exploits) out[4 * M + lane] = lane < X ? 1.f : 0.f;
+}
+
 struct WaveAux { uint64_t* srcb; int32_t* park; };
 // MAPS: the in-CSR columns and slot maps are staged in LDS too (the WIDE per-tick kernel, one 16-wave workgroup per CU)
 template <bool MAPS, class KP>
@@ -358,6 +413,7 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 &
   uint32_t* const Wl = (uint32_t*)e.wl;
   const uint32_t* const Ds = (const uint32_t*)e.dst;
   const bool partial = (mode & CG_MODE_PARTIAL) && ng == 0;   // step(action, agent_cnt != len(net)) :1207
+  const int baseline = CG_MODE_BASELINE_OF(mode, P.c.baseline);   // env.base_line: per env and tick when the mode word carries it
   mode &= 0xFF;
   e.tick = (uint32_t)ie[CG_I_RNG_TICK];
   e.eflags = ie[CG_I_FLAGS];
@@ -394,11 +450,11 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 &
     }
     wsync();
     if (mode == CG_MODE_DEFENDER) {
-      if (P.c.baseline != 0) at = 8;   // :913-914
+      if (baseline != 0) at = 8;   // :913-914
       def_global(e, P, at, devs, Ld, cost, dirty, false, ie, fe);
       if (at == 1 || at == 4 || at == 5 || at == 6 || at == 7 || at == 9 || at == 12 || at == 13)
         if (Ld > 0) def_per_device<XE, WIDE>(e, P, at, devs, Ld, app0, cost, dirty, ie, fe);
-    } else if (P.c.baseline != 3 && (at == 1 || at == 2)) {
+    } else if (baseline != 3 && (at == 1 || at == 2)) {
       // :1127 snapshot of the sources.  Chunk loops are STAGED in groups of four: the LDS reads of a group are issued
       // before its first store (the compiler cannot reorder an LDS load over an LDS store it cannot disambiguate, so a
       // plain chunk loop pays one LDS round trip per chunk, one after the other)
@@ -439,7 +495,7 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 &
       if (mode == CG_MODE_DEFENDER && at == 0) at = 8;
       else if (mode == CG_MODE_ATTACKER && at == 0) at = 3;
       if (mode == CG_MODE_DEFENDER) {
-        if (P.c.baseline != 0) at = 8;
+        if (baseline != 0) at = 8;
         def_global(e, P, at, dp, Ld, cost, dirty, true, ie, fe);
         if (at == 1 && Ld > 0) def_clean(e, P, dp, Ld, cost, ie, fe, occ);
       }
@@ -520,9 +576,11 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 &
   // ---- observation (_get_state CyberDefenseEnv.py:146-191), before evolve.  The static float columns come from
   // LDS, or (large M, where leaving them out of LDS buys resident waves) from the L2-resident blob.
   constexpr int OBS_GP = MT ? ((MT / 2 + WAVE - 1) / WAVE < 4 ? (MT / 2 + WAVE - 1) / WAVE : 4) : CG_OBS_GP0;
-  if (P.t.in_lds) write_obs<OBS_GP>(e.flags, e.osv, e.ver, e.ano, P.o.obs + te * M * 6, M, lane);
-  else write_obs<OBS_GP>(e.flags, (const float*)(P.t.blob + P.t.o_os), (const float*)(P.t.blob + P.t.o_ver),
-                         (const float*)(P.t.blob + P.t.o_ano), P.o.obs + te * M * 6, M, lane);
+  if (P.o.obs) {
+    if (P.t.in_lds) write_obs<OBS_GP>(e.flags, e.osv, e.ver, e.ano, P.o.obs + te * M * 6, M, lane);
+    else write_obs<OBS_GP>(e.flags, (const float*)(P.t.blob + P.t.o_os), (const float*)(P.t.blob + P.t.o_ver),
+                           (const float*)(P.t.blob + P.t.o_ano), P.o.obs + te * M * 6, M, lane);
+  }
 
   STAMP(5);
   if (!partial) {   // :1307-1312
@@ -567,14 +625,10 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 &
         for (int i = lane; i < M; i += WAVE) e.flags[pl * MS + i] = P.snap.live[ss + pl * M + i];
     }
     if (vec) {   // 16 bytes per lane and trip (byte by byte this copy was 128 dependent round trips at 2048 devices)
-      for (int i = lane; i < items; i += WAVE) ((uint4*)(P.b.stash + so))[i] = ((const uint4*)(P.snap.stash + ss))[i];
-    } else {
-      if (vec) {   // 16 bytes per lane and trip (byte by byte this copy was 128 dependent round trips at 2048 devices)
 #pragma nounroll
       for (int i = lane; i < items; i += WAVE) ((uint4*)(P.b.stash + so))[i] = ((const uint4*)(P.snap.stash + ss))[i];
     } else {
       for (int i = lane; i < 4 * M; i += WAVE) P.b.stash[so + i] = P.snap.stash[ss + i];
-    }
     }
     for (int w = lane; w < P.t.EW; w += WAVE) {
       e.blk[w] = P.snap.blocked[(size_t)si * P.t.EW + w];
@@ -617,6 +671,15 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 &
     for (int i = 0; i < CG_D_COUNT; ++i) fe[i] = gf[i];
     wsync();
   }
+  // ---- optional role views of the state this tick leaves behind (after evolve / auto-reset): what the next actor's
+  // policy reads (cygym_outputs.obs_def / obs_att); replaces a cygym_observe launch per tick of a closed loop ----
+  if (COLD(P.o.obs_def != nullptr) || COLD(P.o.obs_att != nullptr)) {
+    const float* osv = P.t.in_lds ? e.osv : (const float*)(P.t.blob + P.t.o_os);
+    const float* ver = P.t.in_lds ? e.ver : (const float*)(P.t.blob + P.t.o_ver);
+    const float* ano = P.t.in_lds ? e.ano : (const float*)(P.t.blob + P.t.o_ano);
+    if (P.o.obs_def) write_obs_def(e.flags, osv, ver, ano, P.o.obs_def + te * M * 6, M, lane);
+    if (P.o.obs_att) write_obs_att(e.flags, osv, ver, P.o.obs_att + te * (size_t)(4 * M + P.c.max_exploits), M, P.t.X, P.c.max_exploits, lane);
+  }
   if (FUSED && tk + 1 < n_ticks) {   // park the scalars for the next tick
     if (lane == 0) {
 #pragma unroll
@@ -651,6 +714,8 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 &
     for (int w = lane; w < P.t.KW; w += WAVE) xg[P.t.K + w] = e.xb[w];
   }
   if (lane == 0) {
+    const uint32_t sticky = (uint32_t)ie[CG_I_FLAGS] & (CG_E_TOPO_OVF | CG_E_BUSY_SAT | CG_E_DET_PENDING | CG_E_UNPINNED);
+    if (COLD(sticky != 0u) && P.o.status) atomicOr(P.o.status, sticky);
     int32_t* g = P.b.ienv + (size_t)env * CG_I_COUNT;
 #pragma unroll
     for (int i = 0; i < CG_I_COUNT; ++i) g[i] = ie[i];

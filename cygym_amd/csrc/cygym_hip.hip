@@ -169,7 +169,7 @@ static int choose_launch(cygym_handle* h, int max_devs) {
       // compile-time size is built for 6 waves per SIMD in workgroups of 2-8 waves and 5 otherwise, everything else
       // for 4 (launch bounds of step_kernel).  Without this a 16-wave shape that LDS would hold twice won over three
       // 8-wave workgroups although only one of the two ever runs (16384 x 256: -11 %).
-      const bool ct = t.M == 64 || t.M == 256, ct_lean = ct && t.K == 0;
+      const bool ct = t.M == 64 || t.M == 256, ct_lean = ct && !full_feature(h);
       // (the full-feature per-tick kernels at a compile-time size need <= 102 VGPRs: 5 waves per SIMD;
       // tests/test_host_cpu.py holds them to that)
       const int reg_cap = ct_lean ? ((wpb > 1 && wpb <= 8) ? 24 : 20) : (ct ? 20 : 16);
@@ -192,7 +192,7 @@ static int choose_launch(cygym_handle* h, int max_devs) {
   // on defender ticks is a block / unblock list): one 16-wave workgroup per CU leaves room for the in-CSR columns and
   // slot maps in LDS as well, so a speculation pass no longer waits on global memory.  Compile-time size 256, lean only.
   h->wide = false;
-  if (h->few_waves && t.M == 256 && t.K == 0 && !forced && (size_t)h->o_maps_end + wave * 16 <= lds_cap) {
+  if (h->few_waves && t.M == 256 && !full_feature(h) && !forced && (size_t)h->o_maps_end + wave * 16 <= lds_cap) {
     h->wide = true;
     h->wpb = 16; h->wpb_fused = 16; h->shared_lds = h->o_maps_end;
     t.lds_bytes = h->o_maps_end; t.in_lds = 1;
@@ -347,8 +347,16 @@ int cygym_bind(cygym_handle* h, const cygym_buffers* state) {
   if (!h) return fail(h, CYGYM_EINVAL, "cygym_bind: null handle%s", "");
   int rc = check_buffers(h, state, false);
   if (rc) return rc;
+  const bool was_full = full_feature(h);
   h->b = *state;
   h->bound = true;
+  // The launch was planned at cygym_create, before it was known whether a forest / history buffer would select the
+  // full-feature kernels (other register budget, no WIDE shape): re-plan now that it is.
+  if (full_feature(h) != was_full) {
+    if (choose_launch(h, h->max_devs) != 0) return fail(h, CYGYM_EUNSUPPORTED, "topology does not fit in LDS%s", "");
+    HIPCHK(h, hipSetDevice(h->device_id));
+    HIPCHK(h, set_lds_attr(h));
+  }
   return CYGYM_OK;
 }
 
@@ -427,7 +435,7 @@ static int launch_ticks(cygym_handle* h, int32_t n_ticks, int32_t env_begin, int
   if (n_ticks < 1) return fail(h, CYGYM_EINVAL, "cygym_rollout: n_ticks must be >= 1%s", "");
   if (env_begin < 0 || n < 0 || env_begin > h->n_envs - n) return fail(h, CYGYM_EINVAL, "cygym_step_range: env range outside [0, n_envs)%s", "");
   if (!a || !o || !a->mode || !a->n_groups || !a->atype || !a->n_exploit || !a->exploit || !a->app ||
-      !a->dev_cnt || !a->dev_idx || !o->obs || !o->raw || !o->shaped || !o->done)
+      !a->dev_cnt || !a->dev_idx || !o->raw || !o->shaped || !o->done)
     return fail(h, CYGYM_EINVAL, "cygym_step: null action / output pointer%s", "");
   if (a->max_groups < 1 || a->max_devs < 1) return fail(h, CYGYM_EINVAL, "cygym_step: max_groups / max_devs must be >= 1%s", "");
   if (a->max_devs > 32767) return fail(h, CYGYM_EINVAL, "cygym_step: max_devs too large%s", "");
@@ -494,6 +502,23 @@ int cygym_gen_actions(cygym_handle* h, int32_t tick, int32_t* mode, int32_t* n_g
   KParams P = make_params(h);
   hipLaunchKernelGGL(gen_actions_kernel, dim3((h->n_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, tick,
                      mode, n_groups, atype, n_exploit, exploit, app, dev_cnt, dev_idx, max_devs);
+  HIPCHK(h, hipGetLastError());
+  return CYGYM_OK;
+}
+
+int cygym_write_actions(cygym_handle* h, const cygym_action_rows* src, const cygym_actions* dst, void* stream) {
+  if (!h) return fail(h, CYGYM_EINVAL, "cygym_write_actions: null handle%s", "");
+  if (!src || !dst || !src->atype || !src->exploit || !src->app || (!src->dev_mask && (!src->dev_idx || !src->dev_cnt)))
+    return fail(h, CYGYM_EINVAL, "cygym_write_actions: null source pointer%s", "");
+  if (!dst->atype || !dst->n_exploit || !dst->exploit || !dst->app || !dst->dev_cnt || !dst->dev_idx || dst->max_groups < 1 ||
+      dst->max_devs < 1)
+    return fail(h, CYGYM_EINVAL, "cygym_write_actions: bad destination%s", "");
+  if (src->n < 0 || (!src->rows && src->n > h->n_envs)) return fail(h, CYGYM_EINVAL, "cygym_write_actions: bad row count%s", "");
+  if (src->n == 0) return CYGYM_OK;
+  HIPCHK(h, hipSetDevice(h->device_id));
+  const int threads = 256, waves_per_block = threads / WAVE;
+  hipLaunchKernelGGL(write_actions_kernel, dim3((src->n + waves_per_block - 1) / waves_per_block), dim3(threads), 0,
+                     (hipStream_t)stream, *src, *dst, h->t.M, h->n_envs);
   HIPCHK(h, hipGetLastError());
   return CYGYM_OK;
 }

@@ -70,6 +70,9 @@ def score_threshold(max_samples: int, n_estimators: int = 2, offset: float = -0.
     return float(np.array([hi], np.uint64).view(np.float64)[0])
 
 
+_SSTAR_CACHE: dict = {}
+
+
 def flatten_forest(model) -> np.ndarray:
     """A fitted sklearn IsolationForest -> u32 [FOREST_WORDS] (layout: cygym_spec.h).  Header words 3..5 (the
     request / answer ticks) are left 0 for the caller."""
@@ -79,30 +82,30 @@ def flatten_forest(model) -> np.ndarray:
     if any(list(f) != [0, 1] for f in model.estimators_features_):
         raise ValueError("feature sub-sampling is not part of the reference's detector")
     words = np.zeros(S.FOREST_WORDS, np.uint32)
-    sstar = score_threshold(int(model.max_samples_), len(ests), float(model.offset_))
-    words[0:2] = np.array([sstar], np.float64).view(np.uint32)
+    key = (int(model.max_samples_), len(ests), float(model.offset_))
+    if key not in _SSTAR_CACHE:      # (a 64-step bisection over numpy expressions: once per distinct training size)
+        _SSTAR_CACHE[key] = score_threshold(*key)
+    words[0:2] = np.array([_SSTAR_CACHE[key]], np.float64).view(np.uint32)
     counts = []
     for t, est in enumerate(ests):
         tr = est.tree_
         n = int(tr.node_count)
         if n > S.FOREST_NODES - 1:
             raise ValueError(f"tree {t} has {n} nodes")
-        depth = np.asarray(tr.compute_node_depths(), np.int64)
+        depth = np.asarray(tr.compute_node_depths(), np.int64)[:n]
+        left = np.asarray(tr.children_left, np.int64)[:n]
+        right = np.asarray(tr.children_right, np.int64)[:n]
+        leaf = left == -1
+        ns = np.asarray(tr.n_node_samples, np.int64)[:n]
+        if np.any(leaf & ~((0 <= ns) & (ns < 512) & (1 <= depth) & (depth <= 15))):
+            raise ValueError("leaf does not fit the node encoding")
+        ft = np.asarray(tr.feature, np.int64)[:n]
+        fl = np.floor(np.where(leaf, 0.0, np.asarray(tr.threshold, np.float64)[:n])).astype(np.int64)
+        if np.any(~leaf & ~(((ft == 0) | (ft == 1)) & (0 <= fl) & (fl < 4096))):
+            raise ValueError("internal node does not fit the node encoding")
         base = S.FOREST_HDR + t * S.FOREST_NODES
-        for i in range(n):
-            l, r = int(tr.children_left[i]), int(tr.children_right[i])
-            if l == -1:     # leaf
-                ns = int(tr.n_node_samples[i])
-                if not (0 <= ns < 512 and 1 <= depth[i] <= 15):
-                    raise ValueError("leaf does not fit the node encoding")
-                words[base + i] = (1 << 31) | (int(depth[i]) << 9) | ns
-            else:
-                thr = float(tr.threshold[i])
-                ft = int(tr.feature[i])
-                fl = int(np.floor(thr))
-                if ft not in (0, 1) or not (0 <= fl < 4096):
-                    raise ValueError("internal node does not fit the node encoding")
-                words[base + i] = (ft << 30) | (fl << 18) | (l << 9) | r
+        words[base: base + n] = np.where(leaf, (1 << 31) | (depth << 9) | ns,
+                                         (ft << 30) | (fl << 18) | (left << 9) | right).astype(np.uint32)
         counts.append(n)
     words[2] = counts[0] | (counts[1] << 16)
     return words
@@ -149,13 +152,38 @@ def fit_forest(X, seed32: int, n_fits: int = 1) -> np.ndarray:
     if len(X) == 0:
         raise ValueError("Detector.train on an empty log is the random-detection mode (CDSimulator.py:688-690)")
     model = IsolationForest(n_estimators=2, max_samples=256, n_jobs=1, random_state=np.random.RandomState(int(seed32)))
-    rows = [[int(a), int(b)] for a, b in X]
+    rows = X     # (the reference passes a list of [from, to] lists: validated into the same float32 matrix)
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")     # "max_samples (256) is greater than the total number of samples"
         for _ in range(max(1, int(n_fits))):
             model.fit(rows)
     return flatten_forest(model)
+
+
+def fit_forests(rows_list, seeds, n_fits=None, workers: int | None = None) -> np.ndarray:
+    """`fit_forest` for a batch of requests -> u32 [n, FOREST_WORDS].  The fits are independent (each has its own
+    numpy stream), so they run on a thread pool; scikit-learn's tree builder releases the GIL, its Python layers do
+    not, so the speed-up is modest -- the gather / scatter around it is what no longer scales with the request count."""
+    n = len(rows_list)
+    n_fits = [1] * n if n_fits is None else list(n_fits)
+    out = np.zeros((n, S.FOREST_WORDS), np.uint32)
+    if n == 0:
+        return out
+    import os
+    workers = workers or min(8, os.cpu_count() or 1, n)
+
+    def one(j):
+        out[j] = fit_forest(rows_list[j], seeds[j], n_fits[j])
+
+    if workers <= 1 or n < 4:
+        for j in range(n):
+            one(j)
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(workers) as pool:
+            list(pool.map(one, range(n)))
+    return out
 
 
 def training_window(hist_row: np.ndarray, log_total: int, turbo: bool = False, turbo_max_logs: int = 256,

@@ -227,7 +227,7 @@ class CyberDefenseEnvView:
             v[i:i + 1].copy_(torch.from_numpy(row[k]))
         obs, raw, shaped, done = b.step_range(i, 1)
         if b.detector and any(int(g[0]) == 10 for g in groups):
-            b.service_detectors()        # Detector.train is synchronous in the reference (volt_typhoon_env.py:961)
+            b.service_detectors([i])     # Detector.train is synchronous in the reference (volt_typhoon_env.py:961); only THIS env's request
         self.state = obs[i].reshape(-1).cpu().numpy().astype(np.float64)   # (.cpu() synchronises with the launch)
         return float(raw[i].item()), float(shaped[i].item()), bool(done[i].item())
 

@@ -257,9 +257,16 @@ def flatten_dynamic(env, static):
     fenv[S.D_CLEAN_COST] = env.clearning_cost
     pp = getattr(env, "_prev_att_potential", None)
     fenv[S.D_PREV_ATT_POT] = 0.0 if pp is None else float(pp)
+    # a trained detector travels with the env: its fitted forest, flattened (cygym_spec.h).  Header word 5 (the
+    # request the installed forest answers) equals word 3 (no request of this env's ticks is outstanding).
+    forest = np.zeros(S.FOREST_WORDS, np.uint32)
+    if det.trained:
+        from . import detector as D
+        forest[:] = D.flatten_forest(det.model)
+        forest[3] = forest[5] = 0
     return dict(flags=flags, busy=busy, wl=wl, comp_by=comp_by, st_flags=st_flags, st_busy=st_busy,
                 st_wl=st_wl, st_comp_by=st_comp_by, blocked=blocked, ring=ring, ienv=ienv, fenv=fenv,
-                extra=extra, hist=hist)
+                extra=extra, hist=hist, forest=forest)
 
 
 def extra_edges(env, static):

@@ -29,6 +29,7 @@ D_DEF_COST, D_CLEAN_COST, D_PREV_ATT_POT, D_COUNT = range(4)
 
 MODE_DEFENDER, MODE_ATTACKER = 0, 1
 MODE_PARTIAL = 0x100
+MODE_BASELINE_SHIFT = 16   # bits 16..18 of the mode word: (env.base_line code + 1) of this env for this tick, 0 = the config's
 LOG_RING = 32
 SCAN_WINDOW = 30
 HIST_RING = 2048

@@ -5,8 +5,8 @@
  * Every device buffer is CALLER-OWNED (the Python host allocates torch tensors
  * and passes tensor.data_ptr()); the library never allocates or frees HBM except
  * for its private copy of the (<= ~100 KB) shared topology and static tables made in
- * cygym_create and two parameter blocks of a few KB (the scratch of cygym_randomize
- * is caller-owned too, see there).
+ * cygym_create (launch parameters travel as the kernel argument only; the scratch of
+ * cygym_randomize is caller-owned too, see there).
  *
  * Each entry point cites the reference interface it replaces (paths relative to
  * the reference checkout).  The reference has no FFI of its own -- it is 100 %
@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CYGYM_ABI_VERSION 3
+#define CYGYM_ABI_VERSION 4
 
 #define CYGYM_OK            0
 #define CYGYM_EINVAL       -1  /* bad argument / shape                       */
@@ -159,10 +159,22 @@ typedef struct cygym_actions {
 
 /* What step() returns, for every env, DEVICE pointers. */
 typedef struct cygym_outputs {
-  float*   obs;     /* [N][M][6] env.state  CyberDefenseEnv.py:146-191          */
+  float*   obs;     /* [N][M][6] env.state  CyberDefenseEnv.py:146-191, or NULL: not written (a closed-loop
+                       consumer that only reads a role view saves the 24 B/device)          */
   double*  raw;     /* [N] raw_reward                                           */
   double*  shaped;  /* [N] shaped_reward                                        */
   uint8_t* done;    /* [N]                                                      */
+  /* Optional role views of the state the tick LEAVES BEHIND (after evolve_network) -- what the reference's rollout
+   * loops read before the next action: `env._get_defender_state()` / `env._get_attacker_state()`
+   * (do_agent.py:212-262, IPPO.py:503-620; CyberDefenseEnv.py:194-257).  NULL: not written.  A closed loop that
+   * alternates roles passes obs_att on defender ticks and obs_def on attacker ticks and needs no cygym_observe
+   * launch in between.  An env that auto-resets in this tick reports the view of its reloaded state.       */
+  float*   obs_def; /* [N][6M]                 _get_defender_state()            */
+  float*   obs_att; /* [N][4M + MaxExploits]   _get_attacker_state()            */
+  uint32_t* status; /* optional, ONE word: OR of (CG_E_TOPO_OVF | CG_E_BUSY_SAT | CG_E_DET_PENDING | CG_E_UNPINNED)
+                       over the envs this launch ticked, as they stand at write-back (atomically OR-ed in: clear
+                       it before the launch).  Lets a driver learn with one 4-byte read whether any env asked for
+                       Detector.train in this tick or ran a scan without a current forest.               */
 } cygym_outputs;
 
 typedef struct cygym_handle cygym_handle;
@@ -222,6 +234,28 @@ int cygym_rollout(cygym_handle* h, int32_t n_ticks, const cygym_actions* a, cons
  * CyberDefenseEnv.py:146-257.  role 0: full [N][6M]; 1: defender [N][6M];
  * 2: attacker [N][4M + MaxExploits].  out: DEVICE float32. */
 int cygym_observe(cygym_handle* h, int32_t role, float* out, void* stream);
+
+/* One strategy's chosen actions for n envs (single-action form), DEVICE pointers: what the reference's rollout loop
+ * builds per env as the tuple (action_type, [exploit], device_indices, app_index) from its actor's output
+ * (do_agent.decode_action, do_agent.py:253-262). */
+typedef struct cygym_action_rows {
+  const int32_t* rows;     /* [n] env ids (rows of the action tensors) to write; NULL = rows 0..n-1             */
+  const int32_t* atype;    /* [n]                                                                              */
+  const int32_t* exploit;  /* [n] one exploit index, -1 = none                                                 */
+  const int32_t* app;      /* [n] app_index                                                                    */
+  const uint8_t* dev_mask; /* [n][M] non-zero = device chosen: compacted to the ascending id list (first max_devs
+                              of them), or NULL: take dev_idx / dev_cnt                                        */
+  const int16_t* dev_idx;  /* [n][max_devs] device lists (when dev_mask == NULL)                               */
+  const int32_t* dev_cnt;  /* [n]                                                                              */
+  int32_t n;
+  int32_t reserved;
+} cygym_action_rows;
+
+/* Scatter `src` into group 0 of the rows src->rows of the action tensors `dst` (atype, n_exploit, exploit[.][0][0],
+ * app, dev_cnt, dev_idx -- list entries past the count are zeroed; mode and n_groups are not touched): ONE launch
+ * per strategy of a closed loop instead of one tensor op per field.  Replaces the per-env action-tuple assembly of
+ * the reference's loop (do_agent.py:206-265) for a batch. */
+int cygym_write_actions(cygym_handle* h, const cygym_action_rows* src, const cygym_actions* dst, void* stream);
 
 /* Synthetic action script of bench.py -- not a reference
  * interface: fills one tick's cygym_actions from Philox on device. */

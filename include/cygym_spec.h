@@ -104,6 +104,14 @@ enum {
 #define CG_MODE_ATTACKER 1
 #define CG_MODE_PARTIAL  0x100 /* OR-ed into mode: step(action, agent_cnt != len(net)) -- no workload advance,
                                   no arrivals, no step counters (volt_typhoon_env.py:1207, :1307) */
+/* env.base_line of THIS env for THIS tick, OR-ed into mode: bits 16..18 hold (baseline code + 1), 0 = use
+ * cygym_config.baseline.  The reference's rollout loops assign env.base_line per env and per turn (a baseline
+ * strategy sets it before its step, do_agent.py:218-221, and it stays set for the other role's turns:
+ * volt_typhoon_env.py:913-914 then turns every defender action into a no-op, :1126 skips the attacker). */
+#define CG_MODE_BASELINE_SHIFT 16
+#define CG_MODE_BASELINE(code) ((((code) & 3) + 1) << CG_MODE_BASELINE_SHIFT)
+#define CG_MODE_BASELINE_OF(mode, cfg_baseline) \
+  ((((mode) >> CG_MODE_BASELINE_SHIFT) & 7) ? ((((mode) >> CG_MODE_BASELINE_SHIFT) & 7) - 1) : (cfg_baseline))
 
 /* ---- comm-log ring ---- */
 #define CG_LOG_RING 32       /* entries kept per env (fast scan reads 30)  */
@@ -118,7 +126,8 @@ enum {
  *                    (sklearn _parallel_compute_tree_depths) -- S* is the smallest f64 sum for which
  *                    sklearn's own  -(2 ** -(s / (2 * apl[max_samples_]))) - offset_ < 0  is false; the host
  *                    finds it by bisection with the same numpy expressions, so the kernel needs no pow.
- *           [2]      node count of tree 0 | tree 1 << 16
+ *           [2]      node count of tree 0 | tree 1 << 16; 0 = no trees were ever installed (a scan in trained mode then
+ *                    answers all "D" and raises CG_E_UNPINNED, like a pending request)
  *           [3]      rng tick of the action-10 tick that asked for this training  (written by the tick)
  *           [4]      len(logger.logs) at that moment                              (written by the tick)
  *           [5]      rng tick whose request the installed forest answers          (written by the host)

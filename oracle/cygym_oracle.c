@@ -55,6 +55,7 @@ typedef struct {
   int isolate_iter;
   int scan_ord;
   int zeroday_occ;
+  int baseline; /* env.base_line of the tick in progress (config, or the override in the mode word) */
 } env_t;
 
 static uint32_t drw(const env_t* e, uint32_t site, uint32_t a, uint32_t b) {
@@ -261,7 +262,7 @@ static void def_per_device(env_t* e, int at, const int16_t* dev, int L, int app,
           int n_anom = 0;
           int fl = e->ienv[CG_I_FLAGS];
           int trained = (fl & CG_E_DET_TRAIN) && !(fl & CG_E_DET_RANDOM) && !e->c->turbo;
-          if (trained && (!e->forest || !e->t->det_apl || (fl & CG_E_DET_PENDING))) {
+          if (trained && (!e->forest || !e->t->det_apl || (fl & CG_E_DET_PENDING) || e->forest[2] == 0)) { /* [2] == 0: no trees were ever installed */
             e->ienv[CG_I_FLAGS] |= CG_E_UNPINNED; /* no current forest: all "D", flagged (cygym_spec.h) */
             trained = 0;
           }
@@ -364,7 +365,7 @@ static void attacker(env_t* e, int at, const int32_t* expl, int n_expl, double* 
   int n_src = 0;
   for (int d = 0; d < M; ++d)
     if (e->flags[d] & (CG_F_COMP | CG_F_OWNED)) srcs[n_src++] = d; /* :1127 snapshot */
-  if (e->c->baseline == 3) return; /* "No Attack" */
+  if (e->baseline == 3) return; /* "No Attack" */
   if (at == 1) {
     for (int j = 0; j < n_expl; ++j) {
       int raw = expl[j];
@@ -676,6 +677,32 @@ static void snapshot_restore(env_t* e, const cygym_buffers* snap, int idx);
 
 typedef struct { uint8_t* newly; uint8_t* occ; int* srcs; int* pu; int* pv; int* pr; int* cdf; ment_t* row; kid_t* tmp; } scratch_t;
 
+/* role 0: _get_state, 1: _get_defender_state, 2: _get_attacker_state (CyberDefenseEnv.py:146-257) */
+static void observe_one(env_t* e, int role, float* o) {
+  const int M = e->M;
+  const cygym_topology* t = e->t;
+  if (role == 0 || role == 1) {
+    write_obs(e, o);
+    if (role == 1) {
+      for (int d = 0; d < M; ++d) {
+        uint8_t f = e->flags[d];
+        if ((f & CG_F_NYA) || !(f & CG_F_OWNED)) for (int k = 0; k < 6; ++k) o[6 * d + k] = -1.f;
+        o[6 * d + 2] = -1.f;
+      }
+    }
+  } else {
+    for (int d = 0; d < M; ++d) {
+      uint8_t f = e->flags[d];
+      int vis = (f & CG_F_KNOWN) && !(f & CG_F_NYA) && (f & CG_F_OWNED);
+      o[4 * d + 0] = vis ? t->os_val[d] : -1.f;
+      o[4 * d + 1] = vis ? t->version[d] : -1.f;
+      o[4 * d + 2] = vis ? ((f & CG_F_COMP) ? 1.f : 0.f) : -1.f;
+      o[4 * d + 3] = vis ? ((f & CG_F_KNOWN) ? 1.f : 0.f) : -1.f;
+    }
+    for (int k = 0; k < e->c->max_exploits; ++k) o[4 * M + k] = (k < t->n_exploits) ? 1.f : 0.f;
+  }
+}
+
 static void step_one(env_t* e, const cygym_actions* a, const cygym_outputs* o, int idx, const scratch_t* sc,
                      const cygym_buffers* snap) {
   const int M = e->M;
@@ -694,6 +721,8 @@ static void step_one(env_t* e, const cygym_actions* a, const cygym_outputs* o, i
   e->tick = (uint32_t)e->ienv[CG_I_RNG_TICK];
   const int partial = (a->mode[idx] & CG_MODE_PARTIAL) != 0 && a->n_groups[idx] == 0; /* agent_cnt mismatch :1207 */
   const int mode = a->mode[idx] & 0xFF;
+  const int baseline = CG_MODE_BASELINE_OF(a->mode[idx], e->c->baseline); /* env.base_line of this env for this tick */
+  e->baseline = baseline;
   const int ng = a->n_groups[idx];
   if (ng < 0) return; /* this env does not tick */
   const int16_t* devs = a->dev_idx + (size_t)idx * L;
@@ -713,7 +742,7 @@ static void step_one(env_t* e, const cygym_actions* a, const cygym_outputs* o, i
       }
     }
     if (mode == CG_MODE_DEFENDER) {
-      if (e->c->baseline != 0) at = 8;
+      if (baseline != 0) at = 8;
       def_global(e, at, devs, Ld, &cost, &dirty, 0);
       if (at == 1 || at == 4 || at == 5 || at == 6 || at == 7 || at == 9 || at == 12 || at == 13)
         def_per_device(e, at, devs, Ld, a->app[(size_t)idx * G], &cost, &dirty, pu, pv, pr, row);
@@ -742,7 +771,7 @@ static void step_one(env_t* e, const cygym_actions* a, const cygym_outputs* o, i
       if (mode == CG_MODE_DEFENDER && at == 0) at = 8;
       else if (mode == CG_MODE_ATTACKER && at == 0) at = 3;
       if (mode == CG_MODE_DEFENDER) {
-        if (e->c->baseline != 0) at = 8;
+        if (baseline != 0) at = 8;
         def_global(e, at, dp, Ld, &cost, &dirty, 1);
         if (at == 1) def_per_device(e, 1, dp, Ld, -1, &cost, &dirty, pu, pv, pr, row);
       }
@@ -754,7 +783,7 @@ static void step_one(env_t* e, const cygym_actions* a, const cygym_outputs* o, i
     rewards(e, mode, cost, current_work, &raw, &shaped);
     e->ienv[CG_I_LAST_ATYPE] = -1;
   }
-  write_obs(e, o->obs + (size_t)idx * M * 6);
+  if (o->obs) write_obs(e, o->obs + (size_t)idx * M * 6);
   if (!partial) { /* :1307-1312 */
     e->ienv[CG_I_STEP_NUM] += 1;
     if (mode == CG_MODE_ATTACKER) e->ienv[CG_I_ATT_STEP] += 1; else e->ienv[CG_I_DEF_STEP] += 1;
@@ -771,6 +800,10 @@ static void step_one(env_t* e, const cygym_actions* a, const cygym_outputs* o, i
   o->shaped[idx] = shaped;
   o->done[idx] = (uint8_t)done;
   if (done && e->c->auto_reset && snap) snapshot_restore(e, snap, idx);
+  /* optional role views of the state the tick leaves behind (cygym_outputs.obs_def / obs_att) + the status word */
+  if (o->obs_def) observe_one(e, 1, o->obs_def + (size_t)idx * 6 * M);
+  if (o->obs_att) observe_one(e, 2, o->obs_att + (size_t)idx * (4 * M + e->c->max_exploits));
+  if (o->status) *o->status |= (uint32_t)e->ienv[CG_I_FLAGS] & (CG_E_TOPO_OVF | CG_E_BUSY_SAT | CG_E_DET_PENDING | CG_E_UNPINNED);
 }
 
 static void bind_env(env_t* e, const cygym_topology* t, const cygym_config* c, const cygym_buffers* b, int idx) {
@@ -880,28 +913,7 @@ int cgo_observe(const cygym_topology* t, const cygym_config* c, const cygym_buff
   for (int i = 0; i < n_envs; ++i) {
     env_t e;
     bind_env(&e, t, c, b, i);
-    if (role == 0 || role == 1) {
-      float* o = out + (size_t)i * 6 * M;
-      write_obs(&e, o);
-      if (role == 1) {
-        for (int d = 0; d < M; ++d) {
-          uint8_t f = e.flags[d];
-          if ((f & CG_F_NYA) || !(f & CG_F_OWNED)) for (int k = 0; k < 6; ++k) o[6 * d + k] = -1.f;
-          o[6 * d + 2] = -1.f;
-        }
-      }
-    } else {
-      float* o = out + (size_t)i * (4 * M + c->max_exploits);
-      for (int d = 0; d < M; ++d) {
-        uint8_t f = e.flags[d];
-        int vis = (f & CG_F_KNOWN) && !(f & CG_F_NYA) && (f & CG_F_OWNED);
-        o[4 * d + 0] = vis ? t->os_val[d] : -1.f;
-        o[4 * d + 1] = vis ? t->version[d] : -1.f;
-        o[4 * d + 2] = vis ? ((f & CG_F_COMP) ? 1.f : 0.f) : -1.f;
-        o[4 * d + 3] = vis ? ((f & CG_F_KNOWN) ? 1.f : 0.f) : -1.f;
-      }
-      for (int k = 0; k < c->max_exploits; ++k) o[4 * M + k] = (k < t->n_exploits) ? 1.f : 0.f;
-    }
+    observe_one(&e, role, out + (size_t)i * (role == 2 ? 4 * M + c->max_exploits : 6 * M));
   }
   return CYGYM_OK;
 }

@@ -1,0 +1,83 @@
+"""Shared by the grid-consumer tests (CPU and GPU): the oracle behind the batch surface simulate_grid / payoff_grid
+use, and an exact integer-weight closed-loop policy."""
+import numpy as np
+import torch
+
+from cygym_amd import spec as S
+
+
+class OracleGrid:
+    """The oracle behind the members simulate_grid / payoff_grid use of a batch (CPU tensors over its arrays).  It has
+    neither fused role views nor the fused action scatter: the loop then takes its observe() / torch fallbacks, so the
+    product's fused paths are checked against the plain ones.  Detector.train is answered with scikit-learn on the
+    oracle's own history ring (cygym_amd.detector.fit_forest) -- the reference's estimator, the request's seed."""
+
+    def __init__(self, topo, cfg, N, init, G, L, detector=False):
+        from oracle import driver as od
+        self.ob = od.OracleBatch(topo, cfg, N, detector=detector)
+        self.init, self.cfg, self.detector = init, cfg, detector
+        self.N, self.M, self.L = N, topo.M, L
+        self.act_np = od.alloc_actions(N, G, L)
+        self.act = {k: torch.from_numpy(v) for k, v in self.act_np.items()}   # shared memory
+        self.obs = torch.zeros(1)
+        self.fitted = 0
+        self.reset()
+
+    def reset(self):
+        self.ob.load_state(self.init)
+
+    def randomize(self):
+        self.ob.randomize()
+
+    def observe(self, role):
+        return torch.from_numpy(self.ob.observe(role))
+
+    def step(self):
+        obs, raw, shaped, done = self.ob.step(self.act_np)
+        return torch.from_numpy(obs), torch.from_numpy(raw.copy()), torch.from_numpy(shaped.copy()), torch.from_numpy(done.copy())
+
+    def take_status(self):
+        return int(np.bitwise_or.reduce(self.ob.state["ienv"][:, S.I_FLAGS]) & (S.E_TOPO_OVF | S.E_BUSY_SAT | S.E_DET_PENDING | S.E_UNPINNED))
+
+    def unpinned_envs(self):
+        return int(((self.ob.state["ienv"][:, S.I_FLAGS] & S.E_UNPINNED) != 0).sum())
+
+    def service_detectors(self):
+        from cygym_amd import detector as D
+        st = self.ob.state
+        for e in np.nonzero(st["ienv"][:, S.I_FLAGS] & S.E_DET_PENDING)[0]:
+            hdr = st["forest"][e]
+            rows = D.training_window(st["hist"][e], int(hdr[4]), bool(self.cfg.turbo), self.cfg.turbo_train_max_logs, self.cfg.turbo_train_stride)
+            self.ob.install_forest(e, D.fit_forest(rows, D.fit_seed(self.cfg.seed, self.cfg.env_id_base + int(e), int(hdr[3])), n_fits=int(hdr[6])))
+            self.fitted += 1
+
+
+class IntPolicy:
+    """Closed-loop test policy: integer weights in {-1, 0, 1}, ReLU, argmax with an index tie-break -- all values are
+    integers far below 2^24, so float32 arithmetic is exact on every device."""
+
+    def __init__(self, role, M, types, seed):
+        rs = np.random.RandomState(seed)
+        self.role, self.M, self.types = role, M, list(types)
+        self.action_types = self.types
+        self.F = 6 if role == "defender" else 4
+        self.w_dev = torch.tensor(rs.randint(-1, 2, size=(self.F,)), dtype=torch.float32)           # per-device score
+        self.w_hid = torch.tensor(rs.randint(-1, 2, size=(self.F * M, 8)), dtype=torch.float32)
+        self.w_out = torch.tensor(rs.randint(-1, 2, size=(8, len(self.types))), dtype=torch.float32)
+        self.mod = int(rs.randint(3, 8))
+
+    def __call__(self, obs, t, M, L):
+        dev = obs.device
+        x = obs[:, : self.F * M]
+        h = torch.relu(x @ self.w_hid.to(dev))
+        logits = h @ self.w_out.to(dev)
+        key = logits * 16 + torch.arange(len(self.types), device=dev, dtype=torch.float32)      # unique maximum
+        atype = torch.tensor(self.types, dtype=torch.int32, device=dev)[torch.argmax(key, dim=1)]
+        score = (x.reshape(-1, M, self.F) * self.w_dev.to(dev)).sum(dim=2) + (t % 5)
+        mask = (torch.remainder(score, self.mod) == 0)
+        if self.role == "defender":
+            mask = mask & (x.reshape(-1, M, self.F)[:, :, 5] != 1)       # skip rows that say "not yet added"
+        expl = torch.remainder(h.sum(dim=1), 3).to(torch.int32) - 1                               # -1, 0 or 1
+        return {"atype": atype, "exploit": expl, "dev_mask": mask, "app": torch.remainder(h[:, 0], 4).to(torch.int32)}
+
+

@@ -45,7 +45,8 @@ def test_hip_matches_reference_fixture(name, detector):
     for t in range(fx.T):
         fx.actions(t, act, flags=env.state["flags"].cpu().numpy())
         env.set_actions_numpy(act)
-        obs, raw, shaped, done = env.step()
+        view = "defender" if t % 2 else "attacker"      # the fused role view of the state the tick leaves behind
+        obs, raw, shaped, done = env.step(view=view)
         if fx.det_events.get(t):   # the host's part of Detector.train, with the forest the reference fitted
             fx.service_detectors(t, env.state_numpy(), env.install_forest)
         got = env.state_numpy()
@@ -70,6 +71,8 @@ def test_hip_matches_reference_fixture(name, detector):
         np.testing.assert_allclose(raw.cpu().numpy()[sel], fx.exp["raw"][sel, t], rtol=0, atol=1e-9)
         np.testing.assert_allclose(shaped.cpu().numpy()[sel], fx.exp["shaped"][sel, t], rtol=0, atol=1e-9)
         np.testing.assert_array_equal(done.cpu().numpy()[sel], fx.exp["done"][sel, t])
+        np.testing.assert_array_equal(env.role_obs[view].cpu().numpy()[sel], fx.exp["obs_def" if view == "defender" else "obs_att"][sel, t],
+                                      err_msg=f"{name} fused {view} view t={t}")
         if t % 7 == 0:
             np.testing.assert_array_equal(env.observe(1).cpu().numpy()[sel], fx.exp["obs_def"][sel, t])
             np.testing.assert_array_equal(env.observe(2).cpu().numpy()[sel], fx.exp["obs_att"][sel, t])

@@ -4,6 +4,7 @@ the reference's own env objects -- runs in the oracle harness, which exports eve
 from types import SimpleNamespace as NS
 
 import numpy as np
+import pytest
 
 from cygym_amd import interchange as I
 from cygym_amd import spec as S
@@ -64,3 +65,42 @@ def test_from_reference_env_reads_the_attribute_surface():
     assert kw["comp_scale"] == 30.0 and kw["n_att_actions"] == 4 and kw["baseline"] == "Nash" and kw["workload_cap"] == -1
     from cygym_amd import abi
     abi.EnvConfig(seed=1, **kw).to_c()       # the keyword dict is a valid EnvConfig
+
+
+def test_trained_detector_travels_with_the_env():
+    """A reference env whose Detector is trained is exported WITH its forest (flattened, node counts in header word 2),
+    so the first scan of the re-hosted env walks the trees instead of an all-zero buffer; and a DET_TRAIN env that
+    arrives without trees (word 2 == 0) is answered all-"D" with CG_E_UNPINNED, never with node-0 loops."""
+    sklearn = pytest.importorskip("sklearn")
+    import warnings
+    from sklearn.ensemble import IsolationForest
+    from cygym_amd import abi
+    from cygym_amd import detector as D
+    from oracle import driver as od
+    env = _fake_env()
+    X = [[0, 1], [0, 2], [1, 0], [2, 3], [0, 3], [0, 1], [0, 2]] * 3
+    model = IsolationForest(n_estimators=2, max_samples=256, n_jobs=1, random_state=np.random.RandomState(5))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model.fit(X)
+    env.simulator.detector = NS(trained=True, random_detection=False, model=model)
+    env.simulator.logger = NS(logs=[{"from_device": a, "to_device": b} for a, b in X])
+    topo, init, kw = I.from_reference_env(env)
+    fo = init["forest"][0]
+    np.testing.assert_array_equal(fo, D.flatten_forest(model))
+    assert fo[2] != 0 and (init["ienv"][0, S.I_FLAGS] & S.E_DET_TRAIN)
+    pts = [(a, b) for a in range(4) for b in range(4)]
+    np.testing.assert_array_equal(D.predict_flat(fo, pts), model.predict(np.array(pts)) == -1)
+    cfg = abi.EnvConfig(seed=1, **kw)
+    act = od.alloc_actions(1, 1, 4)
+    act["mode"][:] = S.MODE_DEFENDER; act["atype"][:] = 5; act["dev_cnt"][:] = 2; act["dev_idx"][0, :2] = [0, 1]
+    ob = od.OracleBatch(topo, cfg, 1, detector=True)
+    ob.load_state(init)
+    ob.step(act)
+    assert not (ob.state["ienv"][0, S.I_FLAGS] & S.E_UNPINNED)
+    bare = dict(init); bare["forest"] = np.zeros_like(init["forest"])
+    ob.load_state(bare)
+    keep = ob.state["flags"].copy()
+    ob.step(act)
+    assert ob.state["ienv"][0, S.I_FLAGS] & S.E_UNPINNED
+    np.testing.assert_array_equal(ob.state["flags"][0] & S.F_COMP, keep[0] & S.F_COMP)     # all "D": nobody flagged

@@ -16,59 +16,7 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
-class OracleGrid:
-    """The oracle behind the few members simulate_grid / payoff_grid use of a batch (CPU tensors over its arrays)."""
-
-    def __init__(self, topo, cfg, N, init, G, L):
-        from oracle import driver as od
-        self.ob = od.OracleBatch(topo, cfg, N)
-        self.init = init
-        self.N, self.M, self.L = N, topo.M, L
-        self.act_np = od.alloc_actions(N, G, L)
-        self.act = {k: torch.from_numpy(v) for k, v in self.act_np.items()}   # shared memory
-        self.obs = torch.zeros(1)
-        self.reset()
-
-    def reset(self):
-        self.ob.load_state(self.init)
-
-    def randomize(self):
-        self.ob.randomize()
-
-    def observe(self, role):
-        return torch.from_numpy(self.ob.observe(role))
-
-    def step(self):
-        obs, raw, shaped, done = self.ob.step(self.act_np)
-        return torch.from_numpy(obs), torch.from_numpy(raw.copy()), torch.from_numpy(shaped.copy()), torch.from_numpy(done.copy())
-
-
-class IntPolicy:
-    """Closed-loop test policy: integer weights in {-1, 0, 1}, ReLU, argmax with an index tie-break -- all values are
-    integers far below 2^24, so float32 arithmetic is exact on every device."""
-
-    def __init__(self, role, M, types, seed):
-        rs = np.random.RandomState(seed)
-        self.role, self.M, self.types = role, M, list(types)
-        self.F = 6 if role == "defender" else 4
-        self.w_dev = torch.tensor(rs.randint(-1, 2, size=(self.F,)), dtype=torch.float32)           # per-device score
-        self.w_hid = torch.tensor(rs.randint(-1, 2, size=(self.F * M, 8)), dtype=torch.float32)
-        self.w_out = torch.tensor(rs.randint(-1, 2, size=(8, len(self.types))), dtype=torch.float32)
-        self.mod = int(rs.randint(3, 8))
-
-    def __call__(self, obs, t, M, L):
-        dev = obs.device
-        x = obs[:, : self.F * M]
-        h = torch.relu(x @ self.w_hid.to(dev))
-        logits = h @ self.w_out.to(dev)
-        key = logits * 16 + torch.arange(len(self.types), device=dev, dtype=torch.float32)      # unique maximum
-        atype = torch.tensor(self.types, dtype=torch.int32, device=dev)[torch.argmax(key, dim=1)]
-        score = (x.reshape(-1, M, self.F) * self.w_dev.to(dev)).sum(dim=2) + (t % 5)
-        mask = (torch.remainder(score, self.mod) == 0)
-        if self.role == "defender":
-            mask = mask & (x.reshape(-1, M, self.F)[:, :, 5] != 1)       # skip rows that say "not yet added"
-        expl = torch.remainder(h.sum(dim=1), 3).to(torch.int32) - 1                               # -1, 0 or 1
-        return {"atype": atype, "exploit": expl, "dev_mask": mask, "app": torch.remainder(h[:, 0], 4).to(torch.int32)}
+from grid_util import IntPolicy, OracleGrid  # noqa: E402
 
 
 def _setup(M=64, n_mc=3):
@@ -123,6 +71,156 @@ def test_closed_loop_grid_equals_the_oracle_loop():
         np.testing.assert_array_equal(batch.act[k].cpu().numpy(), og.act_np[k], err_msg=k)
     assert len(np.unique(np.round(U_def, 6))) > 3, "the strategies must actually differ in payoff"
     batch.close()
+
+
+def test_closed_loop_grid_trains_and_scans_like_the_oracle_loop():
+    """Policies that emit defender action 10 (Detector.train) and 5 (scan): the loop services the trainings after the
+    tick that asked (the reference trains inside the tick, volt_typhoon_env.py:961), later scans walk the forests,
+    and payoffs / final state equal the oracle loop that fits with scikit-learn on its own history ring."""
+    pytest.importorskip("sklearn")
+    from cygym_amd.batched_env import BatchedCyberDefenseEnv
+    from cygym_amd.rollout_grid import simulate_grid
+    topo, init, cfg = _setup()
+    M, T, n_mc, L = topo.M, 60, 3, 16
+    D = [IntPolicy("defender", M, [10, 5, 5, 1, 10, 5], 11), IntPolicy("defender", M, [5, 10, 6, 9, 5, 13, 8], 12),
+         [(10, [0], [], 0), (8, [0], [], 0), (5, [0], [3, 9, 17], 0)]]
+    A = [IntPolicy("attacker", M, [1, 1, 2], 13), [(1, [0], [], 0)]]
+    N = len(D) * len(A) * n_mc
+    batch = BatchedCyberDefenseEnv(topo, cfg, N, init, device="cuda:0", max_groups=1, max_devs=L, detector=True)
+    U_def, U_att = simulate_grid(batch, D, A, n_mc, T, randomize=True)
+    og = OracleGrid(topo, cfg, N, init, 1, L, detector=True)
+    E_def, E_att = simulate_grid(og, D, A, n_mc, T, randomize=True)
+    assert og.fitted > N, "the strategies must actually train (and retrain) their detectors"
+    np.testing.assert_allclose(U_def, E_def, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(U_att, E_att, rtol=0, atol=1e-9)
+    got = batch.state_numpy()
+    got["ienv"] = got["ienv"].copy(); got["ienv"][:, S.I_FLAGS] &= ~0x80
+    assert not gio.compare_state(got, og.ob.state, "simulate_grid + detector")
+    np.testing.assert_array_equal(got["forest"], og.ob.state["forest"])
+    fl = got["ienv"][:, S.I_FLAGS]
+    assert (fl & S.E_DET_TRAIN).sum() > N // 2 and not (fl & (S.E_UNPINNED | S.E_DET_PENDING)).any()
+    assert int(got["ienv"][:, S.I_SCAN_CNT].sum()) > 0
+    batch.close()
+    # the same strategies on a batch that cannot fit forests are refused up front, not answered with all-"D" scans
+    plain = BatchedCyberDefenseEnv(topo, cfg, N, init, device="cuda:0", max_groups=1, max_devs=L)
+    with pytest.raises(ValueError, match="detector=True"):
+        simulate_grid(plain, D, A, n_mc, 4)
+    plain.close()
+
+
+def test_open_loop_script_with_trainings_is_cut_or_refused():
+    """payoff_grid / rollout() with defender action 10 followed by scans: on a detector batch the fused launch is cut
+    after every training tick and serviced (== the oracle loop); without detector buffers it raises."""
+    pytest.importorskip("sklearn")
+    from cygym_amd import _lib
+    from cygym_amd.batched_env import BatchedCyberDefenseEnv
+    from cygym_amd.rollout_grid import payoff_grid, simulate_grid
+    topo, init, cfg = _setup()
+    T, n_mc = 30, 4
+    D = [[(10, [0], [], 0), (5, [0], [3, 9, 17], 0), (5, [0], [1], 0), (1, [0], [2, 4], 0), (5, [0], [7, 8], 0)], "No Defense"]
+    A = [[(1, [0], [], 0)], [(1, [1], [], 0), (2, [0], [], 0)]]
+    N = len(D) * len(A) * n_mc
+    batch = BatchedCyberDefenseEnv(topo, cfg, N, init, device="cuda:0", max_groups=1, max_devs=8, detector=True)
+    U_def, U_att = payoff_grid(batch, D, A, n_mc, T, randomize=True)
+    og = OracleGrid(topo, cfg, N, init, 1, 8, detector=True)
+    E_def, E_att = simulate_grid(og, D, A, n_mc, T, randomize=True)
+    assert og.fitted >= 2 * n_mc
+    np.testing.assert_allclose(U_def, E_def, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(U_att, E_att, rtol=0, atol=1e-9)
+    got = batch.state_numpy()
+    got["ienv"] = got["ienv"].copy(); got["ienv"][:, S.I_FLAGS] &= ~0x80
+    assert not gio.compare_state(got, og.ob.state, "payoff_grid + detector")
+    np.testing.assert_array_equal(got["forest"], og.ob.state["forest"])
+    batch.close()
+    plain = BatchedCyberDefenseEnv(topo, cfg, N, init, device="cuda:0", max_groups=1, max_devs=8)
+    with pytest.raises(_lib.CygymError, match="without a current forest"):
+        payoff_grid(plain, D, A, n_mc, T, randomize=True)
+    plain.close()
+
+
+def test_baseline_names_persist_for_the_other_role():
+    """env.base_line is assigned by a baseline strategy before its step and stays for the other role's turns
+    (do_agent.py:218-221): against a "No Attack" attacker a scripted defender is a no-op from its second turn on
+    (volt_typhoon_env.py:913-914).  Checked on the schedule itself and against the oracle loop."""
+    from cygym_amd.batched_env import BatchedCyberDefenseEnv
+    from cygym_amd.rollout_grid import baseline_schedule, payoff_grid, simulate_grid
+    D = [[(7, [0], [5, 6], 0), (1, [0], [3], 0)], "No Defense"]
+    A = ["No Attack", [(1, [0], [], 0)]]
+    sch = baseline_schedule(D, A, np.arange(4), 1, 5, 0)
+    np.testing.assert_array_equal(sch[:, 0], [0, 3, 3, 3, 3])      # scripted defender x "No Attack"
+    np.testing.assert_array_equal(sch[:, 1], [0, 0, 0, 0, 0])      # scripted x scripted: stays "Nash"
+    np.testing.assert_array_equal(sch[:, 2], [1, 3, 1, 3, 1])      # "No Defense" x "No Attack": each sets its own
+    np.testing.assert_array_equal(sch[:, 3], [1, 1, 1, 1, 1])
+    topo, init, cfg = _setup()
+    T, n_mc = 12, 2
+    N = len(D) * len(A) * n_mc
+    batch = BatchedCyberDefenseEnv(topo, cfg, N, init, device="cuda:0", max_groups=1, max_devs=8)
+    U_def, U_att = payoff_grid(batch, D, A, n_mc, T, randomize=False)
+    flags = batch.state_numpy()["flags"]
+    # cell (0, 0): the removal of devices 5, 6 happens at t = 0 only (base_line still "Nash"); the clean of device 3 at
+    # t = 2 is already a no-op; cell (0, 1) keeps executing its script
+    og = OracleGrid(topo, cfg, N, init, 1, 8)
+    E_def, E_att = simulate_grid(og, D, A, n_mc, T, randomize=False)
+    np.testing.assert_allclose(U_def, E_def, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(U_att, E_att, rtol=0, atol=1e-9)
+    np.testing.assert_array_equal(flags, og.ob.state["flags"])
+    C_def, C_att = simulate_grid(batch, D, A, n_mc, T, randomize=False)       # the closed-loop path agrees
+    np.testing.assert_allclose(C_def, E_def, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(C_att, E_att, rtol=0, atol=1e-9)
+    batch.close()
+
+
+def test_fused_role_views_status_word_and_action_scatter():
+    """cygym_step's optional role views equal cygym_observe after the tick; obs == NULL leaves the full observation
+    alone; the status word reports pending trainings; cygym_write_actions equals the per-field torch scatter."""
+    from cygym_amd.batched_env import BatchedCyberDefenseEnv
+    from cygym_amd.rollout_grid import mask_to_list
+    for M, blocks, N in ((64, 4, 200), (256, 1, 130), (37, 2, 64)):
+        from cygym_amd.topology import make_topology
+        topo, init, ck = make_topology(M, blocks, seed=4, n_active=max(8, M - 8))
+        cfg = abi.EnvConfig(seed=4, **ck)
+        L = max(1, M // 8)
+        env = BatchedCyberDefenseEnv(topo, cfg, N, init, device="cuda:0", max_groups=1, max_devs=L, detector=(M == 64))
+        for t in range(30):
+            env.gen_actions(t)
+            role = "attacker" if t % 2 == 0 else "defender"     # the NEXT actor
+            keep = env.obs.clone()
+            env.step(view=role, full_obs=(t % 3 != 0))
+            np.testing.assert_array_equal(env.role_obs[role].cpu().numpy(), env.observe(1 if role == "defender" else 2).cpu().numpy(),
+                                          err_msg=f"M={M} t={t} {role} view")
+            if t % 3 == 0:
+                assert torch.equal(env.obs, keep), "obs == NULL must not be written"
+        if M == 64:     # action 10 on a non-empty log raises DET_PENDING in the status word until serviced
+            env.take_status()
+            env.act["mode"].fill_(S.MODE_DEFENDER); env.act["atype"].fill_(10); env.act["dev_cnt"].zero_()
+            env.step()
+            assert env.take_status() & S.E_DET_PENDING
+            assert env.service_detectors() > 0
+            env.act["atype"].fill_(8)
+            env.step()
+            assert not (env.take_status() & S.E_DET_PENDING)
+        # fused scatter vs torch
+        g = torch.Generator(device="cpu").manual_seed(M)
+        rows = torch.randperm(N, generator=g)[: N // 2].sort().values.to("cuda:0")
+        n = rows.numel()
+        a = {"atype": torch.randint(0, 14, (n,), generator=g).to("cuda:0", torch.int32),
+             "exploit": (torch.randint(0, 4, (n,), generator=g) - 1).to("cuda:0", torch.int32),
+             "app": torch.randint(0, 4, (n,), generator=g).to("cuda:0", torch.int32),
+             "dev_mask": (torch.rand((n, M), generator=g) < 0.2).to("cuda:0")}
+        before = {k: v.clone() for k, v in env.act.items()}
+        env.write_actions(rows, a)
+        idx, cnt = mask_to_list(a["dev_mask"], L)
+        exp = before
+        exp["atype"][rows, 0] = a["atype"]; exp["exploit"][rows, 0, 0] = a["exploit"]; exp["n_exploit"][rows, 0] = (a["exploit"] >= 0).to(torch.int32)
+        exp["app"][rows, 0] = a["app"]; exp["dev_cnt"][rows, 0] = cnt; exp["dev_idx"][rows] = idx
+        for k in exp:
+            assert torch.equal(env.act[k], exp[k]), f"M={M} write_actions {k}"
+        b = {"atype": a["atype"], "exploit": a["exploit"], "app": a["app"], "dev_idx": idx.flip(1).contiguous(), "dev_cnt": cnt}
+        env.write_actions(rows, b)
+        want = idx.flip(1)
+        want = torch.where(torch.arange(L, device=want.device)[None, :] < cnt[:, None], want, torch.zeros_like(want))
+        assert torch.equal(env.act["dev_idx"][rows], want)
+        env.close()
 
 
 def test_view_step_cost_does_not_grow_with_the_batch():
