@@ -14,9 +14,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.environ.get("CYGYM_SO") or os.path.join(HERE, "libcygym_hip.so")   # CYGYM_SO: A/B a different build
 
 EXPORTS = [
-    "cygym_version", "cygym_last_error", "cygym_create", "cygym_destroy", "cygym_set_config", "cygym_bind", "cygym_derive",
+    "cygym_version", "cygym_sizeof", "cygym_last_error", "cygym_create", "cygym_destroy", "cygym_set_config", "cygym_bind", "cygym_derive",
     "cygym_set_snapshot", "cygym_reset", "cygym_randomize", "cygym_step", "cygym_step_range", "cygym_rollout", "cygym_observe",
-    "cygym_gen_actions", "cygym_write_actions",
+    "cygym_gen_actions", "cygym_write_actions", "cygym_decode_actions", "cygym_actor_head_decode",
     "cygym_timer_start", "cygym_timer_stop",
 ]
 
@@ -56,11 +56,17 @@ def load():
     L.cygym_rollout.argtypes = [H, C.c_int32, C.POINTER(abi.Actions), C.POINTER(abi.Outputs), C.c_void_p]
     L.cygym_observe.argtypes = [H, C.c_int32, C.c_void_p, C.c_void_p]
     L.cygym_write_actions.argtypes = [H, C.POINTER(abi.ActionRows), C.POINTER(abi.Actions), C.c_void_p]
+    L.cygym_decode_actions.argtypes = [H, C.POINTER(abi.ActionVectors), C.POINTER(abi.Actions), C.c_void_p]
+    L.cygym_actor_head_decode.argtypes = [H, C.POINTER(abi.ActorHead), C.POINTER(abi.ActionVectors), C.POINTER(abi.Actions), C.c_void_p]
     L.cygym_gen_actions.argtypes = [H, C.c_int32] + [C.c_void_p] * 8 + [C.c_int32, C.c_void_p]
     L.cygym_timer_start.argtypes = [H, C.c_void_p]
     L.cygym_timer_stop.argtypes = [H, C.c_void_p, C.POINTER(C.c_float)]
     if L.cygym_version() != abi.ABI_VERSION:
         raise CygymError(f"ABI mismatch: library {L.cygym_version()} vs python {abi.ABI_VERSION}")
+    L.cygym_sizeof.argtypes = [C.c_int32]
+    for which, st in enumerate((abi.Topology, abi.Config, abi.Buffers, abi.Actions, abi.Outputs, abi.ActionRows, abi.ActionVectors, abi.ActorHead)):
+        if L.cygym_sizeof(which) != C.sizeof(st):
+            raise CygymError(f"ABI struct {st.__name__}: library {L.cygym_sizeof(which)} bytes vs python {C.sizeof(st)}")
     _lib = L
     return L
 

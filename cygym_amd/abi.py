@@ -71,7 +71,8 @@ class Actions(C.Structure):
 
 class Outputs(C.Structure):
     _fields_ = [("obs", C.c_void_p), ("raw", C.c_void_p), ("shaped", C.c_void_p), ("done", C.c_void_p),
-                ("obs_def", C.c_void_p), ("obs_att", C.c_void_p), ("status", C.c_void_p)]
+                ("obs_def", C.c_void_p), ("obs_att", C.c_void_p), ("ret", C.c_void_p), ("alive", C.c_void_p),
+                ("status", C.c_void_p)]
 
 
 class ActionRows(C.Structure):
@@ -79,6 +80,19 @@ class ActionRows(C.Structure):
                 ("dev_mask", C.c_void_p), ("dev_idx", C.c_void_p), ("dev_cnt", C.c_void_p),
                 ("n", C.c_int32), ("reserved", C.c_int32)]
 
+
+class ActionVectors(C.Structure):
+    _fields_ = [("rows", C.c_void_p), ("vec", C.c_void_p), ("type_map", C.c_void_p), ("stride", C.c_int32),
+                ("n_types", C.c_int32), ("n_devices", C.c_int32), ("n_exploits", C.c_int32), ("n_apps", C.c_int32),
+                ("n", C.c_int32), ("epsilon_thr", C.c_uint64), ("status", C.c_void_p)]
+
+
+class ActorHead(C.Structure):
+    _fields_ = [("hidden", C.c_void_p), ("weight_t", C.c_void_p), ("bias", C.c_void_p), ("H", C.c_int32),
+                ("hidden_stride", C.c_int32), ("tanh_out", C.c_int32), ("weight_pitch", C.c_int32)]
+
+
+DECODE_TRUNCATED = 0x10000
 
 BASELINES = {"Nash": 0, "No Defense": 1, "Preset": 2, "No Attack": 3}
 

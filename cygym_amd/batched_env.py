@@ -135,6 +135,7 @@ class BatchedCyberDefenseEnv:
         # one status word per batch: the kernels OR in the sticky / pending bits of the envs they tick
         # (cygym_outputs.status); take_status() reads and clears it
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.ret = self.alive = None   # episode-return accumulators of step(returns=True), see reset_returns()
         self.role_obs = {}     # "defender" / "attacker" -> [N, W] float32 role view written by step(view=...)
         self._outs = {}        # (view, full_obs) -> abi.Outputs
         self._out = self._outputs(None, True)
@@ -284,12 +285,16 @@ class BatchedCyberDefenseEnv:
             return 4 * self.M + self.cfg.max_exploits
         raise ValueError("role must be 'attacker' or 'defender'")
 
-    def _outputs(self, view, full_obs) -> abi.Outputs:
-        """The cygym_outputs struct for one (role view, full observation) combination; cached."""
-        key = (view, bool(full_obs))
+    def _outputs(self, view, full_obs, returns=False) -> abi.Outputs:
+        """The cygym_outputs struct for one (role view, full observation, return accumulation) combination; cached."""
+        key = (view, bool(full_obs), bool(returns))
         o = self._outs.get(key)
         if o is None:
             o = abi.Outputs()
+            if returns:
+                if self.ret is None:
+                    self.reset_returns()
+                o.ret, o.alive = self.ret.data_ptr(), self.alive.data_ptr()
             o.obs = self.obs.data_ptr() if full_obs else None
             o.raw, o.shaped, o.done = self.raw.data_ptr(), self.shaped.data_ptr(), self.done.data_ptr()
             o.status = self.status.data_ptr()
@@ -300,16 +305,28 @@ class BatchedCyberDefenseEnv:
             self._outs[key] = o
         return o
 
-    def step(self, act=None, view: str | None = None, full_obs: bool = True):
+    def reset_returns(self):
+        """Start a new rollout of every env: zero the episode-return accumulators ([N, 2] f64: defender, attacker reward
+        sums) and mark every env alive (step(returns=True) adds to them until the env's first done, do_agent.py:266-274)."""
+        if self.ret is None:
+            self.ret = torch.zeros((self.N, 2), dtype=torch.float64, device=self.device)
+            self.alive = torch.ones(self.N, dtype=torch.uint8, device=self.device)
+        else:
+            self.ret.zero_()
+            self.alive.fill_(1)
+
+    def step(self, act=None, view: str | None = None, full_obs: bool = True, returns: bool = False):
         """One tick for every env.  `act`: dict of device tensors shaped like self.act (default: self.act).
         Returns (obs [N,M,6] f32, raw [N] f64, shaped [N] f64, done [N] u8) -- views of reused buffers.
 
         view = "defender" / "attacker": the tick also writes that role's view of the state it leaves behind into
         self.role_obs[view] ([N, 6M] / [N, 4M + MaxExploits]) -- what `_get_defender_state()` / `_get_attacker_state()`
         return before the role's next action -- so a closed loop needs no observe() launch between ticks.
-        full_obs=False: the [N, M, 6] full observation is not written (`obs` then holds an older tick's)."""
+        full_obs=False: the [N, M, 6] full observation is not written (`obs` then holds an older tick's).
+        returns=True: the tick also adds its raw reward to self.ret[:, role] for every env that has not reported done
+        since reset_returns() (the `def_total` / `att_total` sums of the reference's loop), in the kernel."""
         a = self.actions_struct(act)
-        o = self._out if (view is None and full_obs) else self._outputs(view, full_obs)
+        o = self._out if (view is None and full_obs and not returns) else self._outputs(view, full_obs, returns)
         _lib.check(self.lib.cygym_step(self._h, C.byref(a), C.byref(o), self._stream()), self._h, "cygym_step")
         return self.obs, self.raw, self.shaped, self.done
 
@@ -357,6 +374,103 @@ class BatchedCyberDefenseEnv:
         _lib.check(self.lib.cygym_write_actions(self._h, C.byref(src), C.byref(dst), self._stream()), self._h, "cygym_write_actions")
         # (`keep` may die here: the caching allocator only reuses the blocks for work enqueued later on this stream)
 
+    def decode_actions(self, rows, vec: torch.Tensor, n_types: int, n_exploits: int | None = None, n_apps: int = 0,
+                       type_map: torch.Tensor | None = None, act=None, epsilon: float = 0.0):
+        """DoubleOracle.decode_action (do_agent.py:935-998, plain branch) for a batch, fused with the scatter into the
+        action tensors: `vec` [n, >= n_types + M + n_exploits + n_apps] float32 actor outputs (type logits | device
+        values | exploit values | app values) -> rows `rows` of `act` (group 0): atype = argmax (through `type_map`
+        [n_types] int32 when given), device list = ascending ids with value > 0, exploit = [argmax], app = argmax.
+        ONE launch (cygym_decode_actions).  A row that chooses more devices than max_devs holds is cut to the first
+        max_devs ids and raises abi.DECODE_TRUNCATED in the batch's status word.  epsilon > 0: with that probability
+        an env's action type is uniformly random instead (the reference's epsilon-greedy, do_agent.py:972-973; the draw
+        is addressed by the env's current rng tick, site CG_SITE_EPS_TYPE)."""
+        act = self.act if act is None else act
+        dst = self.actions_struct(act)
+        if vec.dtype != torch.float32 or vec.dim() != 2 or vec.device != self.device or vec.stride(1) != 1:
+            raise ValueError("vec must be a [n, width] float32 tensor on the batch's device with unit inner stride")
+        n_exploits = self.cfg.max_exploits if n_exploits is None else int(n_exploits)
+        n = int(vec.shape[0])
+        if int(vec.shape[1]) < n_types + self.M + n_exploits + n_apps:
+            raise ValueError("vec rows are narrower than n_types + n_devices + n_exploits + n_apps")
+        src = abi.ActionVectors()
+        src.vec, src.stride = vec.data_ptr(), int(vec.stride(0))
+        src.n_types, src.n_devices, src.n_exploits, src.n_apps, src.n = int(n_types), self.M, n_exploits, int(n_apps), n
+        src.status = self.status.data_ptr()
+        if epsilon > 0.0:
+            from . import rng as R
+            src.epsilon_thr = R.bernoulli_threshold(float(epsilon))
+        keep = [vec]
+        if rows is not None:
+            r = rows if (rows.dtype == torch.int32 and rows.is_contiguous()) else rows.to(torch.int32).contiguous()
+            if int(r.shape[0]) != n or r.device != self.device:
+                raise ValueError("rows must be a device tensor as long as vec")
+            keep.append(r)
+            src.rows = r.data_ptr()
+        elif n > self.N:
+            raise ValueError("more action rows than envs")
+        if type_map is not None:
+            tm = type_map if (type_map.dtype == torch.int32 and type_map.is_contiguous()) else type_map.to(torch.int32).contiguous()
+            if int(tm.numel()) != int(n_types) or tm.device != self.device:
+                raise ValueError("type_map must hold n_types int32 entries on the batch's device")
+            keep.append(tm)
+            src.type_map = tm.data_ptr()
+        _lib.check(self.lib.cygym_decode_actions(self._h, C.byref(src), C.byref(dst), self._stream()), self._h, "cygym_decode_actions")
+
+    def actor_head_decode(self, rows, hidden: torch.Tensor, weight_t: torch.Tensor, bias, n_types: int,
+                          n_exploits: int | None = None, n_apps: int = 0, type_map=None, act=None, epsilon: float = 0.0,
+                          tanh: bool = False):
+        """The actor's LAST linear layer fused with decode_actions (cygym_actor_head_decode): action vector of row r =
+        act(hidden[r] @ weight_t + bias), weight_t = head_weights(nn.Linear.weight) ([H, n_out rounded up to 64], k-major), decoded from registers
+        -- the [n, n_out] vectors never reach HBM.  Limits: H <= 256, n_out = n_types + M + n_exploits + n_apps <= 512."""
+        act = self.act if act is None else act
+        dst = self.actions_struct(act)
+        n_exploits = self.cfg.max_exploits if n_exploits is None else int(n_exploits)
+        n_out = int(n_types) + self.M + n_exploits + int(n_apps)
+        H = int(hidden.shape[1])
+        ok = lambda t: t.dtype == torch.float32 and t.device == self.device  # noqa: E731
+        if not ok(hidden) or hidden.dim() != 2 or hidden.stride(1) != 1:
+            raise ValueError("hidden must be a [n, H] float32 tensor on the batch's device with unit inner stride")
+        pitch = (n_out + 63) // 64 * 64
+        if not ok(weight_t) or tuple(weight_t.shape) != (H, pitch) or not weight_t.is_contiguous():
+            raise ValueError(f"weight_t must be a contiguous float32 [{H}, {pitch}] tensor (see head_weights())")
+        if bias is not None and (not ok(bias) or tuple(bias.shape) != (n_out,) or not bias.is_contiguous()):
+            raise ValueError(f"bias must be a contiguous float32 [{n_out}] tensor")
+        n = int(hidden.shape[0])
+        hd = abi.ActorHead()
+        hd.hidden, hd.weight_t, hd.bias = hidden.data_ptr(), weight_t.data_ptr(), (bias.data_ptr() if bias is not None else None)
+        hd.H, hd.hidden_stride, hd.tanh_out, hd.weight_pitch = H, int(hidden.stride(0)), int(bool(tanh)), pitch
+        src = abi.ActionVectors()
+        src.n_types, src.n_devices, src.n_exploits, src.n_apps, src.n = int(n_types), self.M, n_exploits, int(n_apps), n
+        src.status = self.status.data_ptr()
+        if epsilon > 0.0:
+            from . import rng as R
+            src.epsilon_thr = R.bernoulli_threshold(float(epsilon))
+        keep = [hidden]
+        if rows is not None:
+            r = rows if (rows.dtype == torch.int32 and rows.is_contiguous()) else rows.to(torch.int32).contiguous()
+            if int(r.shape[0]) != n or r.device != self.device:
+                raise ValueError("rows must be a device tensor as long as hidden")
+            keep.append(r)
+            src.rows = r.data_ptr()
+        elif n > self.N:
+            raise ValueError("more action rows than envs")
+        if type_map is not None:
+            tm = type_map if (type_map.dtype == torch.int32 and type_map.is_contiguous()) else type_map.to(torch.int32).contiguous()
+            if int(tm.numel()) != int(n_types) or tm.device != self.device:
+                raise ValueError("type_map must hold n_types int32 entries on the batch's device")
+            keep.append(tm)
+            src.type_map = tm.data_ptr()
+        _lib.check(self.lib.cygym_actor_head_decode(self._h, C.byref(hd), C.byref(src), C.byref(dst), self._stream()),
+                   self._h, "cygym_actor_head_decode")
+
+    @staticmethod
+    def head_weights(weight: torch.Tensor) -> torch.Tensor:
+        """nn.Linear.weight [n_out, H] -> the k-major, row-padded copy actor_head_decode reads: [H, n_out rounded up to 64]."""
+        n_out, H = weight.shape
+        out = torch.zeros((H, (n_out + 63) // 64 * 64), dtype=torch.float32, device=weight.device)
+        out[:, :n_out] = weight.detach().t()
+        return out
+
     def take_status(self) -> int:
         """Read and clear the batch's status word: the OR of CG_E_TOPO_OVF | CG_E_BUSY_SAT | CG_E_DET_PENDING |
         CG_E_UNPINNED over the envs ticked since the last call (one 4-byte device-to-host copy; synchronises)."""
@@ -365,13 +479,21 @@ class BatchedCyberDefenseEnv:
             self.status.zero_()
         return v
 
-    def step_range(self, begin: int, n: int, act=None):
+    def prime_view(self, role: str):
+        """Fill self.role_obs[role] with the role's view of the CURRENT state (one cygym_observe launch): the first
+        observation of a closed loop; every later one is written by step(view=...) itself."""
+        self._outputs(role, False)
+        self.role_obs[role].copy_(self.observe(1 if role == "defender" else 2))
+        return self.role_obs[role]
+
+    def step_range(self, begin: int, n: int, act=None, view: str | None = None, full_obs: bool = True, returns: bool = False):
         """One tick for the envs [begin, begin + n) only, on the current stream (cygym_step_range).  The action and
         output tensors keep their [N] leading dimension.  A closed-loop driver pipelines sub-batches this way: each
         sub-batch on its own stream, so that its policy evaluation and the tail of its slowest env overlap the other
         sub-batches' ticks (see bench.py, leg `per_tick_stepping`)."""
         a = self.actions_struct(act)
-        _lib.check(self.lib.cygym_step_range(self._h, int(begin), int(n), C.byref(a), C.byref(self._out), self._stream()),
+        o = self._out if (view is None and full_obs and not returns) else self._outputs(view, full_obs, returns)
+        _lib.check(self.lib.cygym_step_range(self._h, int(begin), int(n), C.byref(a), C.byref(o), self._stream()),
                    self._h, "cygym_step_range")
         return self.obs, self.raw, self.shaped, self.done
 

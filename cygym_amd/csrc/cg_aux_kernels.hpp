@@ -181,6 +181,176 @@ __global__ void write_actions_kernel(cygym_action_rows src, cygym_actions dst, i
   }
 }
 
+// cygym_decode_actions (do_agent.py:970-998 for a batch): one wave per row.  argmax = first maximum (np.argmax).
+__device__ __forceinline__ int wave_argmax(const float* v, int n, int lane) {
+  float best = -__builtin_inff();
+  int bi = 0x7FFFFFFF;
+  for (int i = lane; i < n; i += WAVE) { const float x = v[i]; if (x > best) { best = x; bi = i; } }   // (ascending i: first maximum per lane)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ob = __shfl_xor(best, off);
+    const int oi = __shfl_xor(bi, off);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  return bi == 0x7FFFFFFF ? 0 : bi;
+}
+__global__ void decode_actions_kernel(cygym_action_vectors src, cygym_actions dst, int n_envs, const int32_t* ienv,
+                                      uint64_t seed, int64_t env_id_base) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= src.n) return;
+  const int row = src.rows ? src.rows[wave] : wave;
+  if (row < 0 || row >= n_envs) return;
+  const int G = dst.max_groups, L = dst.max_devs, M = src.n_devices;
+  const float* v = src.vec + (size_t)wave * src.stride;
+  int at = src.n_types > 0 ? wave_argmax(v, src.n_types, lane) : 0;
+  if (src.epsilon_thr && src.n_types > 0) {   // epsilon-greedy (do_agent.py:972-973)
+    const uint32_t tick = (uint32_t)ienv[(size_t)row * CG_I_COUNT + CG_I_RNG_TICK];
+    const cg_u32x4 r = cg_philox4x32_10((uint32_t)(env_id_base + row), tick, CG_SITE_EPS_TYPE, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+    if ((uint64_t)r.v[0] < src.epsilon_thr) at = (int)cg_index(r.v[1], (uint32_t)src.n_types);
+  }
+  if (src.type_map && src.n_types > 0) at = src.type_map[at];
+  const float* dv = v + src.n_types;
+  int16_t* out = const_cast<int16_t*>(dst.dev_idx) + (size_t)row * L;
+  int base = 0;
+  for (int d0 = 0; d0 < M; d0 += WAVE) {
+    const int d = d0 + lane;
+    const bool on = d < M && dv[d] > 0.f;
+    const uint64_t m = __ballot(on);
+    const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if (on && pos < L) out[pos] = (int16_t)d;
+    base += __popcll(m);
+  }
+  const int cnt = base < L ? base : L;
+  for (int q = cnt + lane; q < L; q += WAVE) out[q] = 0;
+  const int ex = src.n_exploits > 0 ? wave_argmax(dv + M, src.n_exploits, lane) : 0;
+  const int app = src.n_apps > 0 ? wave_argmax(dv + M + src.n_exploits, src.n_apps, lane) : 0;
+  if (lane == 0) {
+    const_cast<int32_t*>(dst.atype)[(size_t)row * G] = at;
+    const_cast<int32_t*>(dst.exploit)[(size_t)row * G * CG_MAX_EXPLOITS] = ex;
+    const_cast<int32_t*>(dst.n_exploit)[(size_t)row * G] = 1;
+    const_cast<int32_t*>(dst.app)[(size_t)row * G] = app;
+    const_cast<int32_t*>(dst.dev_cnt)[(size_t)row * G] = cnt;
+    if (base > L && src.status) atomicOr(src.status, CG_DECODE_TRUNCATED);
+  }
+}
+
+// cygym_actor_head_decode: last Linear layer of the actor + decode_action, fused.  A workgroup of HEAD_WAVES waves stages
+// a 64-row k-slab of the k-major weight matrix in LDS (lane j reads the weights of consecutive outputs j: conflict-free);
+// every wave owns ONE row (16 waves per workgroup = 4 per SIMD: the LDS and reduction latencies of one row hide behind the
+// other rows'); lane j accumulates outputs j, j + 64, ... (HEAD_OPL per lane) with the hidden activation of step k
+// broadcast from the lane that holds it (v_readlane: an SGPR operand, no LDS traffic).  The action vector of a row lives
+// in registers only; its arg-maxima are wave reductions on the DPP path over (order-preserving value bits, ~index) pairs.
+constexpr int HEAD_WAVES = 16, HEAD_OPL_MAX = 8, HEAD_KC = 64;
+// max over the wave of a (hi, lo) pair compared lexicographically; every lane active.  Result valid in lane 63.
+__device__ __forceinline__ void dpp_pair_max(uint32_t& hi, uint32_t& lo) {
+#define CG_PMAX(ctrl, rmask)                                                                          \
+  {                                                                                                   \
+    const uint32_t oh = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, (ctrl), (rmask), 0xf, false); \
+    const uint32_t ol = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, (ctrl), (rmask), 0xf, false); \
+    const bool take = oh > hi || (oh == hi && ol > lo);                                               \
+    hi = take ? oh : hi; lo = take ? ol : lo;                                                         \
+  }
+  CG_PMAX(0x111, 0xf) CG_PMAX(0x112, 0xf) CG_PMAX(0x114, 0xf) CG_PMAX(0x118, 0xf) CG_PMAX(0x142, 0xa) CG_PMAX(0x143, 0xc)
+#undef CG_PMAX
+}
+__device__ __forceinline__ uint32_t float_order_bits(float x) {   // a < b  <=>  bits(a) < bits(b) (finite values)
+  const uint32_t u = __float_as_uint(x);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+template <int HEAD_OPL>
+__global__ __launch_bounds__(HEAD_WAVES * WAVE) void actor_head_kernel(cygym_actor_head hd, cygym_action_vectors src, cygym_actions dst,
+                                                                        int n_envs, const int32_t* ienv, uint64_t seed, int64_t env_id_base) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  float* Wt = (float*)smem;   // [HEAD_KC][n_out_p]: a k-slab of the k-major weight matrix, copied as it lies
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n_out = src.n_types + src.n_devices + src.n_exploits + src.n_apps;
+  const int n_out_p = HEAD_OPL * WAVE;
+  const int H = hd.H;
+  const int srow = blockIdx.x * HEAD_WAVES + wave;   // this wave's source row
+  const bool have = srow < src.n;
+  float acc[HEAD_OPL];
+#pragma unroll
+  for (int i = 0; i < HEAD_OPL; ++i) {
+    const int j = lane + i * WAVE;
+    acc[i] = (hd.bias && j < n_out) ? hd.bias[j] : 0.f;
+  }
+  for (int k0 = 0; k0 < H; k0 += HEAD_KC) {
+    const int kc = H - k0 < HEAD_KC ? H - k0 : HEAD_KC;
+    const float hv = (have && lane < kc) ? hd.hidden[(size_t)srow * hd.hidden_stride + k0 + lane] : 0.f;
+    __syncthreads();
+    // stage rows k0 .. k0 + kc of weight_t (row pitch n_out_p: 16-byte aligned rows as wide as the LDS rows) -> Wt, a
+    // plain copy, 16 bytes per lane, every load of a thread in flight at once
+    {
+      const int total4 = kc * n_out_p / 4;
+      const float4* wsrc = (const float4*)(hd.weight_t + (size_t)k0 * n_out_p);
+      float4* wdst = (float4*)Wt;
+      constexpr int STRIDE = HEAD_WAVES * WAVE, UF = (HEAD_KC * HEAD_OPL * WAVE / 4 + STRIDE - 1) / STRIDE;
+      float4 x[UF];
+#pragma unroll
+      for (int u = 0; u < UF; ++u) { const int i = threadIdx.x + u * STRIDE; x[u] = wsrc[i < total4 ? i : total4 - 1]; }
+#pragma unroll
+      for (int u = 0; u < UF; ++u) { const int i = threadIdx.x + u * STRIDE; if (i < total4) wdst[i] = x[u]; }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int k = 0; k < kc; ++k) {
+      const float hk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hv), k));   // (k is uniform: an SGPR operand)
+#pragma unroll
+      for (int i = 0; i < HEAD_OPL; ++i) acc[i] = __builtin_fmaf(hk, Wt[k * n_out_p + lane + i * WAVE], acc[i]);
+    }
+  }
+  if (!have) return;
+  const int row = src.rows ? src.rows[srow] : srow;
+  if (row < 0 || row >= n_envs) return;
+  const int G = dst.max_groups, L = dst.max_devs, M = src.n_devices, nt = src.n_types;
+  float v[HEAD_OPL];
+#pragma unroll
+  for (int i = 0; i < HEAD_OPL; ++i) v[i] = hd.tanh_out ? tanhf(acc[i]) : acc[i];
+  // argmax of the outputs in [lo, hi) (first maximum, like np.argmax): per lane over its registers, then across the wave
+  auto range_argmax = [&](int lo, int hi) -> int {
+    uint32_t bh = 0u, bl = 0u;   // (0, 0): below every real candidate (order bits of a finite float are >= 0x00800000)
+#pragma unroll
+    for (int i = 0; i < HEAD_OPL; ++i) {
+      const int j = lane + i * WAVE;
+      const uint32_t ob = float_order_bits(v[i]);
+      if (j >= lo && j < hi && ob > bh) { bh = ob; bl = ~(uint32_t)(j - lo); }   // ascending j per lane: first maximum
+    }
+    dpp_pair_max(bh, bl);
+    const uint32_t rl = (uint32_t)__builtin_amdgcn_readlane((int)bl, 63), rh = (uint32_t)__builtin_amdgcn_readlane((int)bh, 63);
+    return rh == 0u ? 0 : (int)~rl;
+  };
+  int at = nt > 0 ? range_argmax(0, nt) : 0;
+  if (src.epsilon_thr && nt > 0) {   // epsilon-greedy (do_agent.py:972-973)
+    const uint32_t tick = (uint32_t)ienv[(size_t)row * CG_I_COUNT + CG_I_RNG_TICK];
+    const cg_u32x4 rr = cg_philox4x32_10((uint32_t)(env_id_base + row), tick, CG_SITE_EPS_TYPE, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+    if ((uint64_t)rr.v[0] < src.epsilon_thr) at = (int)cg_index(rr.v[1], (uint32_t)nt);
+  }
+  if (src.type_map && nt > 0) at = src.type_map[at];
+  int16_t* out = const_cast<int16_t*>(dst.dev_idx) + (size_t)row * L;
+  int base = 0;
+#pragma unroll
+  for (int i = 0; i < HEAD_OPL; ++i) {   // (i, lane) ascending == output index ascending == device id ascending
+    const int d = lane + i * WAVE - nt;
+    const bool on = d >= 0 && d < M && v[i] > 0.f;
+    const uint64_t m = __ballot(on);
+    const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if (on && pos < L) out[pos] = (int16_t)d;
+    base += __popcll(m);
+  }
+  const int cnt = base < L ? base : L;
+  for (int q = cnt + lane; q < L; q += WAVE) out[q] = 0;
+  const int ex = src.n_exploits > 0 ? range_argmax(nt + M, nt + M + src.n_exploits) : 0;
+  const int app = src.n_apps > 0 ? range_argmax(nt + M + src.n_exploits, n_out) : 0;
+  if (lane == 0) {
+    const_cast<int32_t*>(dst.atype)[(size_t)row * G] = at;
+    const_cast<int32_t*>(dst.exploit)[(size_t)row * G * CG_MAX_EXPLOITS] = ex;
+    const_cast<int32_t*>(dst.n_exploit)[(size_t)row * G] = 1;
+    const_cast<int32_t*>(dst.app)[(size_t)row * G] = app;
+    const_cast<int32_t*>(dst.dev_cnt)[(size_t)row * G] = cnt;
+    if (base > L && src.status) atomicOr(src.status, CG_DECODE_TRUNCATED);
+  }
+}
+
 // Synthetic action script of bench.py: alternating defender / attacker turns.
 // Mirrored in numpy by cygym_amd/actions.py (tests check equality).
 __global__ void gen_actions_kernel(KParams P, int tick, int32_t* mode, int32_t* n_groups, int32_t* atype,

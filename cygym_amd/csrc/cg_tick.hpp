@@ -612,6 +612,10 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 &
     P.o.raw[te] = raw;
     P.o.shaped[te] = shaped;
     P.o.done[te] = done ? 1 : 0;
+    if (COLD(P.o.ret != nullptr) && P.o.alive && P.o.alive[env]) {   // episode returns of a rollout loop (do_agent.py:266-274)
+      P.o.ret[(size_t)env * 2 + (mode & 1)] += raw;
+      if (done) P.o.alive[env] = 0;
+    }
   }
 
   if (done && P.c.auto_reset && P.snap.live) {   // reload the initial snapshot; the RNG tick stays monotone

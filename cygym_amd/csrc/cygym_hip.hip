@@ -132,6 +132,19 @@ static hipError_t set_lds_attr(cygym_handle* h) {   // every instantiation this 
 extern "C" {
 
 int cygym_version(void) { return CYGYM_ABI_VERSION; }
+int cygym_sizeof(int32_t which) {
+  switch (which) {
+    case 0: return (int)sizeof(cygym_topology);
+    case 1: return (int)sizeof(cygym_config);
+    case 2: return (int)sizeof(cygym_buffers);
+    case 3: return (int)sizeof(cygym_actions);
+    case 4: return (int)sizeof(cygym_outputs);
+    case 5: return (int)sizeof(cygym_action_rows);
+    case 6: return (int)sizeof(cygym_action_vectors);
+    case 7: return (int)sizeof(cygym_actor_head);
+    default: return -1;
+  }
+}
 const char* cygym_last_error(const cygym_handle* h) { return h ? h->err : g_err; }
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -519,6 +532,68 @@ int cygym_write_actions(cygym_handle* h, const cygym_action_rows* src, const cyg
   const int threads = 256, waves_per_block = threads / WAVE;
   hipLaunchKernelGGL(write_actions_kernel, dim3((src->n + waves_per_block - 1) / waves_per_block), dim3(threads), 0,
                      (hipStream_t)stream, *src, *dst, h->t.M, h->n_envs);
+  HIPCHK(h, hipGetLastError());
+  return CYGYM_OK;
+}
+
+int cygym_decode_actions(cygym_handle* h, const cygym_action_vectors* src, const cygym_actions* dst, void* stream) {
+  if (!h) return fail(h, CYGYM_EINVAL, "cygym_decode_actions: null handle%s", "");
+  if (!src || !dst || !src->vec) return fail(h, CYGYM_EINVAL, "cygym_decode_actions: null source pointer%s", "");
+  if (!dst->atype || !dst->n_exploit || !dst->exploit || !dst->app || !dst->dev_cnt || !dst->dev_idx || dst->max_groups < 1 ||
+      dst->max_devs < 1)
+    return fail(h, CYGYM_EINVAL, "cygym_decode_actions: bad destination%s", "");
+  if (src->n_types < 0 || src->n_exploits < 0 || src->n_apps < 0 || src->n_devices != h->t.M ||
+      (long long)src->stride < (long long)src->n_types + src->n_devices + src->n_exploits + src->n_apps)
+    return fail(h, CYGYM_EINVAL, "cygym_decode_actions: row layout does not fit the stride / the handle's device count%s", "");
+  if (src->n < 0 || (!src->rows && src->n > h->n_envs)) return fail(h, CYGYM_EINVAL, "cygym_decode_actions: bad row count%s", "");
+  if (src->epsilon_thr && !h->bound) return fail(h, CYGYM_ENOTBOUND, "cygym_decode_actions: epsilon > 0 needs a bound handle%s", "");
+  if (src->n == 0) return CYGYM_OK;
+  HIPCHK(h, hipSetDevice(h->device_id));
+  const int threads = 256, waves_per_block = threads / WAVE;
+  hipLaunchKernelGGL(decode_actions_kernel, dim3((src->n + waves_per_block - 1) / waves_per_block), dim3(threads), 0,
+                     (hipStream_t)stream, *src, *dst, h->n_envs, h->b.ienv, h->c.seed, h->c.env_id_base);
+  HIPCHK(h, hipGetLastError());
+  return CYGYM_OK;
+}
+
+int cygym_actor_head_decode(cygym_handle* h, const cygym_actor_head* head, const cygym_action_vectors* src,
+                            const cygym_actions* dst, void* stream) {
+  if (!h) return fail(h, CYGYM_EINVAL, "cygym_actor_head_decode: null handle%s", "");
+  if (!head || !src || !dst || !head->hidden || !head->weight_t) return fail(h, CYGYM_EINVAL, "cygym_actor_head_decode: null source pointer%s", "");
+  if (!dst->atype || !dst->n_exploit || !dst->exploit || !dst->app || !dst->dev_cnt || !dst->dev_idx || dst->max_groups < 1 ||
+      dst->max_devs < 1)
+    return fail(h, CYGYM_EINVAL, "cygym_actor_head_decode: bad destination%s", "");
+  if (src->n_types < 0 || src->n_exploits < 0 || src->n_apps < 0 || src->n_devices != h->t.M || head->H < 1 || head->hidden_stride < head->H)
+    return fail(h, CYGYM_EINVAL, "cygym_actor_head_decode: bad layout%s", "");
+  const long long n_out = (long long)src->n_types + src->n_devices + src->n_exploits + src->n_apps;
+  if (head->H > 256 || n_out > (long long)HEAD_OPL_MAX * WAVE)
+    return fail(h, CYGYM_EUNSUPPORTED, "cygym_actor_head_decode: H > 256 or more than 512 outputs%s", "");
+  if (src->n < 0 || (!src->rows && src->n > h->n_envs)) return fail(h, CYGYM_EINVAL, "cygym_actor_head_decode: bad row count%s", "");
+  if (src->epsilon_thr && !h->bound) return fail(h, CYGYM_ENOTBOUND, "cygym_actor_head_decode: epsilon > 0 needs a bound handle%s", "");
+  if (src->n == 0) return CYGYM_OK;
+  HIPCHK(h, hipSetDevice(h->device_id));
+  const int n_out_p = ((int)n_out + 63) & ~63;
+  if (head->weight_pitch != n_out_p) return fail(h, CYGYM_EINVAL, "cygym_actor_head_decode: weight_pitch must be n_out rounded up to 64%s", "");
+  const size_t lds = (size_t)n_out_p * HEAD_KC * sizeof(float);
+  const void* k = nullptr;
+  switch (n_out_p / WAVE) {   // outputs per lane
+    case 1: k = (const void*)actor_head_kernel<1>; break;
+    case 2: k = (const void*)actor_head_kernel<2>; break;
+    case 3: k = (const void*)actor_head_kernel<3>; break;
+    case 4: k = (const void*)actor_head_kernel<4>; break;
+    case 5: k = (const void*)actor_head_kernel<5>; break;
+    case 6: k = (const void*)actor_head_kernel<6>; break;
+    case 7: k = (const void*)actor_head_kernel<7>; break;
+    default: k = (const void*)actor_head_kernel<8>; break;
+  }
+  HIPCHK(h, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, HEAD_OPL_MAX * WAVE * HEAD_KC * (int)sizeof(float)));
+  const int rows_per_wg = HEAD_WAVES;
+  int n_envs = h->n_envs;
+  const int32_t* ienv = h->b.ienv;
+  uint64_t seed = h->c.seed;
+  int64_t base = h->c.env_id_base;
+  void* args[] = {(void*)head, (void*)src, (void*)dst, &n_envs, &ienv, &seed, &base};
+  HIPCHK(h, hipLaunchKernel(k, dim3((src->n + rows_per_wg - 1) / rows_per_wg), dim3(HEAD_WAVES * WAVE), args, lds, (hipStream_t)stream));
   HIPCHK(h, hipGetLastError());
   return CYGYM_OK;
 }

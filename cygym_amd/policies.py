@@ -1,0 +1,133 @@
+"""Closed-loop strategies for the batched rollout consumer (cygym_amd/rollout_grid.simulate_grid).
+
+`ActorPolicy` is the batched form of branch (D) of the reference's rollout loop (do_agent.py:240-262): a parametric
+actor maps the role observation to an action vector [type logits | device values | exploit values | app values] and
+`DoubleOracle.decode_action` (do_agent.py:935-998) turns it into the action tuple.  Here the actor is any torch
+module evaluated on all the cells that play the strategy at once, and the decoding + scatter into the batch's
+action tensors is ONE launch of the library (cygym_decode_actions).  `reference_actor` builds the reference's own
+architecture (do_agent.py:357-370); `mlp_actor` a smaller one.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+
+class ActorPolicy:
+    tick_free = True      # the action does not depend on the tick number: the loop may be captured in a HIP graph
+
+    def __init__(self, net: nn.Module, n_types: int, n_exploits: int, n_apps: int = 0, type_map=None, epsilon: float = 0.0):
+        self.net, self.n_types, self.n_exploits, self.n_apps = net, int(n_types), int(n_exploits), int(n_apps)
+        self.epsilon = float(epsilon)      # epsilon-greedy action type (do_agent.py:972-973), fused path only
+        self.fuse_head = True              # run the last Linear layer inside the decode launch when it fits
+        self.type_map = None if type_map is None else torch.as_tensor(type_map, dtype=torch.int32)
+        # what the policy can emit (simulate_grid asks: action 10 needs a detector batch)
+        self.action_types = list(range(self.n_types)) if type_map is None else sorted({int(x) for x in self.type_map.tolist()})
+
+    def _map(self, device):
+        if self.type_map is not None and self.type_map.device != device:
+            self.type_map = self.type_map.to(device)
+        return self.type_map
+
+    def _split_head(self, M):
+        """(body modules, last nn.Linear, tanh?) when the actor is a Sequential ending in Linear [+ Tanh] that the fused
+        head kernel can take (cygym_actor_head_decode: H <= 256, <= 512 outputs), else None.  Cached."""
+        if not hasattr(self, "_head"):
+            self._head = None
+            if isinstance(self.net, nn.Sequential) and len(self.net) >= 2:
+                mods = list(self.net)
+                tanh = isinstance(mods[-1], nn.Tanh)
+                last = mods[-2] if tanh else mods[-1]
+                if isinstance(last, nn.Linear) and last.in_features <= 256 and last.out_features <= 512 \
+                        and last.out_features == self.n_types + M + self.n_exploits + self.n_apps and last.weight.dtype == torch.float32:
+                    self._head = (type(self.net)(*mods[: -2 if tanh else -1]), last, tanh)
+        return self._head
+
+    @torch.no_grad()
+    def write(self, batch, act, rows, obs):
+        """Fused path: actor forward, then one decode-and-scatter launch into rows `rows` of the action tensors; when the
+        actor ends in a Linear layer of at most 512 outputs that layer runs inside the decode launch as well."""
+        head = self._split_head(batch.M) if (self.fuse_head and hasattr(batch, "actor_head_decode")) else None
+        if head is not None:
+            body, last, tanh = head
+            ver = (last.weight._version, last.weight.data_ptr())
+            if getattr(self, "_wt_ver", None) != ver:          # k-major copy of the layer's weights, redone when they change
+                self._wt, self._wt_ver = batch.head_weights(last.weight), ver
+            batch.actor_head_decode(rows, body(obs), self._wt, last.bias, self.n_types, self.n_exploits, self.n_apps,
+                                    self._map(obs.device), act, epsilon=self.epsilon, tanh=tanh)
+            return
+        batch.decode_actions(rows, self.net(obs), self.n_types, self.n_exploits, self.n_apps, self._map(obs.device), act,
+                             epsilon=self.epsilon)
+
+    @torch.no_grad()
+    def __call__(self, obs, t, M, L):
+        """The same decoding with torch ops (batch-likes without cygym_decode_actions: the tests' oracle harness)."""
+        if self.epsilon > 0.0:
+            raise NotImplementedError("epsilon-greedy types are drawn in cygym_decode_actions (needs the envs' rng ticks)")
+        v = self.net(obs)
+        k = self.n_types
+        at = torch.argmax(v[:, :k], dim=1).to(torch.int32) if k > 0 else torch.zeros(v.shape[0], dtype=torch.int32, device=v.device)
+        tm = self._map(obs.device)
+        if tm is not None:
+            at = tm[at.long()]
+        ex = torch.argmax(v[:, k + M: k + M + self.n_exploits], dim=1) if self.n_exploits > 0 else torch.zeros_like(at)
+        app = torch.argmax(v[:, k + M + self.n_exploits: k + M + self.n_exploits + self.n_apps], dim=1) if self.n_apps > 0 else torch.zeros_like(at)
+        return {"atype": at, "exploit": ex.to(torch.int32), "dev_mask": v[:, k: k + M] > 0, "app": app.to(torch.int32)}
+
+
+class FusedMLP(nn.Sequential):
+    """nn.Sequential of Linear / ReLU / Tanh whose Linear + ReLU pairs run as ONE GEMM with a ReLU epilogue
+    (torch._addmm_activation) on 2-D inputs -- one launch less per hidden layer of a closed-loop tick."""
+
+    def forward(self, x):
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, nn.Linear) and x.dim() == 2:
+                if i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU) and hasattr(torch, "_addmm_activation"):
+                    x = torch._addmm_activation(m.bias, x, m.weight.t())
+                    i += 2
+                    continue
+                x = torch.addmm(m.bias, x, m.weight.t())
+            else:
+                x = m(x)
+            i += 1
+        return x
+
+
+def mlp_actor(state_dim: int, action_dim: int, hidden=(64,), seed: int = 0, device="cpu", tanh: bool = False) -> nn.Module:
+    """Linear-ReLU stack ending in a linear layer of `action_dim` outputs (tanh on top like the reference's actor when
+    asked); default-initialised from `seed`."""
+    g = torch.Generator().manual_seed(int(seed))
+    layers, d = [], int(state_dim)
+    for h in hidden:
+        layers += [nn.Linear(d, int(h)), nn.ReLU()]
+        d = int(h)
+    layers.append(nn.Linear(d, int(action_dim)))
+    if tanh:
+        layers.append(nn.Tanh())
+    net = FusedMLP(*layers)
+    with torch.no_grad():
+        for p in net.parameters():      # same distribution as nn.Linear's default (uniform +- 1/sqrt(fan_in)), seeded
+            bound = 1.0 / (p.shape[-1] ** 0.5) if p.dim() > 1 else 1.0 / (state_dim ** 0.5)
+            p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) * bound)
+    return net.to(device).eval()
+
+
+def reference_actor(state_dim: int, action_dim: int, seed: int = 0, device="cpu") -> nn.Module:
+    """The reference's DDPG actor (do_agent.py:357-370): state -> 256 -> 256 -> action_dim, ReLU, tanh."""
+    return mlp_actor(state_dim, action_dim, hidden=(256, 256), seed=seed, device=device, tanh=True)
+
+
+@torch.no_grad()
+def calibrate_device_head(policy: ActorPolicy, obs: torch.Tensor, M: int, fraction: float):
+    """Shift the bias of the actor's device outputs so that on `obs` a fraction `fraction` of the device values is
+    positive, i.e. the policy lists about fraction * M devices per action.  A freshly initialised actor selects every
+    second device (its outputs are symmetric around 0); trained policies act on a handful -- benchmarks of the closed
+    loop calibrate their random actors to the list lengths they want to measure."""
+    last = [m for m in policy.net.modules() if isinstance(m, nn.Linear)][-1]
+    k = policy.n_types
+    v = policy.net(obs)[:, k: k + M]
+    q = torch.quantile(v.flatten().float()[: 1 << 22], 1.0 - float(fraction))
+    last.bias[k: k + M] -= q

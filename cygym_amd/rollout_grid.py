@@ -205,7 +205,8 @@ def _write_rows(batch, act, r, a, L):
 
 
 def simulate_grid(batch, def_policies, att_policies, n_mc: int, T: int, randomize: bool = True,
-                  group=None, n_total: int | None = None, cell_offset: int = 0, timers: dict | None = None):
+                  group=None, n_total: int | None = None, cell_offset: int = 0, timers: dict | None = None,
+                  graph: bool = False, streams: int = 1):
     """The |D| x |A| x n_mc grid of `simulate_game` (do_agent.py:1875-2089 / worker :129-287) with CLOSED-LOOP
     strategies, as one batch: cell (i, j, mc) is env slot i*|A|*n_mc + j*n_mc + mc.
 
@@ -215,12 +216,21 @@ def simulate_grid(batch, def_policies, att_policies, n_mc: int, T: int, randomiz
       t        the role's turn number (tick // 2)
       returns  atype [n] i32, exploit [n] i32 (one exploit index, -1 = none), dev_idx [n, L] i16 + dev_cnt [n] i32
                (or `dev_mask` [n, M] bool instead of the two), app [n] i32 -- device tensors
-    A policy may declare `action_types` (iterable of the action types it can emit).  Baseline names and fixed
-    sequences are accepted too (wrapped in SequencePolicy; they follow the global tick like the reference).
+    or an object with `write(batch, act, rows, obs)` that fills the rows itself (cygym_amd.policies.ActorPolicy: actor
+    forward + ONE fused decode-and-scatter launch).  A policy may declare `action_types` (iterable of the action
+    types it can emit) and `tick_free = True` (its action does not depend on t).  Baseline names and fixed sequences
+    are accepted too (wrapped in SequencePolicy; they follow the global tick like the reference).
 
     Per tick: one policy call per distinct strategy of the acting role -> rows scattered into the batch's action
-    tensors (one fused launch per strategy) -> cygym_step, which also writes the next actor's role view.  An env that
-    reports done stops contributing (the reference breaks out of its loop, :271-274).
+    tensors (one fused launch per strategy) -> cygym_step, which also writes the next actor's role view and adds the
+    reward to the env's episode return while it is alive (an env that reports done stops contributing: the
+    reference breaks out of its loop, :271-274).
+
+    streams = S > 1: the batch is walked as S contiguous sub-batches, each on its own HIP stream (cygym_step_range):
+    a sub-batch's policy evaluation overlaps the other sub-batches' ticks, and its next tick starts when ITS slowest
+    env is done -- the batched counterpart of the reference's process-per-rollout fan-out (do_agent.py:1928-1942).
+    graph=True: when every policy is tick_free and none can train, ticks 6, 7 are captured in a HIP graph (all
+    streams) and replayed for the rest of the horizon (no host work per tick); otherwise the flag is ignored.
 
     Detector.train (defender action 10): when some defender policy can emit it the batch must have been created
     with detector=True; after every defender tick the 4-byte status word says whether any env asked, and the
@@ -235,31 +245,55 @@ def simulate_grid(batch, def_policies, att_policies, n_mc: int, T: int, randomiz
     N, M, L, dev = batch.N, batch.M, batch.L, batch.obs.device
     if cell_offset + N > cells:
         raise ValueError("batch holds more envs than grid cells")
-    pol = {HL.DEFENDER: [p if callable(p) else SequencePolicy(p, HL.DEFENDER) for p in def_policies],
-           HL.ATTACKER: [p if callable(p) else SequencePolicy(p, HL.ATTACKER) for p in att_policies]}
+    ROLES = (HL.DEFENDER, HL.ATTACKER)
+    pol = {HL.DEFENDER: [p if (callable(p) or hasattr(p, "write")) else SequencePolicy(p, HL.DEFENDER) for p in def_policies],
+           HL.ATTACKER: [p if (callable(p) or hasattr(p, "write")) else SequencePolicy(p, HL.ATTACKER) for p in att_policies]}
     trains = any(can_train(p) for p in pol[HL.DEFENDER])
     has_det = bool(getattr(batch, "detector", False))
     if trains and not has_det:
         raise ValueError("a defender strategy can emit action 10 (Detector.train): create the batch with detector=True "
                          "(or declare the policy's `action_types` without 10)")
-    cell = torch.arange(cell_offset, cell_offset + N, device=dev)
-    strat_of = {HL.DEFENDER: cell // (nA * n_mc), HL.ATTACKER: (cell // n_mc) % nA}
-    rows = {r: [torch.nonzero(strat_of[r] == k).flatten() for k in range(len(pol[r]))] for r in pol}
-    bl = baseline_schedule(def_policies, att_policies, cell.cpu().numpy(), n_mc, min(T, 4), _cfg_baseline_code(batch))
+    fused = hasattr(batch, "role_obs")            # the product batch: fused role views, scatter, return accumulators
+    split = timers is not None and bool(timers.get("split"))
+    S_sub = max(1, min(int(streams), N)) if (fused and not trains and not split) else 1
+    cell_np = np.arange(cell_offset, cell_offset + N)
+    strat_np = {HL.DEFENDER: cell_np // (nA * n_mc), HL.ATTACKER: (cell_np // n_mc) % nA}
+    bounds = [(j * N // S_sub, (j + 1) * N // S_sub) for j in range(S_sub)]
+    # plan[role][sub-batch] = [(policy, env ids int64, env ids int32, slice or None when the ids are not one range)]
+    plan = {r: [] for r in ROLES}
+    for r in ROLES:
+        for lo, hi in bounds:
+            items = []
+            for k, p in enumerate(pol[r]):
+                ids = lo + np.nonzero(strat_np[r][lo:hi] == k)[0]
+                if ids.size == 0:
+                    continue
+                sl = slice(int(ids[0]), int(ids[-1]) + 1) if ids[-1] - ids[0] + 1 == ids.size else None
+                t64 = torch.from_numpy(ids).to(dev)
+                items.append((p, t64, t64.to(torch.int32), sl))
+            plan[r].append(items)
+    bl = baseline_schedule(def_policies, att_policies, cell_np, n_mc, min(T, 4), _cfg_baseline_code(batch))
     # (ticks >= 2 repeat with period 2: rows 2 / 3 of the schedule; shorter runs only have the first rows)
     mode_words = [torch.from_numpy(((bl[t] + 1) << S.MODE_BASELINE_SHIFT) | (t % 2)).to(device=dev, dtype=torch.int32)
                   for t in range(bl.shape[0])]
     batch.reset()
     if randomize:
         batch.randomize()                                  # do_agent.py:189-190
-    act = batch.act
-    totals = torch.zeros((N, 2), dtype=torch.float64, device=dev)
-    alive = torch.ones(N, dtype=torch.bool, device=dev)
-    act["n_groups"].zero_()
-    act["n_exploit"].zero_()
-    fused_views = hasattr(batch, "role_obs")
-    obs = None
-    ev = [] if timers is not None else None
+    # one action dict per role: the roles share every tensor but the mode words (no per-tick copy in steady state)
+    acts = {r: dict(batch.act) for r in ROLES}
+    for r in acts:
+        acts[r]["mode"] = torch.zeros_like(batch.act["mode"])
+    batch.act["n_groups"].zero_()
+    batch.act["n_exploit"].zero_()
+    if fused:
+        batch.reset_returns()
+        batch.prime_view(HL.DEFENDER)             # the first actor's observation (every later one comes from the tick itself)
+    else:
+        totals = torch.zeros((N, 2), dtype=torch.float64, device=dev)
+        alive = torch.ones(N, dtype=torch.bool, device=dev)
+    # timers: {"split": True} asks for the per-tick split (observe / policy+scatter / step, HIP events around each part:
+    # eager single-stream loop only); in any case the dict receives "loop_s" / "ticks" = HIP-event time of the tick loop
+    ev = [] if split else None
 
     def mark():
         if ev is not None:
@@ -267,43 +301,101 @@ def simulate_grid(batch, def_policies, att_policies, n_mc: int, T: int, randomiz
             e.record()
             ev.append(e)
 
-    for t in range(T):
-        role = HL.DEFENDER if t % 2 == 0 else HL.ATTACKER
-        nxt = HL.ATTACKER if role == HL.DEFENDER else HL.DEFENDER
+    def tick(t, j=0):
+        """Tick t of sub-batch j (on the current stream)."""
+        nonlocal totals, alive
+        role = ROLES[t % 2]
+        nxt = ROLES[(t + 1) % 2]
+        act = acts[role]
+        lo, hi = bounds[j]
         mark()
-        if obs is None:      # first tick (or a batch-like without fused role views)
-            obs = batch.observe(1 if role == HL.DEFENDER else 2)
+        obs = batch.role_obs[role] if fused else batch.observe(1 if role == HL.DEFENDER else 2)
         mark()
-        act["mode"].copy_(mode_words[t if t < 2 else 2 + (t % 2)])
-        for k, p in enumerate(pol[role]):
-            r = rows[role][k]
-            if r.numel() == 0:
-                continue
-            o = obs if r.numel() == N else obs.index_select(0, r)
-            a = p(o, t if getattr(p, "uses_global_tick", False) else t // 2, M, L)
-            _write_rows(batch, act, r, a, L)
+        if t < 4 and t < len(mode_words):
+            act["mode"][lo:hi].copy_(mode_words[t][lo:hi])
+        for p, r64, r32, sl in plan[role][j]:
+            o = obs[sl] if sl is not None else obs.index_select(0, r64)
+            if fused and hasattr(p, "write"):
+                p.write(batch, act, r32, o)
+            else:
+                a = p(o, t if getattr(p, "uses_global_tick", False) else t // 2, M, L)
+                if fused:
+                    batch.write_actions(r32, a, act)
+                else:
+                    _write_rows(batch, batch.act, r64, a, L)
         mark()
-        if fused_views:
-            _, raw, _, done = batch.step(view=nxt, full_obs=False)
-            obs = batch.role_obs[nxt] if t + 1 < T else None
+        if fused:
+            batch.step_range(lo, hi - lo, act, view=nxt, full_obs=False, returns=True)
         else:
+            batch.act["mode"].copy_(act["mode"])
             _, raw, _, done = batch.step()
-            obs = None
+            totals[:, t % 2] += torch.where(alive, raw, torch.zeros_like(raw))
+            alive = alive & (done == 0)
         mark()
-        totals[:, t % 2] += torch.where(alive, raw, torch.zeros_like(raw))
-        alive = alive & (done == 0)
         if trains and role == HL.DEFENDER and (batch.take_status() & S.E_DET_PENDING):
             batch.service_detectors()        # Detector.train is synchronous in the reference (volt_typhoon_env.py:961)
+
+    def ticks(t0, t1, cur):
+        """Ticks [t0, t1) of every sub-batch: sub-batch j on side stream j (fork from / join into `cur`)."""
+        if S_sub == 1:
+            for t in range(t0, t1):
+                tick(t)
+            return
+        for st in side:
+            st.wait_stream(cur)
+        for t in range(t0, t1):
+            for j, st in enumerate(side):
+                with torch.cuda.stream(st):
+                    tick(t, j)
+        for st in side:
+            cur.wait_stream(st)
+
+    use_graph = (graph and fused and not trains and T >= 10 and not split
+                 and all(getattr(p, "tick_free", False) for r in pol for p in pol[r]))
+    side = [torch.cuda.Stream(device=dev) for _ in range(S_sub)] if S_sub > 1 else []
+    on_gpu = dev.type == "cuda"
+    if timers is not None and on_gpu:
+        loop_ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        loop_ev[0].record()
+    t = 0
+    if use_graph:
+        main = torch.cuda.current_stream(dev)
+        ticks(0, 6, main)                         # mode words settle at tick 4; also the warm-up of the captured pair
+        t = 6
+        cap = torch.cuda.Stream(device=dev)
+        cap.wait_stream(main)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(cap):
+            with torch.cuda.graph(g, stream=cap):
+                ticks(t, t + 2, cap)
+            # (capturing does not execute: ticks 6, 7 run with the first replay)
+            while t + 2 <= T:
+                g.replay()
+                t += 2
+        main.wait_stream(cap)
+    if t < T:
+        ticks(t, T, torch.cuda.current_stream(dev) if on_gpu else None)
+    if timers is not None and on_gpu:
+        loop_ev[1].record()
+        loop_ev[1].synchronize()
+        timers["loop_s"] = timers.get("loop_s", 0.0) + loop_ev[0].elapsed_time(loop_ev[1]) * 1e-3
+        timers["ticks"] = timers.get("ticks", 0) + T
+        timers["graph"] = bool(use_graph)
+        timers["streams"] = S_sub
     if has_det or hasattr(batch, "unpinned_envs"):
         n_bad = batch.unpinned_envs()
         if n_bad:
             raise RuntimeError(f"{n_bad} env(s) ran a scan in trained-detector mode without a current forest "
                                "(CG_E_UNPINNED): their payoffs are not the reference's")
+    if fused:
+        if batch.take_status() & abi.DECODE_TRUNCATED:
+            raise RuntimeError("a policy chose more devices than the batch's max_devs holds: create the batch with a larger max_devs")
+        totals = batch.ret
     if ev is not None:
         torch.cuda.synchronize(dev)
         names = ("observe", "policy+scatter", "step")
         for j, name in enumerate(names):
-            timers[name] = timers.get(name, 0.0) + sum(ev[4 * t + j].elapsed_time(ev[4 * t + j + 1]) for t in range(T)) * 1e-3
+            timers[name] = timers.get(name, 0.0) + sum(ev[4 * i + j].elapsed_time(ev[4 * i + j + 1]) for i in range(len(ev) // 4)) * 1e-3
     both = sharding.gather_by_env(totals, n_total, group)   # no-op on one rank
     if both.shape[0] != cells:
         raise ValueError("gathered cells do not cover the grid")

@@ -171,6 +171,11 @@ typedef struct cygym_outputs {
    * launch in between.  An env that auto-resets in this tick reports the view of its reloaded state.       */
   float*   obs_def; /* [N][6M]                 _get_defender_state()            */
   float*   obs_att; /* [N][4M + MaxExploits]   _get_attacker_state()            */
+  /* Optional episode-return accumulators of a rollout loop (do_agent.py:266-274: `def_total += r` on defender turns,
+   * `att_total += r` on attacker turns, `if done: break`): while alive[env] != 0 the tick adds its raw reward to
+   * ret[env][mode & 1], and a tick that reports done clears alive[env].  Both NULL: nothing is accumulated.   */
+  double*  ret;     /* [N][2] (defender, attacker) reward sums                   */
+  uint8_t* alive;   /* [N] 1 until the env's first done                           */
   uint32_t* status; /* optional, ONE word: OR of (CG_E_TOPO_OVF | CG_E_BUSY_SAT | CG_E_DET_PENDING | CG_E_UNPINNED)
                        over the envs this launch ticked, as they stand at write-back (atomically OR-ed in: clear
                        it before the launch).  Lets a driver learn with one 4-byte read whether any env asked for
@@ -180,6 +185,10 @@ typedef struct cygym_outputs {
 typedef struct cygym_handle cygym_handle;
 
 int cygym_version(void);
+/* sizeof of the ABI structs as this library was compiled (which: 0 cygym_topology, 1 cygym_config, 2 cygym_buffers,
+ * 3 cygym_actions, 4 cygym_outputs, 5 cygym_action_rows, 6 cygym_action_vectors, 7 cygym_actor_head; -1 for anything else): lets a
+ * binding check its own struct layouts at load time. */
+int cygym_sizeof(int32_t which);
 const char* cygym_last_error(const cygym_handle* h);  /* h may be NULL */
 
 /* Replaces: building the env object's caches after initialize_environment()
@@ -256,6 +265,49 @@ typedef struct cygym_action_rows {
  * per strategy of a closed loop instead of one tensor op per field.  Replaces the per-env action-tuple assembly of
  * the reference's loop (do_agent.py:206-265) for a batch. */
 int cygym_write_actions(cygym_handle* h, const cygym_action_rows* src, const cygym_actions* dst, void* stream);
+
+/* Actor outputs of n envs, DEVICE pointers: one row per env laid out as the reference's DDPG / actor-critic policies
+ * emit it (do_agent.py:1016-1020): [n_types action-type logits | n_devices device values | n_exploits exploit values |
+ * n_apps app values]. */
+typedef struct cygym_action_vectors {
+  const int32_t* rows;     /* [n] env ids (rows of the action tensors) to write; NULL = rows 0..n-1             */
+  const float*   vec;      /* [n][stride]                                                                      */
+  const int32_t* type_map; /* optional [n_types]: the action type each logit stands for (NULL: its index)      */
+  int32_t stride;          /* floats per row, >= n_types + n_devices + n_exploits + n_apps                     */
+  int32_t n_types, n_devices, n_exploits, n_apps;
+  int32_t n;
+  uint64_t epsilon_thr;    /* ceil(epsilon * 2^32): with probability epsilon the action type is a uniformly random one
+                              instead of the argmax (the epsilon-greedy of decode_action, do_agent.py:972-973), drawn
+                              with the Philox draw addressed (env, the env's current rng tick, CG_SITE_EPS_TYPE); 0 = greedy.
+                              Needs a bound handle (the rng ticks are read from cygym_buffers.ienv)                */
+  uint32_t* status;        /* optional, ONE word: CG_DECODE_TRUNCATED is OR-ed in when a row chose more devices than
+                              the action tensors' max_devs holds (the list is cut to the first max_devs ids)    */
+} cygym_action_vectors;
+#define CG_DECODE_TRUNCATED 0x10000u
+
+/* Replaces: DoubleOracle.decode_action (do_agent.py:935-998, the plain branch :970-998) for a batch, fused with the
+ * scatter into the action tensors: action_type = argmax of the type logits (first maximum, like np.argmax),
+ * device_indices = ascending ids whose value is > 0, exploit_indices = [argmax of the exploit values] ([0] when
+ * n_exploits == 0), app_index = argmax of the app values (0 when n_apps == 0).  Values must be finite.  Writes group 0
+ * of the rows like cygym_write_actions; n_devices must equal the handle's device count. */
+int cygym_decode_actions(cygym_handle* h, const cygym_action_vectors* src, const cygym_actions* dst, void* stream);
+
+/* The LAST layer of an actor network fused with cygym_decode_actions: `vec` of cygym_action_vectors is not read;
+ * row r of the action vectors is  act(hidden[r] x weight_t + bias)  with weight_t [H][pitch] (k-major: torch's
+ * nn.Linear.weight transposed), n_out = n_types + n_devices + n_exploits + n_apps, act = tanh when `tanh_out` (the reference's
+ * actor ends in tanh, do_agent.py:370) else identity -- computed in fp32 in the kernel (k ascending per output) and
+ * decoded from registers, so the [n][n_out] action vectors never touch HBM.  Limits: H <= 256, n_out <= 512
+ * (CYGYM_EUNSUPPORTED otherwise: run the layer yourself and call cygym_decode_actions). */
+typedef struct cygym_actor_head {
+  const float* hidden;     /* [n][hidden_stride] activations of the actor's last hidden layer                   */
+  const float* weight_t;   /* [H][weight_pitch], the first n_out entries of a row are used                       */
+  const float* bias;       /* [n_out] or NULL                                                                  */
+  int32_t H, hidden_stride;
+  int32_t tanh_out;
+  int32_t weight_pitch;    /* floats per row of weight_t: n_out rounded up to a multiple of 64 (rows 16-byte aligned)  */
+} cygym_actor_head;
+int cygym_actor_head_decode(cygym_handle* h, const cygym_actor_head* head, const cygym_action_vectors* layout,
+                            const cygym_actions* dst, void* stream);
 
 /* Synthetic action script of bench.py -- not a reference
  * interface: fills one tick's cygym_actions from Philox on device. */

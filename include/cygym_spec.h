@@ -179,7 +179,10 @@ enum {
   CG_SITE_DET_COIN,          /* CDSimulator.py:716               a=window pos b=scan  */
   CG_SITE_LAZY,              /* CDSimulator.py:328 (no observable effect)             */
   CG_SITE_DET_FIT,           /* CDSimulator.py:694 IsolationForest.fit: seed of the numpy stream it draws from */
-  CG_SITE_ACTGEN = 64        /* synthetic action script of bench.py (not reference)   */
+  CG_SITE_ACTGEN = 64,       /* synthetic action script of bench.py (not reference)   */
+  CG_SITE_EPS_TYPE = 65      /* do_agent.py:972-973 epsilon-greedy action type of decode_action: word 0 is the coin
+                                (u < ceil(eps * 2^32)), word 1 the uniform type index.  Addressed by the env's own rng
+                                tick, read when the action is decoded (the tick that will execute it)            */
 };
 
 /* ---- Philox4x32-10 (Salmon et al., SC'11), counter-based ----

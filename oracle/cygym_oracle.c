@@ -799,6 +799,10 @@ static void step_one(env_t* e, const cygym_actions* a, const cygym_outputs* o, i
   o->raw[idx] = raw;
   o->shaped[idx] = shaped;
   o->done[idx] = (uint8_t)done;
+  if (o->ret && o->alive && o->alive[idx]) { /* episode returns of a rollout loop (do_agent.py:266-274) */
+    o->ret[(size_t)idx * 2 + (mode & 1)] += raw;
+    if (done) o->alive[idx] = 0;
+  }
   if (done && e->c->auto_reset && snap) snapshot_restore(e, snap, idx);
   /* optional role views of the state the tick leaves behind (cygym_outputs.obs_def / obs_att) + the status word */
   if (o->obs_def) observe_one(e, 1, o->obs_def + (size_t)idx * 6 * M);

@@ -81,3 +81,19 @@ class IntPolicy:
         return {"atype": atype, "exploit": expl, "dev_mask": mask, "app": torch.remainder(h[:, 0], 4).to(torch.int32)}
 
 
+
+
+class IntActor(torch.nn.Module):
+    """An actor network (role observation -> action vector [type logits | device values | exploit values | app values],
+    do_agent.py:1016-1020) with integer weights: every value is a small integer, exact in float32 on CPU and GPU, and
+    `16 * z + position` makes every argmax unique -- so the fused decode, the torch decode and np.argmax agree."""
+
+    def __init__(self, state_dim, action_dim, seed, hidden=8):
+        super().__init__()
+        rs = np.random.RandomState(seed)
+        self.w1 = torch.nn.Parameter(torch.tensor(rs.randint(-1, 2, size=(state_dim, hidden)), dtype=torch.float32), requires_grad=False)
+        self.w2 = torch.nn.Parameter(torch.tensor(rs.randint(-1, 2, size=(hidden, action_dim)), dtype=torch.float32), requires_grad=False)
+        self.pos = torch.nn.Parameter(torch.arange(action_dim, dtype=torch.float32) - action_dim // 3, requires_grad=False)
+
+    def forward(self, x):
+        return (torch.relu(x @ self.w1) @ self.w2) * 16 + self.pos

@@ -164,7 +164,10 @@ def test_baseline_names_persist_for_the_other_role():
     np.testing.assert_allclose(U_def, E_def, rtol=0, atol=1e-9)
     np.testing.assert_allclose(U_att, E_att, rtol=0, atol=1e-9)
     np.testing.assert_array_equal(flags, og.ob.state["flags"])
-    C_def, C_att = simulate_grid(batch, D, A, n_mc, T, randomize=False)       # the closed-loop path agrees
+    batch.close()
+    # the closed-loop path agrees (a fresh batch: reset() keeps an env's draw counter running, like a new episode)
+    batch = BatchedCyberDefenseEnv(topo, cfg, N, init, device="cuda:0", max_groups=1, max_devs=8)
+    C_def, C_att = simulate_grid(batch, D, A, n_mc, T, randomize=False)
     np.testing.assert_allclose(C_def, E_def, rtol=0, atol=1e-9)
     np.testing.assert_allclose(C_att, E_att, rtol=0, atol=1e-9)
     batch.close()
@@ -220,6 +223,122 @@ def test_fused_role_views_status_word_and_action_scatter():
         want = idx.flip(1)
         want = torch.where(torch.arange(L, device=want.device)[None, :] < cnt[:, None], want, torch.zeros_like(want))
         assert torch.equal(env.act["dev_idx"][rows], want)
+        env.close()
+
+
+def test_actor_policies_fused_decode_equals_the_oracle_loop_eager_and_graph():
+    """cygym_amd.policies.ActorPolicy: actor forward + ONE fused decode-and-scatter launch (cygym_decode_actions =
+    do_agent.decode_action for a batch), role views and episode returns from the tick kernel -- eager and replayed from
+    a HIP graph -- against the same actors decoded with torch ops on the oracle loop."""
+    from grid_util import IntActor
+    from cygym_amd.batched_env import BatchedCyberDefenseEnv
+    from cygym_amd.policies import ActorPolicy
+    from cygym_amd.rollout_grid import simulate_grid
+    topo, init, cfg = _setup()
+    M, X, T, n_mc = topo.M, cfg.max_exploits, 41, 5
+    def_types = [1, 4, 5, 6, 7, 8, 9, 13, 2, 12, 11, 3]
+    def make(dev):
+        D = [ActorPolicy(IntActor(6 * M, len(def_types) + M + X + 4, 21).to(dev), len(def_types), X, 4, type_map=def_types),
+             ActorPolicy(IntActor(6 * M, len(def_types) + M + X + 4, 22).to(dev), len(def_types), X, 4, type_map=def_types), "No Defense"]
+        A = [ActorPolicy(IntActor(4 * M + X, 4 + M + X, 23).to(dev), 4, X, 0), ActorPolicy(IntActor(4 * M + X, 3 + M + X, 24).to(dev), 3, X, 0)]
+        return D, A
+    N = 3 * 2 * n_mc
+    og = OracleGrid(topo, cfg, N, init, 1, M)
+    E_def, E_att = simulate_grid(og, *make("cpu"), n_mc, T, randomize=True)
+    assert len(np.unique(np.round(E_def, 6))) > 3
+    for graph, streams in ((False, 1), (True, 1), (False, 3), (True, 2)):
+        batch = BatchedCyberDefenseEnv(topo, cfg, N, init, device="cuda:0", max_groups=1, max_devs=M)
+        U_def, U_att = simulate_grid(batch, *make("cuda:0"), n_mc, T, randomize=True, graph=graph, streams=streams)
+        np.testing.assert_allclose(U_def, E_def, rtol=0, atol=1e-9, err_msg=f"graph={graph} streams={streams}")
+        np.testing.assert_allclose(U_att, E_att, rtol=0, atol=1e-9, err_msg=f"graph={graph} streams={streams}")
+        got = batch.state_numpy()
+        got["ienv"] = got["ienv"].copy(); got["ienv"][:, S.I_FLAGS] &= ~0x80
+        assert not gio.compare_state(got, og.ob.state, f"actor grid graph={graph}")
+        for k in ("atype", "dev_cnt", "dev_idx", "exploit", "app"):      # the last tick's decoded actions
+            np.testing.assert_array_equal(batch.act[k].cpu().numpy(), og.act_np[k], err_msg=f"{k} graph={graph}")
+        batch.close()
+    # a list capacity the policies overflow is reported, not silently cut
+    small = BatchedCyberDefenseEnv(topo, cfg, N, init, device="cuda:0", max_groups=1, max_devs=2)
+    with pytest.raises(RuntimeError, match="max_devs"):
+        simulate_grid(small, *make("cuda:0"), n_mc, 6, randomize=True)
+    small.close()
+
+
+def test_decode_actions_matches_numpy_including_epsilon_greedy():
+    """cygym_decode_actions against do_agent.decode_action restated with numpy (:970-998): argmax type through the type
+    map, ascending ids of positive device values, argmax exploit / app; with epsilon the coin and the uniform index of
+    the addressed Philox draw (env, the env's rng tick, CG_SITE_EPS_TYPE)."""
+    from cygym_amd import rng as R
+    from cygym_amd.batched_env import BatchedCyberDefenseEnv
+    from cygym_amd.topology import make_topology
+    M, N = 100, 77
+    topo, init, ck = make_topology(M, 2, seed=6, n_active=90)
+    cfg = abi.EnvConfig(seed=0x1234567890, env_id_base=1000, **ck)
+    env = BatchedCyberDefenseEnv(topo, cfg, N, init, device="cuda:0", max_groups=1, max_devs=M)
+    for t in range(3):
+        env.gen_actions(t); env.step()                 # rng ticks move on
+    X, n_types, n_apps = cfg.max_exploits, 9, 5
+    tm = np.array([1, 4, 5, 6, 7, 8, 9, 13, 2], np.int32)
+    g = torch.Generator().manual_seed(3)
+    vec = torch.randn((N, n_types + M + X + n_apps + 3), generator=g)           # (stride wider than the layout)
+    rows = torch.randperm(N, generator=g)[:50].sort().values
+    v = vec[:50].numpy()
+    ticks = env.state["ienv"][:, S.I_RNG_TICK].cpu().numpy()
+    for eps in (0.0, 0.35, 1.0):
+        env.act["atype"].fill_(-7)
+        env.decode_actions(rows.to("cuda:0"), vec[:50].to("cuda:0"), n_types, X, n_apps, torch.from_numpy(tm).to("cuda:0"), epsilon=eps)
+        at = np.argmax(v[:, :n_types], axis=1)
+        if eps > 0:
+            c = R.philox4x32_10_np(cfg.env_id_base + rows.numpy(), ticks[rows.numpy()], S.SITE_EPS_TYPE, 0, cfg.seed & 0xFFFFFFFF, cfg.seed >> 32)
+            coin = c[0] < R.bernoulli_threshold(eps)
+            at = np.where(coin, ((c[1].astype(np.uint64) * np.uint64(n_types)) >> np.uint64(32)).astype(np.int64), at)
+            assert eps == 1.0 or (0 < coin.sum() < 50)
+        got = {k: t.cpu().numpy() for k, t in env.act.items()}
+        np.testing.assert_array_equal(got["atype"][rows.numpy(), 0], tm[at], err_msg=f"eps={eps}")
+        assert (got["atype"][np.setdiff1d(np.arange(N), rows.numpy()), 0] == -7).all()
+        for i, r in enumerate(rows.numpy()):
+            ids = np.nonzero(v[i, n_types:n_types + M] > 0)[0]
+            assert got["dev_cnt"][r, 0] == len(ids) and (got["dev_idx"][r, :len(ids)] == ids).all() and (got["dev_idx"][r, len(ids):] == 0).all()
+            assert got["exploit"][r, 0, 0] == np.argmax(v[i, n_types + M:n_types + M + X]) and got["n_exploit"][r, 0] == 1
+            assert got["app"][r, 0] == np.argmax(v[i, n_types + M + X:n_types + M + X + n_apps])
+    env.close()
+
+
+def test_actor_head_kernel_equals_linear_plus_decode():
+    """cygym_actor_head_decode (last Linear layer + decode in one launch, action vectors in registers) against
+    nn.Linear followed by cygym_decode_actions: exact on integer-valued weights (H = 64 and a two-slab H = 160), and on
+    float weights with tanh wherever the decision is not a near-tie."""
+    from cygym_amd.batched_env import BatchedCyberDefenseEnv
+    from cygym_amd.topology import make_topology
+    for M, H, n_types, n_apps in ((256, 64, 11, 4), (64, 160, 3, 0), (37, 32, 14, 7)):
+        topo, init, ck = make_topology(M, 1 if M != 64 else 4, seed=2, n_active=max(8, M - 8))
+        cfg = abi.EnvConfig(seed=2, **ck)
+        N, X = 203, cfg.max_exploits
+        env = BatchedCyberDefenseEnv(topo, cfg, N, init, device="cuda:0", max_groups=1, max_devs=M)
+        other = {k: v.clone() for k, v in env.act.items()}
+        n_out = n_types + M + X + n_apps
+        g = torch.Generator().manual_seed(M)
+        hidden = torch.randint(0, 4, (N, H + 5), generator=g).float().to("cuda:0")[:, :H]          # (row stride > H)
+        W = (torch.randint(-1, 2, (n_out, H), generator=g) * 16).float().to("cuda:0")
+        b = (torch.arange(n_out) - n_out // 3).float().to("cuda:0")
+        rows = torch.randperm(N, generator=g)[:150].sort().values.to("cuda:0")
+        tm = torch.arange(n_types, dtype=torch.int32, device="cuda:0") + 1
+        env.actor_head_decode(rows, hidden[:150], env.head_weights(W), b, n_types, X, n_apps, tm, epsilon=0.3)
+        env.decode_actions(rows, torch.addmm(b, hidden[:150], W.t()), n_types, X, n_apps, tm, act=other, epsilon=0.3)
+        for k in other:
+            assert torch.equal(env.act[k], other[k]), f"M={M} H={H}: {k}"
+        # float weights + tanh: compare with torch on the rows whose decisions are clear
+        Wf = torch.randn((n_out, H), generator=g).to("cuda:0") * 0.05
+        bf = torch.randn((n_out,), generator=g).to("cuda:0") * 0.1
+        env.actor_head_decode(None, hidden, env.head_weights(Wf), bf, n_types, X, n_apps, None, tanh=True)
+        v = torch.tanh(torch.addmm(bf.double(), hidden.double(), Wf.double().t()).float())
+        top2 = torch.topk(v[:, :n_types], 2, dim=1).values
+        clear = (top2[:, 0] - top2[:, 1]) > 1e-4
+        assert clear.sum() > N // 2
+        assert torch.equal(env.act["atype"][clear, 0], torch.argmax(v[:, :n_types], dim=1).to(torch.int32)[clear])
+        dv = v[:, n_types:n_types + M]
+        sure = (dv.abs() > 1e-4).all(dim=1)
+        assert torch.equal(env.act["dev_cnt"][sure, 0], (dv > 0).sum(dim=1).to(torch.int32)[sure]) and sure.sum() > N // 2
         env.close()
 
 
