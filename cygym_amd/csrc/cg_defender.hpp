@@ -142,7 +142,10 @@ struct PoolPtrs {
 template <bool WIDE>
 __device__ __forceinline__ Pick pool_pick(const PoolPtrs q, bool want, uint32_t u, int o0, int o1, int i0, int i1) {
   Pick p; p.slot = -1; p.j = -1; p.x = -1;
-  const int nbo = WIDE ? range_popc_wide(q.blk, o0, o1) : range_popc(q.blk, o0, o1);
+  int nbo = WIDE ? range_popc_wide(q.blk, o0, o1) : range_popc(q.blk, o0, o1);
+#ifdef CG_SEQ_POOLS
+  if constexpr (WIDE) asm volatile("" : "+v"(nbo));   // the out-pool count is complete before the in-pool words are loaded
+#endif
   const int nbi = WIDE ? range_popc_wide(q.bin, i0, i1) : range_popc(q.bin, i0, i1);
   const int n_out = want ? nbo : (o1 - o0) - nbo;
   const int n_in = want ? nbi : (i1 - i0) - nbi;

@@ -73,10 +73,12 @@ __device__ __forceinline__ int range_popc(const uint32_t* blk, int a, int b) {
 #ifndef CG_WIDE_W
 #define CG_WIDE_W 9
 #endif
+// (Rows longer than 9 words cannot occur where these are used: the WIDE kernel is only chosen for topologies whose
+// out- and in-rows hold at most 256 slots, choose_launch -- so there is no fallback loop, whose LDS addresses were the
+// kernel's last two spilled VGPRs.)
 __device__ __forceinline__ int range_popc_wide(const uint32_t* blk, int a, int b) {
   if (a >= b) return 0;
   const int w0 = a >> 5, w1 = (b - 1) >> 5;
-  if (w1 - w0 >= CG_WIDE_W) return range_popc(blk, a, b);
   int n = 0;
 #pragma unroll
   for (int j = 0; j < CG_WIDE_W; ++j) {
@@ -106,7 +108,6 @@ __device__ __forceinline__ int range_select(const uint32_t* blk, int a, int b, b
 // callers only (block / unblock pools), see range_popc_wide
 __device__ __forceinline__ int range_select_wide(const uint32_t* blk, int a, int b, bool want, int r) {
   const int w0 = a >> 5, w1 = (b - 1) >> 5;
-  if (w1 - w0 >= CG_WIDE_W) return range_select(blk, a, b, want, r);
   const uint32_t inv = want ? 0u : 0xFFFFFFFFu;
   const uint32_t m_lo = 0xFFFFFFFFu << (a & 31), m_hi = (b & 31) ? 0xFFFFFFFFu >> (32 - (b & 31)) : 0xFFFFFFFFu;
   int cum = 0, wsel = 0, rbase = 0;

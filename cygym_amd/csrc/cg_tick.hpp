@@ -342,6 +342,22 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 &
   __syncthreads();   // the only workgroup barrier: waves diverge per env from here on
   if (!live) return;
   STAMP(1);
+#ifndef CG_NO_UNIFORM_SCALARS
+  if constexpr (!FUSED) {
+    // The 16 + 3 per-env scalars were fetched with vector loads (a uniform address into memory the kernel also
+    // writes is not eligible for the scalar cache), i.e. into 22 VGPRs that stay live to the write-back.  Telling
+    // the compiler they are uniform moves them to SGPRs: the VGPRs go back to the per-lane work (the WIDE kernel
+    // spilled 7 of them, an f64 accumulator among them), and a spilled SGPR costs a v_writelane, not scratch traffic.
+#pragma unroll
+    for (int i = 0; i < CG_I_COUNT; ++i) ie[i] = __builtin_amdgcn_readfirstlane(ie[i]);
+#pragma unroll
+    for (int i = 0; i < CG_D_COUNT; ++i)
+      fe[i] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(fe[i])), __builtin_amdgcn_readfirstlane(__double2loint(fe[i])));
+    mode = __builtin_amdgcn_readfirstlane(mode); ng = __builtin_amdgcn_readfirstlane(ng); at0 = __builtin_amdgcn_readfirstlane(at0);
+    cnt0 = __builtin_amdgcn_readfirstlane(cnt0); nexp0 = __builtin_amdgcn_readfirstlane(nexp0); app0 = __builtin_amdgcn_readfirstlane(app0);
+    ex0 = __builtin_amdgcn_readfirstlane(ex0);   // (the tick's action header: uniform as well)
+  }
+#endif
 
   const int NW = MS >> 2;
   // word loops run in groups of WGP words per lane, loads first (see the chunk loops of the spread): one LDS round trip
@@ -698,6 +714,9 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 &
 
   STAMP(6);
   // ---- write back: the whole [4][M] live block with 16-byte stores ----
+  // (the lane id is laundered: the per-lane global addresses of the write-back are recomputed here instead of being
+  // kept -- or spilled -- from the prologue, where the same addresses were used for the loads)
+  asm volatile("" : "+v"(lane));
   if (vec) {
     for (int i = lane; i < items; i += WAVE) ((uint4*)(P.b.live + so))[i] = ((const uint4*)e.flags)[i];
   } else {

@@ -57,6 +57,7 @@ struct cygym_handle {
   bool few_waves;       // n_envs <= 16 per CU: one wave per env cannot use more than 4 waves per SIMD
   bool wide;            // the WIDE per-tick kernel runs: one 16-wave workgroup per CU with the WHOLE blob (in-CSR maps too) in LDS
   int o_maps_end;       // blob offset just past the in-CSR maps
+  int max_row;          // longest out- or in-row of the shared CSR, in slots
   int wave_lds, shared_lds;
   hipEvent_t ev0, ev1;
   unsigned long long* dbg;
@@ -205,7 +206,8 @@ static int choose_launch(cygym_handle* h, int max_devs) {
   // on defender ticks is a block / unblock list): one 16-wave workgroup per CU leaves room for the in-CSR columns and
   // slot maps in LDS as well, so a speculation pass no longer waits on global memory.  Compile-time size 256, lean only.
   h->wide = false;
-  if (h->few_waves && t.M == 256 && !full_feature(h) && !forced && (size_t)h->o_maps_end + wave * 16 <= lds_cap) {
+  // (its nine-word pool reads cover rows of at most 256 slots: max_row is checked here, there is no fallback in the kernel)
+  if (h->few_waves && t.M == 256 && !full_feature(h) && !forced && h->max_row <= 256 && (size_t)h->o_maps_end + wave * 16 <= lds_cap) {
     h->wide = true;
     h->wpb = 16; h->wpb_fused = 16; h->shared_lds = h->o_maps_end;
     t.lds_bytes = h->o_maps_end; t.in_lds = 1;
@@ -291,6 +293,12 @@ int cygym_create(const cygym_topology* topo, const cygym_config* cfg, int32_t n_
     for (int k = topo->out_ptr[u]; k < topo->out_ptr[u + 1] && !t.multi; ++k)
       for (int k2 = k + 1; k2 < topo->out_ptr[u + 1]; ++k2)
         if (topo->out_col[k2] == topo->out_col[k]) { t.multi = 1; break; }
+  h->max_row = 0;
+  for (int u = 0; u < M; ++u) {
+    const int lo = topo->out_ptr[u + 1] - topo->out_ptr[u], li = topo->in_ptr[u + 1] - topo->in_ptr[u];
+    if (lo > h->max_row) h->max_row = lo;
+    if (li > h->max_row) h->max_row = li;
+  }
   if (choose_launch(h, M > 8 ? M / 8 : 1) != 0) { delete h; return fail(nullptr, CYGYM_EUNSUPPORTED, "topology does not fit in LDS%s", ""); }
   uint8_t* host = (uint8_t*)calloc(1, off);
   if (!host) { delete h; return fail(nullptr, CYGYM_EINVAL, "out of host memory%s", ""); }

@@ -154,11 +154,11 @@ def test_tick_kernels_do_not_spill():
         mt, fused, xe, wide = int(m.group(1)), m.group(2) == "1", m.group(3) == "1", m.group(4) == "1"
         seen.add((fused, xe))
         if wide:          # held at 128 VGPRs (4 waves per SIMD = the whole 4096-env batch in one residency round) with its
-            # nine-words-at-once pool counts and selects: a handful of spilled registers measured 9 % FASTER than the
-            # narrow variant without spills, more than that is a regression
-            assert r["vgprs"] <= 128 and r.get("vgpr_spill", 0) <= 10 and r["scratch"] <= 48, (name, r)
+            # nine-words-at-once pool counts and selects -- and, like every other variant, without a single spilled VGPR
+            # (round 2 tolerated 7 here, next to ~130 SGPRs in VGPR lanes: the pattern CG_LB records as miscompiled once)
+            assert r["vgprs"] <= 128 and r.get("vgpr_spill", 0) == 0 and r["scratch"] == 0, (name, r)
             continue
-        # every other instantiation -- lean and full-feature, per-tick and rollout, every workgroup shape: NO spilled
+        # every instantiation -- lean and full-feature, per-tick and rollout, every workgroup shape: NO spilled
         # VGPRs.  (History: spills in the rollout kernel once meant flat addressing through generic pointers, -25 %;
         # spilled VGPRs next to ~150 SGPRs kept in VGPR lanes miscompiled a full-feature kernel at an 80-VGPR cap, see
         # CG_LB in csrc/cg_device.hpp.)  Some instantiations reserve a private segment of a few dozen bytes that no
