@@ -534,9 +534,13 @@ def main():
                     help="which way of issuing the K steps fills value / roofline (the other one is reported beside it)")
     args = ap.parse_args()
 
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world_env:
+        # one rank per GPU: a run whose rank count differs from --gpus would report the wrong job size under the right label
+        print(f"[bench] error: --gpus {args.gpus} but WORLD_SIZE={world_env}: launch with `python -m torch.distributed.run --nnodes=1 "
+              f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...`", file=sys.stderr)
+        sys.exit(2)
     D = Dist()
-    if args.gpus != D.world and D.rank == 0 and D.world > 1:
-        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={D.world}", file=sys.stderr)
     K, W = args.steps, args.warmup
     name = args.workload
     n_per_gpu = args.envs or WORKLOADS[name][0]

@@ -106,6 +106,41 @@ class SubnetView:
     def __init__(self, net, graph):
         self.net = net
         self.graph = graph
+        self.partitions = None
+
+    def create_partitions(self, partition_size: int):
+        """Subnet.create_partitions (CDSimulatorComponents.py:556-582): disjoint parts of about `partition_size` devices,
+        stored in `.partitions` as lists of device ids (read by the hierarchical agents, hierarchical_br.py:142-147,
+        :435-438).  The reference asks METIS (pymetis.part_graph) for nparts = ceil(n / partition_size) parts; METIS's
+        exact cut is a property of that library build and is not pinned here (pymetis is not installable in this
+        image): this is a deterministic balanced partition of the same graph with the same part count -- breadth-first
+        order from the lowest unvisited id over the undirected adjacency, cut into nparts runs whose sizes differ by
+        at most one -- so connected devices land together, like a graph partitioner's parts."""
+        import math
+        n = self.graph.vcount()
+        if n == 0:
+            raise ValueError("Cannot partition an empty graph")
+        nparts = min(max(1, math.ceil(n / partition_size)), n)
+        seen, order = [False] * n, []
+        for root in range(n):
+            if seen[root]:
+                continue
+            seen[root] = True
+            queue = [root]
+            while queue:
+                v = queue.pop(0)
+                order.append(v)
+                for w in self.graph.neighbors(v, mode="all"):
+                    if not seen[w]:
+                        seen[w] = True
+                        queue.append(w)
+        q, r = divmod(n, nparts)
+        parts, pos = [], 0
+        for p in range(nparts):
+            size = q + (1 if p < r else 0)
+            parts.append(sorted(order[pos:pos + size]))
+            pos += size
+        self.partitions = parts
 
 
 class LoggerView:

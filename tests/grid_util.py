@@ -36,6 +36,22 @@ class OracleGrid:
         obs, raw, shaped, done = self.ob.step(self.act_np)
         return torch.from_numpy(obs), torch.from_numpy(raw.copy()), torch.from_numpy(shaped.copy()), torch.from_numpy(done.copy())
 
+    def alloc_rollout(self, T):
+        act = {k: torch.zeros((T,) + tuple(v.shape), dtype=v.dtype) for k, v in self.act.items()}
+        act["exploit"].fill_(-1); act["app"].fill_(-1)
+        return act, {"raw": torch.zeros((T, self.N), dtype=torch.float64)}
+
+    def rollout(self, act, out):
+        """cygym_rollout's contract on the oracle: T ticks of a pre-staged script, trainings serviced after their tick."""
+        for t in range(act["mode"].shape[0]):
+            for k in self.act_np:
+                self.act_np[k][...] = act[k][t].numpy()
+            _, raw, _, _ = self.step()
+            out["raw"][t] = raw
+            if self.detector and (self.take_status() & S.E_DET_PENDING):
+                self.service_detectors()
+        return out
+
     def take_status(self):
         return int(np.bitwise_or.reduce(self.ob.state["ienv"][:, S.I_FLAGS]) & (S.E_TOPO_OVF | S.E_BUSY_SAT | S.E_DET_PENDING | S.E_UNPINNED))
 

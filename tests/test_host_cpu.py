@@ -267,3 +267,24 @@ def test_profile_summary_parser(tmp_path):
     assert tr[("per_tick", 4096)] == [20.0, 24.0] and tr[("fused", 4096)] == [400.0]
     assert tp.kernel_class("_ZN12_GLOBAL__N_111step_kernelILi8ELi256ELb1ELb0ELb0EEEvNS_7KParamsE") == "fused"
     assert tp.kernel_class("gen_actions_kernel") is None
+
+
+def test_subnet_view_create_partitions():
+    """SubnetView.create_partitions (the METIS call of CDSimulatorComponents.py:556-582 replaced by a deterministic
+    balanced BFS partition): nparts = ceil(n / size), disjoint cover, sizes within one, `.partitions` as lists of ids."""
+    from cygym_amd.facade import GraphView, SubnetView
+    from cygym_amd.topology import make_topology
+    topo, _, _ = make_topology(64, 4, seed=3, n_active=56)
+    topo = topo.normalised()
+    sub = SubnetView({}, GraphView(topo, np.zeros(topo.E, np.uint8)))
+    assert sub.partitions is None
+    for size in (16, 10, 64, 1, 100):
+        sub.create_partitions(size)
+        parts = sub.partitions
+        assert len(parts) == min(max(1, -(-64 // size)), 64)
+        assert sorted(x for p in parts for x in p) == list(range(64))
+        assert max(map(len, parts)) - min(map(len, parts)) <= 1
+    sub.create_partitions(16)
+    again = [list(p) for p in sub.partitions]
+    sub.create_partitions(16)
+    assert again == sub.partitions

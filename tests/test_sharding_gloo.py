@@ -70,3 +70,48 @@ def test_two_rank_gloo_equals_single_process(tmp_path):
     ret_full, flags_full = _run_shard(_base_cfg(), N_TOTAL)
     np.testing.assert_allclose(np.load(out + ".ret.npy"), ret_full, rtol=0, atol=1e-9)
     np.testing.assert_array_equal(np.load(out + ".flags.npy"), flags_full)
+
+
+# ---- the grid consumer sharded by cell: 4 ranks, `cell_offset` / `n_total`, gathered payoff matrices ----
+GRID_D = ["No Defense", [(1, [0], [3, 9, 12], 0), (7, [0], [5], 0), (6, [0], [1, 2, 3, 4], 0)]]
+GRID_A = ["No Attack", [(1, [0], [], 0)], [(2, [0], [], 0), (1, [1], [], 0)]]
+GRID_MC, GRID_T = 5, 16                                   # 2 x 3 x 5 = 30 cells over 4 ranks: shards of 8, 8, 7, 7
+
+
+def _grid_shard(rank, world, closed_loop):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from grid_util import OracleGrid
+    from cygym_amd.rollout_grid import payoff_grid, simulate_grid
+    topo, init, _ = make_topology(M, 4, seed=SEED, n_active=56)
+    cells = len(GRID_D) * len(GRID_A) * GRID_MC
+    begin, end = sharding.shard_range(cells, rank, world)
+    cfg, n_local = sharding.shard_config(_base_cfg(), cells, rank, world)      # env_id_base = first cell of the shard
+    og = OracleGrid(topo, cfg, n_local, init, 1, 8)
+    fn = simulate_grid if closed_loop else payoff_grid
+    return fn(og, GRID_D, GRID_A, GRID_MC, GRID_T, randomize=True, n_total=cells, cell_offset=begin)
+
+
+def _grid_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = [_grid_shard(rank, world, cl) for cl in (False, True)]
+    np.save(out + f".r{rank}.npy", np.stack([np.stack(r) for r in res]))       # [2 ways, (U_def, U_att), |D|, |A|]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_four_rank_grid_shards_equal_single_process(tmp_path):
+    """payoff_grid and simulate_grid with the cells sharded over 4 gloo ranks (`cell_offset`, per-rank env_id_base,
+    gather_by_env before averaging): every rank ends with the full payoff matrices of the single-process run."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "grid")
+    mp.spawn(_grid_worker, args=(4, port, out), nprocs=4, join=True)
+    full = np.stack([np.stack(_grid_shard(0, 1, cl)) for cl in (False, True)])
+    np.testing.assert_allclose(full[0], full[1], rtol=0, atol=1e-9)           # open-loop script == closed-loop SequencePolicy
+    for r in range(4):
+        np.testing.assert_allclose(np.load(out + f".r{r}.npy"), full, rtol=0, atol=1e-9, err_msg=f"rank {r}")

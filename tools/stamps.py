@@ -5,7 +5,8 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from cygym_amd import abi, build as B
 so = os.path.join(ROOT, "cygym_amd", "libcygym_hip_stamps.so")
-B.build_to(so, None, flags=["-DCG_STAMPS", *os.environ.get("CYGYM_EXTRA_FLAGS", "").split()], dev_mt=int(os.environ["CYGYM_STAMP_MT"]) if "CYGYM_STAMP_MT" in os.environ else None)
+if not (os.environ.get("CYGYM_STAMP_NOBUILD") and os.path.exists(so)):   # (prebuilt in the build container: saves GPU-box minutes)
+    B.build_to(so, None, flags=["-DCG_STAMPS", *os.environ.get("CYGYM_EXTRA_FLAGS", "").split()], dev_mt=int(os.environ["CYGYM_STAMP_MT"]) if "CYGYM_STAMP_MT" in os.environ else None)
 from cygym_amd import _lib
 _lib.SO = so
 from cygym_amd.batched_env import BatchedCyberDefenseEnv
