@@ -56,7 +56,7 @@ class Buffers(C.Structure):
     _fields_ = [
         ("live", C.c_void_p), ("stash", C.c_void_p),
         ("blocked", C.c_void_p), ("blocked_in", C.c_void_p), ("ring", C.c_void_p), ("ienv", C.c_void_p),
-        ("fenv", C.c_void_p), ("extra", C.c_void_p), ("forest", C.c_void_p), ("hist", C.c_void_p),
+        ("fenv", C.c_void_p), ("extra", C.c_void_p), ("forest", C.c_void_p), ("hist", C.c_void_p), ("anomaly", C.c_void_p),
         ("n_envs", C.c_int32), ("reserved", C.c_int32),
     ]
 
@@ -99,7 +99,7 @@ BASELINES = {"Nash": 0, "No Defense": 1, "Preset": 2, "No Attack": 3}
 LIVE_PLANES = ("flags", "busy", "wl", "comp_by")          # order inside Buffers.live  [N][4][M]
 STASH_PLANES = ("st_flags", "st_busy", "st_wl", "st_comp_by")  # order inside Buffers.stash [N][4][M]
 STATE_PLANES = LIVE_PLANES + STASH_PLANES
-BUFFER_FIELDS = ("live", "stash", "blocked", "blocked_in", "ring", "ienv", "fenv", "extra", "forest", "hist")
+BUFFER_FIELDS = ("live", "stash", "blocked", "blocked_in", "ring", "ienv", "fenv", "extra", "forest", "hist", "anomaly")
 
 
 @dataclass

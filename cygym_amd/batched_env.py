@@ -19,19 +19,21 @@ from . import spec as S
 
 _BUF_DTYPES = {"live": torch.uint8, "stash": torch.uint8, "blocked": torch.int32, "blocked_in": torch.int32,
                "ring": torch.int16,
-               "ienv": torch.int32, "fenv": torch.float64, "extra": torch.int32, "forest": torch.int32, "hist": torch.int16}
+               "ienv": torch.int32, "fenv": torch.float64, "extra": torch.int32, "forest": torch.int32, "hist": torch.int16,
+               "anomaly": torch.float32}
 _STATE_KEYS = abi.STATE_PLANES + ("blocked", "ring", "ienv", "fenv")
 _NP_VIEW = {"blocked": np.uint32, "ring": np.uint16, "extra": np.uint32, "forest": np.uint32, "hist": np.uint16}
 
 
-def _alloc_state(n, M, EW, device, K=0, detector=False):
+def _alloc_state(n, M, EW, device, K=0, detector=False, anomaly=False):
     """`live` / `stash` are the [N][4][M] buffers of the ABI; flags/busy/... are VIEWS into them.
     `extra` is the per-env list of edges evolve_network added (K = topo.max_extra entries); `forest` / `hist`
     (trained-detector mode: the env's flattened isolation forest and the comm-log history it is fitted on) have
     zero width unless asked for."""
     dims = {"live": (4, M), "stash": (4, M), "blocked": (EW,), "blocked_in": (EW,), "ring": (S.LOG_RING, 2),
             "ienv": (S.I_COUNT,), "fenv": (S.D_COUNT,), "extra": (abi.x_words(K),),
-            "forest": (S.FOREST_WORDS if detector else 0,), "hist": (S.HIST_RING if detector else 0, 2)}
+            "forest": (S.FOREST_WORDS if detector else 0,), "hist": (S.HIST_RING if detector else 0, 2),
+            "anomaly": (M if anomaly else 0,)}   # per-env Device.anomaly_score: only the per-log scan path (fast_scan=False) writes it
     st = {k: torch.zeros((n,) + dims[k], dtype=dt, device=device) for k, dt in _BUF_DTYPES.items()}
     st["hist"].fill_(-1)
     for i, k in enumerate(abi.LIVE_PLANES):
@@ -89,7 +91,8 @@ class BatchedCyberDefenseEnv:
         self.topo = topo.normalised()
         # detector=True: trained-detector mode is available (defender action 10 -> service_detectors()): binds the
         # per-env forest (4 KB) and history ring (8 KB) and selects the full-feature kernels
-        self.detector = bool(detector)
+        self.slow_scan = not cfg.fast_scan      # the per-log scan path (volt_typhoon_env.py:1030-1050) reads the long history
+        self.detector = bool(detector) or self.slow_scan   # ... and writes per-env anomaly scores: both buffers come with it
         if self.detector and self.topo.det_apl is None:
             from . import detector as D
             self.topo.det_apl = D.apl_table()
@@ -105,13 +108,13 @@ class BatchedCyberDefenseEnv:
             rc = self.lib.cygym_create(C.byref(t), C.byref(c), self.N, self.device.index or 0, C.byref(self._h))
         _lib.check(rc, None, "cygym_create")
         self.K = self.topo.max_extra
-        self.state = _alloc_state(self.N, self.M, self.EW, self.device, self.K, self.detector)
+        self.state = _alloc_state(self.N, self.M, self.EW, self.device, self.K, self.detector, self.slow_scan)
         self._scratch = None   # cygym_randomize's shuffle keys, allocated on first use
         self._act_cache = {}   # id(action dict) -> (data pointers, shapes, validated C struct)
         lead = int(np.asarray(init_state["flags"]).shape[0])
         if lead not in (1, self.N):
             raise ValueError("init_state must have leading dimension 1 or n_envs")
-        self.snapshot = _alloc_state(lead, self.M, self.EW, self.device, self.K, self.detector)
+        self.snapshot = _alloc_state(lead, self.M, self.EW, self.device, self.K, self.detector, self.slow_scan)
         self._load(self.snapshot, init_state)
         _lib.check(self.lib.cygym_bind(self._h, C.byref(_buffers_struct(self.state))), self._h, "cygym_bind")
         self._snap_struct = _buffers_struct(self.snapshot)
@@ -166,6 +169,9 @@ class BatchedCyberDefenseEnv:
         if "extra" in src and dst["extra"].numel():
             a = np.ascontiguousarray(np.asarray(src["extra"]).astype(np.uint32)).view(np.int32)
             dst["extra"].copy_(torch.from_numpy(a).reshape(dst["extra"].shape))
+        if dst["anomaly"].numel():
+            a = np.asarray(src["anomaly"], np.float32) if "anomaly" in src else self.topo.anomaly[None]
+            dst["anomaly"].copy_(torch.from_numpy(np.ascontiguousarray(a)).reshape((-1, self.M)).expand_as(dst["anomaly"]))
         dst["forest"].zero_()
         dst["hist"].fill_(-1)
         for k, udt, sdt in (("forest", np.uint32, np.int32), ("hist", np.uint16, np.int16)):
@@ -205,7 +211,7 @@ class BatchedCyberDefenseEnv:
             self._load(self.state, state)
             self._derive(self.state)
         else:
-            tmp = _alloc_state(1, self.M, self.EW, self.device, self.K, self.detector)
+            tmp = _alloc_state(1, self.M, self.EW, self.device, self.K, self.detector, self.slow_scan)
             self._load(tmp, state)
             self._derive(tmp)
             for k in abi.BUFFER_FIELDS:
@@ -507,6 +513,7 @@ class BatchedCyberDefenseEnv:
         f = self.state["forest"][env]
         f[0:3] = w[0:3]
         f[5] = f[3]
+        f[7] = w[7]
         f[S.FOREST_HDR:] = w[S.FOREST_HDR:]
         self.state["ienv"][env, S.I_FLAGS] &= ~S.E_DET_PENDING
 
@@ -561,6 +568,7 @@ class BatchedCyberDefenseEnv:
         cur = f[pend]                                # [n, FOREST_WORDS]: keep the request the tick recorded (words 3, 4, 6)
         cur[:, 0:3] = w[:, 0:3]
         cur[:, 5] = cur[:, 3]
+        cur[:, 7] = w[:, 7]
         cur[:, S.FOREST_HDR:] = w[:, S.FOREST_HDR:]
         f[pend] = cur
         st["ienv"][pend, S.I_FLAGS] &= ~S.E_DET_PENDING

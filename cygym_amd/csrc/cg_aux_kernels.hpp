@@ -32,6 +32,8 @@ __global__ void reset_kernel(KParams P, const int32_t* env_ids, int n) {
   if (P.b.forest && P.snap.forest)
     for (int i = lane; i < CG_FOREST_WORDS; i += WAVE)
       P.b.forest[(size_t)env * CG_FOREST_WORDS + i] = P.snap.forest[(size_t)si * CG_FOREST_WORDS + i];
+  if (P.b.anomaly && P.snap.anomaly)
+    for (int i = lane; i < M; i += WAVE) P.b.anomaly[(size_t)env * M + i] = P.snap.anomaly[(size_t)si * M + i];
   if (lane < CG_I_COUNT) {
     int32_t v = P.snap.ienv[(size_t)si * CG_I_COUNT + lane];
     if (lane == CG_I_RNG_TICK) v = tick;   // the draw counter is monotone across episodes
@@ -118,7 +120,7 @@ __global__ void observe_kernel(KParams P, int role, float* out) {
       int d = i / 6, col = i - d * 6;
       uint8_t f = flags[d];
       float x = col == 0 ? P.t.os_val[d] : col == 1 ? P.t.version[d] : col == 2 ? ((f & CG_F_COMP) ? 1.f : 0.f)
-              : col == 3 ? P.t.anomaly[d] : col == 4 ? ((f & CG_F_KNOWN) ? 1.f : 0.f) : ((f & CG_F_NYA) ? 1.f : 0.f);
+              : col == 3 ? (P.b.anomaly ? P.b.anomaly[(size_t)env * M + d] : P.t.anomaly[d]) : col == 4 ? ((f & CG_F_KNOWN) ? 1.f : 0.f) : ((f & CG_F_NYA) ? 1.f : 0.f);
       if (role == 1 && ((f & CG_F_NYA) || !(f & CG_F_OWNED) || col == 2)) x = -1.f;
       o[i] = x;
     }

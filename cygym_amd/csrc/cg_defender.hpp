@@ -252,7 +252,91 @@ __device__ __forceinline__ void block_one(Env& e, const PoolPtrs q, int d, bool 
   wsync();
 }
 
-template <bool XE, bool WIDE, class KP>
+// Action 5 with fast_scan == False (volt_typhoon_env.py:1030-1050): every scan predicts the last <= 256 log entries one
+// by one (Detector.predict), pays 0.5 * def_scale per entry, and an entry predicted "A" discovers the exploits its
+// SENDER was compromised by, cleans and stalls the sender; the scanned device's anomaly_score becomes the score of the
+// last entry (None -> -1 unless the detector is trained; 0.0 in turbo mode).  Wave-cooperative, one lane per entry,
+// 64 entries per step, read from the long history (global memory).  Uniform arguments.
+//   n_mult: scans (list entries on active devices); the entries are the same for each of them, so are the trained
+//   detector's predictions -- only the coin mode draws per scan -- and a flagged sender keeps the stall of the last
+//   scan that flagged it (the draw is addressed by sender and scan ordinal, like on the fast path).
+template <class KP>
+__device__ __forceinline__ float slow_scan(Env& e, const KP& P, int n_mult, double& cost, int32_t* ie, double* fe) {
+  const int M = e.M;
+  const double ds = P.c.def_scale;
+  const int w = e.log_total < CG_SLOW_SCAN_WINDOW ? e.log_total : CG_SLOW_SCAN_WINDOW;
+  if (w <= 0 || n_mult <= 0) return __builtin_nanf("");   // no entry looked at: the scores stand
+  const double c = 0.5 * (double)w * (double)n_mult * ds;
+  cost += -c;
+  fe[CG_D_DEF_COST] += c;
+  float score = -1.f;   // Detector.predict(..., return_score=True) gives None unless trained
+  if (P.c.turbo) return 0.f;   // :1036-1038 predicted_kind = None, anomaly_score = 0.0
+  const uint16_t* hist = P.b.hist + (size_t)e.env * CG_HIST_RING * 2;
+  const bool coin = (e.eflags & CG_E_DET_RANDOM) != 0;
+  bool trained = !coin && (e.eflags & CG_E_DET_TRAIN);
+  const uint32_t* fo = P.b.forest ? P.b.forest + (size_t)e.env * CG_FOREST_WORDS : nullptr;
+  const double* apl = P.t.apl;
+  if (trained && (!fo || !apl || (e.eflags & CG_E_DET_PENDING) || fo[2] == 0u)) {
+    e.eflags |= CG_E_UNPINNED;   // no current forest: all "D", flagged (cygym_spec.h)
+    trained = false;
+  }
+  if (!coin && !trained) return score;   // untrained: every entry "D", score None
+  int disc = 0;
+#pragma nounroll
+  for (int s = 0; s < (coin ? n_mult : 1); ++s) {
+    const int ord = coin ? s : n_mult - 1;
+#pragma nounroll
+    for (int p0 = 0; p0 < w; p0 += WAVE) {
+      const int p = p0 + e.lane;
+      bool anom = false;
+      int snd = 0;
+      if (p < w) {
+        const uint32_t idx = (uint32_t)(e.log_total - w + p);
+        snd = hist[2 * (idx % CG_HIST_RING)];
+        const uint32_t to = hist[2 * (idx % CG_HIST_RING) + 1];
+        if (coin) {
+          anom = cg_index(e.draw(CG_SITE_DET_COIN, p, s), 2) == 0;
+        } else {
+          double depths = 0.0;
+#pragma nounroll
+          for (int t = 0; t < CG_FOREST_TREES; ++t) {
+            const uint32_t* tr = fo + CG_FOREST_HDR + t * CG_FOREST_NODES;
+            uint32_t nd = tr[0];
+#pragma nounroll
+            for (int it = 0; it < 16 && !CG_FN_LEAF(nd); ++it) {
+              const uint32_t x = CG_FN_FEAT(nd) ? to : (uint32_t)snd;
+              nd = tr[x <= CG_FN_THR(nd) ? CG_FN_LEFT(nd) : CG_FN_RIGHT(nd)];
+            }
+            uint32_t ns = CG_FN_NSAMP(nd);
+            if (ns >= CG_DET_APL_N) ns = CG_DET_APL_N - 1;
+            depths += ((double)CG_FN_DEPTH(nd) + apl[ns]) - 1.0;
+          }
+          anom = depths < __hiloint2double((int)fo[1], (int)fo[0]);
+          if (p == w - 1) {   // the scanned device keeps the decision_function value of the last entry
+            uint32_t ms = fo[7];
+            if (ms >= CG_DET_APL_N) ms = CG_DET_APL_N - 1;
+            const double den = (double)CG_FOREST_TREES * apl[ms];
+            score = (float)(0.5 - exp2(-(den != 0.0 ? depths / den : 1.0)));
+          }
+        }
+      }
+      if (anom && snd < M) {   // (a sender id outside the network: the reference would raise KeyError)
+        disc |= e.cby[snd];
+        e.cby[snd] = 0;
+        atomicAnd((unsigned int*)(e.flags + (snd & ~3)), ~((uint32_t)CG_F_COMP << ((snd & 3) * 8)));
+        e.busy[snd] = (uint8_t)cg_randint(e.draw(CG_SITE_STALL_SCAN, snd, ord), 0, P.c.default_high);
+      }
+      wsync();
+    }
+  }
+  ie[CG_I_DISCOVERED] |= wave_or(disc);
+  if (!coin) score = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(score), (w - 1) & 63));
+  return score;
+}
+
+// SLOW: the instantiation carries the per-log scan path (full-feature per-tick kernels; the rollout kernels sit at their
+// 128-VGPR cap and do not -- cygym_rollout issues a fast_scan=False handle's ticks as single-tick launches)
+template <bool XE, bool WIDE, bool SLOW, class KP>
 __device__ __forceinline__ void def_per_device(Env& e, const KP& P, int at, const int16_t* dev, int L, int app,
                                                double& cost, bool& dirty, int32_t* ie, double* fe) {
   const double ds = P.c.def_scale;
@@ -429,6 +513,25 @@ __device__ __forceinline__ void def_per_device(Env& e, const KP& P, int at, cons
   } else if (at == 7) {
     cost += -0.5 * n_dist * ds;   // a repeated entry finds the device already removed (:992)
     if (n_dist > 0) dirty = true;
+  } else if (COLD(at == 5 && !P.c.fast_scan)) {  // per-log scan :1030-1050 (full-feature kernels: history + anomaly plane bound)
+    ie[CG_I_SCAN_CNT] += n_mult;
+    if constexpr (SLOW) {
+      const float sc = slow_scan(e, P, n_mult, cost, ie, fe);
+      if (sc == sc && P.b.anomaly) {   // (NaN: no entry was looked at)  every scanned active device takes the last entry's score
+        float* an = P.b.anomaly + (size_t)e.env * M;
+        if (simple && L <= WAVE) {
+          int d = -1;
+          if (e.lane < L) { d = dev[e.lane]; if (d < 0 || d >= M) d = -1; }
+          if (d >= 0 && !(e.flags[d] & CG_F_NYA)) an[d] = sc;
+        } else {
+          const uint8_t* cnt = (const uint8_t*)e.scr;   // multiplicities of list_counts above
+          for (int d = e.lane; d < M; d += WAVE)
+            if (cnt[d] > 0 && !(e.flags[d] & CG_F_NYA)) an[d] = sc;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the observation writers of this wave read the plane back
+      }
+    }
+    wsync();
   } else if (at == 5) {  // fast scan :1020-1069
     ie[CG_I_SCAN_CNT] += n_mult;
     int w = e.log_total < CG_SCAN_WINDOW ? e.log_total : CG_SCAN_WINDOW;

@@ -11,9 +11,17 @@
 // instantiation (none of those buffers bound) carries none of that code.
 // Per-wave LDS carve + pointer table of one env (must match wave_lds_bytes on the host).
 // One lane per device PAIR: 12 floats = three 16-byte stores; static columns read as float2.
+// anomaly column of an env that owns a per-env plane (cygym_buffers.anomaly): global memory this wave may have written
+// in this very tick (slow scan path) -- read around the vector L1
+__device__ __forceinline__ float2 ld_ano2(const float2* p, bool vol) {
+  if (!vol) return *p;
+  const volatile float* q = (const volatile float*)p;
+  return make_float2(q[0], q[1]);
+}
+__device__ __forceinline__ float ld_ano(const float* p, bool vol) { return vol ? *(const volatile float*)p : *p; }
 template <int GP>   // pairs per lane and step
 __device__ __forceinline__ void write_obs(const uint8_t* flags, const float* osv, const float* ver, const float* ano,
-                                          float* obs, int M, int lane) {
+                                          float* obs, int M, int lane, bool vol = false) {
   if (!(M & 1)) {
     float4* out4 = (float4*)obs;
     const int npairs = M >> 1;
@@ -29,7 +37,7 @@ __device__ __forceinline__ void write_obs(const uint8_t* flags, const float* osv
 #pragma unroll
       for (int j = 0; j < GP; ++j) {
         const int p = p0 + j * WAVE, pc = p < npairs ? p : npairs - 1;
-        f2[j] = F2[pc]; o[j] = os2[pc]; v[j] = ve2[pc]; a[j] = an2[pc];
+        f2[j] = F2[pc]; o[j] = os2[pc]; v[j] = ve2[pc]; a[j] = ld_ano2(an2 + pc, vol);
       }
       if constexpr (GP > 1) {
 #pragma unroll
@@ -48,7 +56,7 @@ __device__ __forceinline__ void write_obs(const uint8_t* flags, const float* osv
   } else {   // odd M: rows are not 16-byte aligned across envs
     for (int d = lane; d < M; d += WAVE) {
       const uint32_t f = flags[d];
-      obs[6 * d + 0] = osv[d]; obs[6 * d + 1] = ver[d]; obs[6 * d + 2] = (float)(f & 1u); obs[6 * d + 3] = ano[d];
+      obs[6 * d + 0] = osv[d]; obs[6 * d + 1] = ver[d]; obs[6 * d + 2] = (float)(f & 1u); obs[6 * d + 3] = ld_ano(ano + d, vol);
       obs[6 * d + 4] = (float)((f >> 2) & 1u); obs[6 * d + 5] = (float)((f >> 4) & 1u);
     }
   }
@@ -59,14 +67,14 @@ __device__ __forceinline__ void write_obs(const uint8_t* flags, const float* osv
 // _get_defender_state (CyberDefenseEnv.py:243-257): rows of not-yet-added or non-attacker-owned devices are all -1,
 // column 2 (isCompromised) is -1 everywhere.  One lane per device PAIR, three 16-byte stores (even M).
 __device__ __forceinline__ void write_obs_def(const uint8_t* flags, const float* osv, const float* ver, const float* ano,
-                                              float* out, int M, int lane) {
+                                              float* out, int M, int lane, bool vol = false) {
   if (!(M & 1)) {
     float4* out4 = (float4*)out;
     const int npairs = M >> 1;
     const uint16_t* F2 = (const uint16_t*)flags;
     for (int p = lane; p < npairs; p += WAVE) {
       const uint32_t f2 = F2[p];
-      const float2 o = ((const float2*)osv)[p], v = ((const float2*)ver)[p], a = ((const float2*)ano)[p];
+      const float2 o = ((const float2*)osv)[p], v = ((const float2*)ver)[p], a = ld_ano2((const float2*)ano + p, vol);
       const uint32_t fa = f2 & 0xFFu, fb = f2 >> 8;
       const bool ha = (fa & CG_F_NYA) || !(fa & CG_F_OWNED), hb = (fb & CG_F_NYA) || !(fb & CG_F_OWNED);
       const float ka = (float)((fa >> 2) & 1u), kb = (float)((fb >> 2) & 1u);
@@ -79,7 +87,7 @@ __device__ __forceinline__ void write_obs_def(const uint8_t* flags, const float*
       const uint32_t f = flags[d];
       const bool h = (f & CG_F_NYA) || !(f & CG_F_OWNED);
       out[6 * d + 0] = h ? -1.f : osv[d]; out[6 * d + 1] = h ? -1.f : ver[d]; out[6 * d + 2] = -1.f;
-      out[6 * d + 3] = h ? -1.f : ano[d]; out[6 * d + 4] = h ? -1.f : (float)((f >> 2) & 1u); out[6 * d + 5] = h ? -1.f : 0.f;
+      out[6 * d + 3] = h ? -1.f : ld_ano(ano + d, vol); out[6 * d + 4] = h ? -1.f : (float)((f >> 2) & 1u); out[6 * d + 5] = h ? -1.f : 0.f;
     }
   }
 }
@@ -469,7 +477,7 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 &
       if (baseline != 0) at = 8;   // :913-914
       def_global(e, P, at, devs, Ld, cost, dirty, false, ie, fe);
       if (at == 1 || at == 4 || at == 5 || at == 6 || at == 7 || at == 9 || at == 12 || at == 13)
-        if (Ld > 0) def_per_device<XE, WIDE>(e, P, at, devs, Ld, app0, cost, dirty, ie, fe);
+        if (Ld > 0) def_per_device<XE, WIDE, XE && !FUSED>(e, P, at, devs, Ld, app0, cost, dirty, ie, fe);
     } else if (baseline != 3 && (at == 1 || at == 2)) {
       // :1127 snapshot of the sources.  Chunk loops are STAGED in groups of four: the LDS reads of a group are issued
       // before its first store (the compiler cannot reorder an LDS load over an LDS store it cannot disambiguate, so a
@@ -593,7 +601,11 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 &
   // LDS, or (large M, where leaving them out of LDS buys resident waves) from the L2-resident blob.
   constexpr int OBS_GP = MT ? ((MT / 2 + WAVE - 1) / WAVE < 4 ? (MT / 2 + WAVE - 1) / WAVE : 4) : CG_OBS_GP0;
   if (P.o.obs) {
-    if (P.t.in_lds) write_obs<OBS_GP>(e.flags, e.osv, e.ver, e.ano, P.o.obs + te * M * 6, M, lane);
+    bool dyn_ano = false;
+    if constexpr (XE && !FUSED) dyn_ano = COLD(P.b.anomaly != nullptr);   // this env's own Device.anomaly_score plane (slow scan path; per-tick kernels only)
+    if (dyn_ano) write_obs<OBS_GP>(e.flags, P.t.in_lds ? e.osv : (const float*)(P.t.blob + P.t.o_os), P.t.in_lds ? e.ver : (const float*)(P.t.blob + P.t.o_ver),
+                                   P.b.anomaly + (size_t)env * M, P.o.obs + te * M * 6, M, lane, true);
+    else if (P.t.in_lds) write_obs<OBS_GP>(e.flags, e.osv, e.ver, e.ano, P.o.obs + te * M * 6, M, lane);
     else write_obs<OBS_GP>(e.flags, (const float*)(P.t.blob + P.t.o_os), (const float*)(P.t.blob + P.t.o_ver),
                            (const float*)(P.t.blob + P.t.o_ano), P.o.obs + te * M * 6, M, lane);
   }
@@ -663,6 +675,13 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 &
 #pragma nounroll
         for (int i = lane; i < CG_HIST_RING; i += WAVE) hd[i] = hs[i];
       }
+      if (!FUSED && COLD(P.b.anomaly && P.snap.anomaly)) {
+        const float* as = P.snap.anomaly + (size_t)si * M;
+        float* ad = P.b.anomaly + (size_t)env * M;
+#pragma nounroll
+        for (int i = lane; i < M; i += WAVE) ad[i] = as[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      }
       if (COLD(P.b.forest && P.snap.forest)) {
         const uint32_t* fs = P.snap.forest + (size_t)si * CG_FOREST_WORDS;
         uint32_t* fd = P.b.forest + (size_t)env * CG_FOREST_WORDS;
@@ -697,7 +716,10 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 &
     const float* osv = P.t.in_lds ? e.osv : (const float*)(P.t.blob + P.t.o_os);
     const float* ver = P.t.in_lds ? e.ver : (const float*)(P.t.blob + P.t.o_ver);
     const float* ano = P.t.in_lds ? e.ano : (const float*)(P.t.blob + P.t.o_ano);
-    if (P.o.obs_def) write_obs_def(e.flags, osv, ver, ano, P.o.obs_def + te * M * 6, M, lane);
+    bool dyn_ano = false;
+    if constexpr (XE && !FUSED) dyn_ano = COLD(P.b.anomaly != nullptr);
+    if (dyn_ano) ano = P.b.anomaly + (size_t)env * M;
+    if (P.o.obs_def) write_obs_def(e.flags, osv, ver, ano, P.o.obs_def + te * M * 6, M, lane, dyn_ano);
     if (P.o.obs_att) write_obs_att(e.flags, osv, ver, P.o.obs_att + te * (size_t)(4 * M + P.c.max_exploits), M, P.t.X, P.c.max_exploits, lane);
   }
   if (FUSED && tk + 1 < n_ticks) {   // park the scalars for the next tick

@@ -111,7 +111,7 @@ static const void* kernel_for_m(const cygym_handle* h) {
 // WIDE (lean per-tick kernel only): the block / unblock pools count their bits nine words at a time.  That costs
 // registers (108 VGPRs: 4 waves per SIMD), so it is used when the batch cannot fill more than that anyway
 // (envs <= 16 per CU) -- there a launch lasts as long as its slowest env, and block / unblock is that env.
-static bool full_feature(const cygym_handle* h) { return h->t.K > 0 || h->b.forest || h->b.hist; }
+static bool full_feature(const cygym_handle* h) { return h->t.K > 0 || h->b.forest || h->b.hist || h->b.anomaly; }
 static const void* pick_kernel(const cygym_handle* h, bool fused, int full = -1) {
   const bool xe = full < 0 ? full_feature(h) : full != 0;
   if (fused) return xe ? kernel_for_m<true, true, false>(h) : kernel_for_m<true, false, false>(h);
@@ -222,7 +222,6 @@ int cygym_create(const cygym_topology* topo, const cygym_config* cfg, int32_t n_
   if (M < 1 || M > 2048) return fail(nullptr, CYGYM_EUNSUPPORTED, "n_devices must be in [1, 2048]%s", "");
   if (E < 0 || E > 65535) return fail(nullptr, CYGYM_EUNSUPPORTED, "n_edges must be <= 65535%s", "");
   if (X < 0 || X > CG_MAX_EXPLOITS) return fail(nullptr, CYGYM_EINVAL, "n_exploits out of range%s", "");
-  if (!cfg->fast_scan) return fail(nullptr, CYGYM_EUNSUPPORTED, "fast_scan=False (per-log scan path) is not implemented%s", "");
   if (cfg->num_of_device > 5000) return fail(nullptr, CYGYM_EUNSUPPORTED, "numOfDevice > 5000 (ready-set path) is not implemented%s", "");
   // host-side validation of the CSR: a malformed topology must never reach a kernel
   for (int i = 0; i <= M; ++i) {
@@ -350,7 +349,8 @@ void cygym_destroy(cygym_handle* h) {
 
 int cygym_set_config(cygym_handle* h, const cygym_config* cfg) {
   if (!h || !cfg) return fail(h, CYGYM_EINVAL, "cygym_set_config: bad argument%s", "");
-  if (!cfg->fast_scan) return fail(h, CYGYM_EUNSUPPORTED, "fast_scan=False is not implemented%s", "");
+  if (!cfg->fast_scan && h->bound && (!h->b.hist || !h->b.anomaly))
+    return fail(h, CYGYM_EINVAL, "fast_scan=False (per-log scan path) needs the `hist` and `anomaly` planes bound%s", "");
   h->c = *cfg;
   return CYGYM_OK;
 }
@@ -368,6 +368,8 @@ int cygym_bind(cygym_handle* h, const cygym_buffers* state) {
   if (!h) return fail(h, CYGYM_EINVAL, "cygym_bind: null handle%s", "");
   int rc = check_buffers(h, state, false);
   if (rc) return rc;
+  if (!h->c.fast_scan && (!state->hist || !state->anomaly))
+    return fail(h, CYGYM_EINVAL, "fast_scan=False (per-log scan path) needs the `hist` and `anomaly` planes bound%s", "");
   const bool was_full = full_feature(h);
   h->b = *state;
   h->bound = true;
@@ -453,6 +455,35 @@ int cygym_set_snapshot(cygym_handle* h, const cygym_buffers* snapshot) {
 static int launch_ticks(cygym_handle* h, int32_t n_ticks, int32_t env_begin, int32_t n, const cygym_actions* a,
                         const cygym_outputs* o, void* stream) {
   if (!h || !h->bound) return fail(h, CYGYM_ENOTBOUND, "cygym_step: handle not bound%s", "");
+  if (n_ticks > 1 && (!h->c.fast_scan || h->b.anomaly) && a && o) {
+    // The per-log scan path and the per-env anomaly plane it writes live in the per-tick kernels only (the rollout kernels
+    // have no registers to spare for them): a rollout of such a handle is issued as n_ticks single-tick launches over
+    // the same [n_ticks][N] arrays.
+    const size_t N = (size_t)h->n_envs, G = (size_t)(a->max_groups > 0 ? a->max_groups : 1), L = (size_t)(a->max_devs > 0 ? a->max_devs : 1);
+    const size_t M = (size_t)h->t.M, WA = 4 * M + (size_t)h->c.max_exploits;
+    for (int32_t t = 0; t < n_ticks; ++t) {
+      cygym_actions at = *a;
+      cygym_outputs ot = *o;
+      const size_t r = (size_t)t * N;
+      if (at.mode) at.mode += r;
+      if (at.n_groups) at.n_groups += r;
+      if (at.atype) at.atype += r * G;
+      if (at.n_exploit) at.n_exploit += r * G;
+      if (at.exploit) at.exploit += r * G * CG_MAX_EXPLOITS;
+      if (at.app) at.app += r * G;
+      if (at.dev_cnt) at.dev_cnt += r * G;
+      if (at.dev_idx) at.dev_idx += r * L;
+      if (ot.obs) ot.obs += r * M * 6;
+      if (ot.raw) ot.raw += r;
+      if (ot.shaped) ot.shaped += r;
+      if (ot.done) ot.done += r;
+      if (ot.obs_def) ot.obs_def += r * M * 6;
+      if (ot.obs_att) ot.obs_att += r * WA;
+      const int rc = launch_ticks(h, 1, env_begin, n, &at, &ot, stream);
+      if (rc != CYGYM_OK) return rc;
+    }
+    return CYGYM_OK;
+  }
   if (n_ticks < 1) return fail(h, CYGYM_EINVAL, "cygym_rollout: n_ticks must be >= 1%s", "");
   if (env_begin < 0 || n < 0 || env_begin > h->n_envs - n) return fail(h, CYGYM_EINVAL, "cygym_step_range: env range outside [0, n_envs)%s", "");
   if (!a || !o || !a->mode || !a->n_groups || !a->atype || !a->n_exploit || !a->exploit || !a->app ||

@@ -108,6 +108,7 @@ def flatten_forest(model) -> np.ndarray:
                                          (ft << 30) | (fl << 18) | (left << 9) | right).astype(np.uint32)
         counts.append(n)
     words[2] = counts[0] | (counts[1] << 16)
+    words[7] = int(model.max_samples_)      # what the decision_function value of the slow scan path is scaled by
     return words
 
 
@@ -198,3 +199,24 @@ def training_window(hist_row: np.ndarray, log_total: int, turbo: bool = False, t
         rows = rows[-int(turbo_max_logs):]
         rows = rows[:: max(1, int(turbo_stride))]
     return rows
+
+
+def decision_value(words: np.ndarray, point, apl: np.ndarray | None = None) -> float:
+    """sklearn IsolationForest.decision_function for one (from, to) point over a flattened forest:
+    0.5 - 2 ** (-s / (2 * apl[max_samples_])) with s the summed leaf values (the host-side twin of the device's
+    anomaly score on the slow scan path)."""
+    apl = apl_table() if apl is None else apl
+    words = np.asarray(words, np.uint32)
+    a, b = point
+    depths = 0.0
+    for t in range(S.FOREST_TREES):
+        base = S.FOREST_HDR + t * S.FOREST_NODES
+        w = int(words[base])
+        for _ in range(16):
+            if w >> 31:
+                break
+            x = b if (w >> 30) & 1 else a
+            w = int(words[base + (((w >> 9) & 0x1FF) if x <= ((w >> 18) & 0xFFF) else (w & 0x1FF))])
+        depths += (float((w >> 9) & 0xF) + float(apl[min(w & 0x1FF, S.DET_APL_N - 1)])) - 1.0
+    den = S.FOREST_TREES * float(apl[min(int(words[7]), S.DET_APL_N - 1)])
+    return 0.5 - 2.0 ** (-(depths / den if den != 0.0 else 1.0))     # (sklearn divides with where=den != 0, out=ones)

@@ -264,9 +264,14 @@ def flatten_dynamic(env, static):
         from . import detector as D
         forest[:] = D.flatten_forest(det.model)
         forest[3] = forest[5] = 0
+    # Device.anomaly_score as it stands (the per-log scan path rewrites it, volt_typhoon_env.py:1033-1038); -1 = None
+    anomaly = np.full(M, -1.0, np.float32)
+    for i, d in net.items():
+        a = getattr(d, "anomaly_score", None)
+        anomaly[i] = -1.0 if a is None else float(a)
     return dict(flags=flags, busy=busy, wl=wl, comp_by=comp_by, st_flags=st_flags, st_busy=st_busy,
                 st_wl=st_wl, st_comp_by=st_comp_by, blocked=blocked, ring=ring, ienv=ienv, fenv=fenv,
-                extra=extra, hist=hist, forest=forest)
+                extra=extra, hist=hist, forest=forest, anomaly=anomaly)
 
 
 def extra_edges(env, static):

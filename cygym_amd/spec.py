@@ -32,6 +32,7 @@ MODE_PARTIAL = 0x100
 MODE_BASELINE_SHIFT = 16   # bits 16..18 of the mode word: (env.base_line code + 1) of this env for this tick, 0 = the config's
 LOG_RING = 32
 SCAN_WINDOW = 30
+SLOW_SCAN_WINDOW = 256
 HIST_RING = 2048
 TRAIN_WINDOW = 2000
 

@@ -56,7 +56,7 @@ typedef struct cygym_topology {
   const uint8_t* napps;     /* [M] len(device.apps)                             */
   const float*   os_val;    /* [M] os_to_float(device.OS)  CyberDefenseEnv.py:125 */
   const float*   version;   /* [M] float(device.version) or -1                  */
-  const float*   anomaly;   /* [M] device.anomaly_score (static on fast-scan path) */
+  const float*   anomaly;   /* [M] device.anomaly_score at export time, -1 = None (see cygym_buffers.anomaly) */
   const int32_t* out_ptr;   /* [M+1] CSR of _outnbrs                            */
   const int32_t* out_col;   /* [E]                                              */
   const int32_t* in_ptr;    /* [M+1] CSR of _innbrs                             */
@@ -81,7 +81,8 @@ typedef struct cygym_config {
   int32_t  workload_period_base; /* env.workload_period_base                    */
   int32_t  workload_period_max;  /* env.workload_period_max                     */
   int32_t  scaling_vulnerability;/* env.scaling_vulnerability                   */
-  int32_t  fast_scan;            /* env.fast_scan (must be 1)                   */
+  int32_t  fast_scan;            /* env.fast_scan; 0 = the per-log scan path (volt_typhoon_env.py:1030-1050): needs
+                                    cygym_buffers.hist and cygym_buffers.anomaly bound                       */
   int32_t  n_att_actions;        /* env.attacker_action_space.n                 */
   int32_t  n_def_actions;        /* env.defender_action_space.n                 */
   int32_t  zero_day;             /* env.zero_day                                */
@@ -136,6 +137,10 @@ typedef struct cygym_buffers {
                            (cygym_amd/detector.py).  Detector.batch_predict (:721-723) then runs in the tick kernel.   */
   uint16_t* hist;       /* [N][CG_HIST_RING][2] the last 2048 comm-log (from,to) pairs -- what action 10 trains on
                            (volt_typhoon_env.py:955-961) -- or NULL (then only `ring` is kept)                          */
+  float*    anomaly;    /* [N][M] Device.anomaly_score per env (-1 = None), or NULL: the topology's static column is
+                           the score of every env.  Written only by the per-log scan path (fast_scan = 0), which sets
+                           the score of every scanned device to the detector's decision_function of the last log it
+                           looked at (volt_typhoon_env.py:1033-1035); read by the observation builders (column 3).   */
   int32_t   n_envs;     /* leading dimension (N, or 1 for a broadcast snapshot) */
   int32_t   reserved;
 } cygym_buffers;

@@ -116,6 +116,8 @@ enum {
 /* ---- comm-log ring ---- */
 #define CG_LOG_RING 32       /* entries kept per env (fast scan reads 30)  */
 #define CG_SCAN_WINDOW 30    /* volt_typhoon_env.py:1052                   */
+#define CG_SLOW_SCAN_WINDOW 256 /* fast_scan=False: logs[-512:][-256:] are predicted one by one (:1022-1031); needs the
+                                   long history (cygym_buffers.hist) and the per-env anomaly plane (cygym_buffers.anomaly) */
 #define CG_HIST_RING 2048    /* optional long history (cygym_buffers.hist): what Detector.train fits on    */
 #define CG_TRAIN_WINDOW 2000 /* action 10 trains on the last <= 2000 logs  volt_typhoon_env.py:958        */
 
@@ -134,7 +136,9 @@ enum {
  *           [6]      how many times that tick asked (a step_grouped tick may carry action 10 in several groups:
  *                    the reference then fits several times on the same logs, each fit continuing the numpy
  *                    stream -- the host does the same and keeps the last forest)   (written by the tick)
- *           [7]      reserved
+ *           [7]      max_samples_ of the fit (min(256, training rows)): the slow scan path turns a point's summed depth s into
+ *                    sklearn's decision_function value  0.5 - 2^(-s / (2 * apl[max_samples_]))  (device.anomaly_score,
+ *                    volt_typhoon_env.py:1033-1035)                                    (written by the host)
  *   tree t: words [CG_FOREST_HDR + t * CG_FOREST_NODES, +node count), node 0 = root
  *     internal node: bit 31 = 0 | feature << 30 (0: from_device, 1: to_device) | floor(threshold) << 18 (12 bits)
  *                    | left child << 9 | right child;  go left iff x[feature] <= threshold (ids are integers,

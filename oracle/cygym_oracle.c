@@ -48,6 +48,7 @@ typedef struct {
   uint16_t* ring;
   uint16_t* hist;   /* [CG_HIST_RING][2] long comm-log history, or NULL */
   uint32_t* forest; /* [CG_FOREST_WORDS] fitted isolation forest, or NULL */
+  float* anomaly;   /* [M] Device.anomaly_score of this env (-1 = None), or NULL: the topology's static column */
   int32_t* ienv;
   double* fenv;
   uint32_t env_id, tick;
@@ -134,7 +135,12 @@ static int stall(env_t* e, uint32_t site, int d, int b, int lo, int hi) {
 /* IsolationForest.predict(point) == -1 for one (from, to) log point, over the flattened forest of cygym_spec.h:
  * depths = sum over trees of (node depth of the leaf + apl[n_node_samples of the leaf] - 1.0)
  * (sklearn _parallel_compute_tree_depths), anomaly iff depths < S* (the header's threshold). */
+static int forest_anomaly_s(const uint32_t* fo, const double* apl, unsigned from, unsigned to, double* sum);
 static int forest_anomaly(const uint32_t* fo, const double* apl, unsigned from, unsigned to) {
+  double s;
+  return forest_anomaly_s(fo, apl, from, to, &s);
+}
+static int forest_anomaly_s(const uint32_t* fo, const double* apl, unsigned from, unsigned to, double* sum) {
   uint64_t sb = (uint64_t)fo[0] | ((uint64_t)fo[1] << 32);
   double sstar, depths = 0.0;
   memcpy(&sstar, &sb, 8);
@@ -149,6 +155,7 @@ static int forest_anomaly(const uint32_t* fo, const double* apl, unsigned from, 
     if (n >= CG_DET_APL_N) n = CG_DET_APL_N - 1;
     depths += ((double)CG_FN_DEPTH(w) + apl[n]) - 1.0;
   }
+  *sum = depths;
   return depths < sstar;
 }
 
@@ -252,10 +259,46 @@ static void def_per_device(env_t* e, int at, const int16_t* dev, int L, int app,
           set_busy(e, d, stall(e, CG_SITE_STALL_PATCH, d, b, 0, e->c->default_high));
         }
         break;
-      case 5: { /* fast scan :1020-1069 */
+      case 5: { /* scan :1020-1069 */
         e->ienv[CG_I_SCAN_CNT] += 1;
         int ord = e->scan_ord++;
         uint32_t total = (uint32_t)e->ienv[CG_I_LOG_TOTAL];
+        if (!e->c->fast_scan) { /* per-log path :1030-1050: predict the last <= 256 entries one by one */
+          int w = total < CG_SLOW_SCAN_WINDOW ? (int)total : CG_SLOW_SCAN_WINDOW;
+          int fl = e->ienv[CG_I_FLAGS];
+          int coin = (fl & CG_E_DET_RANDOM) != 0;
+          int trained = !coin && (fl & CG_E_DET_TRAIN) && !e->c->turbo;
+          if (trained && w > 0 && (!e->forest || !e->t->det_apl || (fl & CG_E_DET_PENDING) || e->forest[2] == 0)) {
+            e->ienv[CG_I_FLAGS] |= CG_E_UNPINNED;
+            trained = 0;
+          }
+          for (int j = 0; j < w; ++j) {
+            uint32_t idx = total - (uint32_t)w + (uint32_t)j;
+            const uint16_t* pt = e->hist + 2 * (idx % CG_HIST_RING);
+            int a = 0;
+            float score = -1.f; /* Detector.predict(..., return_score=True): None unless trained */
+            if (e->c->turbo) score = 0.f; /* :1036-1038 */
+            else if (coin) a = (cg_index(drw(e, CG_SITE_DET_COIN, (uint32_t)j, (uint32_t)ord), 2) == 0);
+            else if (trained) {
+              double sum;
+              a = forest_anomaly_s(e->forest, e->t->det_apl, pt[0], pt[1], &sum);
+              unsigned ms = e->forest[7] < CG_DET_APL_N ? e->forest[7] : CG_DET_APL_N - 1;
+              double den = (double)CG_FOREST_TREES * e->t->det_apl[ms];
+              score = (float)(0.5 - pow(2.0, -(den != 0.0 ? sum / den : 1.0)));
+            }
+            if (e->anomaly) e->anomaly[d] = score;
+            *cost += -0.5 * ds;
+            e->fenv[CG_D_DEF_COST] += 0.5 * ds;
+            if (a && pt[0] < e->M) {
+              int snd = pt[0];
+              e->ienv[CG_I_DISCOVERED] |= e->comp_by[snd];
+              e->comp_by[snd] = 0;
+              e->flags[snd] &= (uint8_t)~CG_F_COMP;
+              set_busy(e, snd, stall(e, CG_SITE_STALL_SCAN, snd, ord, 0, e->c->default_high));
+            }
+          }
+          break;
+        }
         int w = total < CG_SCAN_WINDOW ? (int)total : CG_SCAN_WINDOW;
         if (w > 0) {
           int anom[CG_SCAN_WINDOW];
@@ -632,7 +675,7 @@ static void write_obs(const env_t* e, float* obs) { /* _get_state CyberDefenseEn
     r[0] = e->t->os_val[d];
     r[1] = e->t->version[d];
     r[2] = (f & CG_F_COMP) ? 1.f : 0.f;
-    r[3] = e->t->anomaly[d];
+    r[3] = e->anomaly ? e->anomaly[d] : e->t->anomaly[d];
     r[4] = (f & CG_F_KNOWN) ? 1.f : 0.f;
     r[5] = (f & CG_F_NYA) ? 1.f : 0.f;
   }
@@ -822,6 +865,7 @@ static void bind_env(env_t* e, const cygym_topology* t, const cygym_config* c, c
   e->ring = b->ring + (size_t)idx * CG_LOG_RING * 2;
   e->hist = b->hist ? b->hist + (size_t)idx * CG_HIST_RING * 2 : NULL;
   e->forest = b->forest ? b->forest + (size_t)idx * CG_FOREST_WORDS : NULL;
+  e->anomaly = b->anomaly ? b->anomaly + (size_t)idx * e->M : NULL;
   e->ienv = b->ienv + (size_t)idx * CG_I_COUNT;
   e->fenv = b->fenv + (size_t)idx * CG_D_COUNT;
   e->env_id = (uint32_t)(c->env_id_base + idx);
@@ -838,6 +882,7 @@ static void snapshot_restore(env_t* e, const cygym_buffers* s, int idx) {
   memcpy(e->ring, s->ring + (size_t)si * CG_LOG_RING * 2, CG_LOG_RING * 2 * 2);
   if (e->hist && s->hist) memcpy(e->hist, s->hist + (size_t)si * CG_HIST_RING * 2, CG_HIST_RING * 2 * 2);
   if (e->forest && s->forest) memcpy(e->forest, s->forest + (size_t)si * CG_FOREST_WORDS, CG_FOREST_WORDS * 4);
+  if (e->anomaly && s->anomaly) memcpy(e->anomaly, s->anomaly + (size_t)si * e->M, (size_t)e->M * 4);
   memcpy(e->ienv, s->ienv + (size_t)si * CG_I_COUNT, CG_I_COUNT * 4);
   memcpy(e->fenv, s->fenv + (size_t)si * CG_D_COUNT, CG_D_COUNT * 8);
   e->ienv[CG_I_RNG_TICK] = tick; /* the draw counter is monotone across episodes */
@@ -848,6 +893,7 @@ int cgo_step(const cygym_topology* t, const cygym_config* c, const cygym_buffers
              int32_t env_begin, int32_t env_end) {
   size_t M = (size_t)t->n_devices, E = (size_t)t->n_edges;
   scratch_t sc;
+  if (!c->fast_scan && (!b->hist || !b->anomaly)) return CYGYM_EINVAL; /* the per-log scan path reads the long history */
   const size_t K = (size_t)(t->max_extra_edges > 0 ? t->max_extra_edges : 0);
   sc.newly = (uint8_t*)malloc(M + 1);
   sc.occ = (uint8_t*)malloc(3 * M + 1);

@@ -54,7 +54,7 @@ OTHER_SHAPES = {"blocked": ("EW", np.uint32), "ring": ("R", np.uint16), "ienv": 
 STATE_KEYS = abi.STATE_PLANES + tuple(OTHER_SHAPES)
 
 
-def alloc_state(n, M, EW, K=0, detector=False):
+def alloc_state(n, M, EW, K=0, detector=False, anomaly=False):
     """Struct-of-arrays state.  `live` / `stash` are the [N][4][M] buffers of the ABI; the
     per-plane entries (flags, busy, ..., st_comp_by) are numpy VIEWS into them."""
     dims = {"EW": (EW,), "R": (S.LOG_RING, 2), "I": (S.I_COUNT,), "D": (S.D_COUNT,)}
@@ -70,6 +70,7 @@ def alloc_state(n, M, EW, K=0, detector=False):
     # trained-detector mode: the env's flattened isolation forest and the long comm-log history it is fitted on
     st["forest"] = np.zeros((n, S.FOREST_WORDS if detector else 0), np.uint32)
     st["hist"] = np.full((n, S.HIST_RING if detector else 0, 2), 0xFFFF, np.uint16)
+    st["anomaly"] = np.zeros((n, M if anomaly else 0), np.float32)   # per-env Device.anomaly_score (slow scan path only)
     st["ring"][:] = 0xFFFF
     return st
 
@@ -118,12 +119,16 @@ class OracleBatch:
         if detector and self.topo.det_apl is None:
             from cygym_amd import detector as D
             self.topo.det_apl = D.apl_table()
-        self.detector = bool(detector)
+        self.slow_scan = not cfg.fast_scan       # the per-log scan path: long history + per-env anomaly scores
+        self.detector = bool(detector) or self.slow_scan
+        if self.detector and self.topo.det_apl is None:
+            from cygym_amd import detector as D
+            self.topo.det_apl = D.apl_table()
         self.topo.validate()
         self.cfg = cfg
         self.N = n_envs
         self.M = self.topo.M
-        self.state = alloc_state(n_envs, self.M, self.topo.EW, self.topo.max_extra, self.detector)
+        self.state = alloc_state(n_envs, self.M, self.topo.EW, self.topo.max_extra, self.detector, self.slow_scan)
         self.snapshot = None
         self.obs = np.zeros((n_envs, self.M, 6), np.float32)
         self.raw = np.zeros(n_envs, np.float64)
@@ -150,6 +155,9 @@ class OracleBatch:
             if k in init and self.state[k].size:
                 src = np.asarray(init[k]).astype(self.state[k].dtype)
                 self.state[k][...] = src if src.shape[0] == self.N else np.broadcast_to(src, self.state[k].shape)
+        if self.state["anomaly"].size:
+            src = np.asarray(init["anomaly"], np.float32) if "anomaly" in init else self.topo.anomaly[None]
+            self.state["anomaly"][...] = src if src.shape[0] == self.N else np.broadcast_to(src, self.state["anomaly"].shape)
         self.snapshot = copy_state(self.state)
 
     def install_forest(self, env: int, words):
@@ -159,6 +167,7 @@ class OracleBatch:
         w = np.asarray(words, np.uint32)
         f[0:3] = w[0:3]
         f[5] = f[3]
+        f[7] = w[7]
         f[S.FOREST_HDR:] = w[S.FOREST_HDR:]
         self.state["ienv"][env, S.I_FLAGS] &= ~S.E_DET_PENDING
 

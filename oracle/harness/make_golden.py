@@ -331,6 +331,55 @@ def s64_turbo():
     return H.run_scenario(env0, 2, 260, mixed_actions(M, ALL_DEF + [5, 5, 10], ALL_ATT, 8), seed=43, env_id_base=400), 1
 
 
+def slow_scan_actions(M, kmax, X=2, train=True):
+    """Spread-heavy attacker (fills the comm log); defender dominated by per-log scans (5), with trainings (10), cleans,
+    duplicate scan lists and the occasional no-op."""
+    def fn(e, t, env, rs):
+        if t % 2 == 1 or t < 3:
+            at = int(rs.choice([1, 1, 1, 2]))
+            return ATT, (at, np.array([int(rs.randint(0, X))]), [], 0)
+        at = int(rs.choice([5, 5, 5, 5, 5, 1, 6, 7, 8, 13] + ([10, 10] if train else [])))
+        dv = dev_list(rs, M, kmax, unique=rs.rand() < 0.7)
+        if at == 10 and rs.rand() < 0.5:
+            dv = []
+        return DEF, (at, np.array([0]), dv, 0)
+    return fn
+
+
+@scenario("s16_slowscan")
+def s16_slowscan():
+    """fast_scan = False (volt_typhoon_env.py:1030-1050): every scan predicts the last <= 256 log entries one by one with
+    Detector.predict, 0.5 * def_scale per entry; "A" entries discover and clean their SENDER; the scanned device's
+    anomaly_score becomes the decision_function value of the last entry (observation column 3).  Untrained first
+    (scores None), then trained and retrained by action 10; the log outgrows the 256-entry window."""
+    M = 16
+    env0 = H.build_env(M, 14, init_seed=161, strip_vuln_frac=0.2, extra_reachable=1, overrides=dict(fast_scan=False))
+    return H.run_scenario(env0, 3, 220, slow_scan_actions(M, 4), seed=51), 1
+
+
+@scenario("s16_slowcoin")
+def s16_slowcoin():
+    """The per-log scan path with the detector in random-detection mode (Detector.train([]), CDSimulator.py:688-690,
+    :697-700): one coin per log entry and scan; a flagged sender keeps the stall of the last scan that flagged it."""
+    M = 16
+    env0 = H.build_env(M, 14, init_seed=171, strip_vuln_frac=0.2, extra_reachable=1, overrides=dict(fast_scan=False))
+
+    def pre(e, env, rs):
+        env.simulator.detector.train([])
+        return False
+    return H.run_scenario(env0, 2, 160, slow_scan_actions(M, 4, train=False), seed=52, pre_fn=pre), 1
+
+
+@scenario("s32_slowturbo")
+def s32_slowturbo():
+    """fast_scan = False with env.turbo = True (:1036-1038): scans still pay per entry, predict nothing, and set the scanned
+    devices' anomaly_score to 0.0."""
+    M = 32
+    env0 = H.build_env(M, 28, init_seed=181, strip_vuln_frac=0.3, extra_reachable=2,
+                       overrides=dict(fast_scan=False, turbo=True, workload_period_base=3, turbo_ramp_steps=40))
+    return H.run_scenario(env0, 2, 120, slow_scan_actions(M, 6), seed=53, env_id_base=500), 1
+
+
 def outputs_of(name):
     """File stems a scenario writes."""
     if name == "s16_baselines":

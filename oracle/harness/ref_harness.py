@@ -235,6 +235,12 @@ def _inj_choice(seq):
             return canon[R.index(CTX.draw(site, a, 0), len(canon))]
         if loc.get("action_type") == 2:
             return seq[R.index(CTX.draw(S.SITE_PROBE_SRC, 0, 0), len(seq))]
+    if name == "predict":   # Detector.predict in random-detection mode (CDSimulator.py:697-700): the per-log scan path
+        step = _find(fr, "step")   # (volt_typhoon_env.py:1030-1035); a = position of the log in this scan, b = scan ordinal
+        env = step.f_locals["self"]
+        b = int(env.scan_cnt) - CTX.scan_base - 1
+        a = CTX.next_occ(S.SITE_DET_COIN, b)
+        return seq[R.index(CTX.draw(S.SITE_DET_COIN, a, b), len(seq))]
     if name == "<listcomp>" and fr[1].f_code.co_name == "batch_predict":
         step = _find(fr, "step")
         env = step.f_locals["self"]

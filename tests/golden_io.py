@@ -236,6 +236,21 @@ def compare_state(got: dict, exp: dict, label: str, ring_total=None):
     return bad
 
 
+def assert_obs_equal(got, exp, slow_scan: bool, err_msg: str = ""):
+    """Observation views against the reference's: exact -- except, on the per-log scan path (fast_scan = False), the
+    anomaly column, whose values are scikit-learn's decision_function floats (0.5 - 2^(-s/c): one exp2 / pow apart
+    between numpy, libm and the device): within the north star's 1e-6."""
+    got, exp = np.asarray(got), np.asarray(exp)
+    if not slow_scan:
+        np.testing.assert_array_equal(got, exp, err_msg=err_msg)
+        return
+    g = got.reshape(got.shape[0], -1, 6).copy()
+    x = exp.reshape(exp.shape[0], -1, 6).copy()
+    np.testing.assert_allclose(g[:, :, 3], x[:, :, 3], rtol=0, atol=1e-6, err_msg=err_msg + " (anomaly column)")
+    g[:, :, 3] = x[:, :, 3]
+    np.testing.assert_array_equal(g, x, err_msg=err_msg)
+
+
 def check_oracle_against_fixture(fx: "Fixture") -> int:
     """Step the CPU oracle through a fixture (outputs of the reference itself) and compare every tick:
     integer planes / counters / ring / extra edges bit-exact, rewards within 1e-9, the three observation
@@ -268,11 +283,12 @@ def check_oracle_against_fixture(fx: "Fixture") -> int:
         got = {k: v[sel] for k, v in ob.state.items()}
         bad = compare_state(got, {k: v[sel] for k, v in exp.items()}, f"{name} t={t}")
         assert not bad, "\n".join(bad[:8])
-        np.testing.assert_array_equal(obs[sel], fx.exp["obs"][sel, t], err_msg=f"{name} obs t={t}")
+        slow = not fx.cfg.fast_scan
+        assert_obs_equal(obs[sel].reshape(len(sel), -1), fx.exp["obs"][sel, t].reshape(len(sel), -1), slow, f"{name} obs t={t}")
         np.testing.assert_allclose(raw[sel], fx.exp["raw"][sel, t], rtol=0, atol=1e-9, err_msg=f"{name} raw t={t}")
         np.testing.assert_allclose(shaped[sel], fx.exp["shaped"][sel, t], rtol=0, atol=1e-9, err_msg=f"{name} shaped t={t}")
         np.testing.assert_array_equal(done[sel], fx.exp["done"][sel, t], err_msg=f"{name} done t={t}")
-        np.testing.assert_array_equal(ob.observe(1)[sel], fx.exp["obs_def"][sel, t], err_msg=f"{name} obs_def t={t}")
+        assert_obs_equal(ob.observe(1)[sel], fx.exp["obs_def"][sel, t], slow, f"{name} obs_def t={t}")
         np.testing.assert_array_equal(ob.observe(2)[sel], fx.exp["obs_att"][sel, t], err_msg=f"{name} obs_att t={t}")
         checked += 1
     if alive.all():

@@ -152,3 +152,42 @@ def test_malformed_action_tensors_are_python_errors():
     assert env.lib.cygym_reset(env._h, None, C.c_void_p(ids.data_ptr()), 9, None) == EINVAL
     assert env.lib.cygym_randomize(env._h, None, 8, None, None) == EINVAL
     env.close()
+
+
+def test_slow_scan_needs_its_planes_and_rolls_out_tick_by_tick():
+    """fast_scan = False: cygym_bind refuses a buffer set without the history / anomaly planes; cygym_rollout on such a
+    handle (the per-log scan path lives in the per-tick kernels) gives the reference's trajectory of fixture
+    s16_slowcoin -- rewards of every tick, final state, final anomaly scores."""
+    import golden_io as gio
+    from cygym_amd import _lib
+    from cygym_amd import spec as S
+    from cygym_amd.batched_env import BatchedCyberDefenseEnv
+    from oracle import driver as od
+    fx = gio.Fixture("s16_slowcoin")
+    assert not fx.cfg.fast_scan
+    lib = _lib.load()
+    t, c = fx.topo.to_c(), fx.cfg.to_c()
+    h = C.c_void_p()
+    assert lib.cygym_create(C.byref(t), C.byref(c), fx.N, 0, C.byref(h)) == 0
+    env = BatchedCyberDefenseEnv(fx.topo, fx.cfg, fx.N, fx.init, device="cuda:0", max_groups=fx.G, max_devs=fx.L)
+    assert env.detector and env.state["anomaly"].shape == (fx.N, fx.M)       # the planes come with the flag
+    bb = abi.Buffers()
+    for k in abi.BUFFER_FIELDS:
+        setattr(bb, k, env.state[k].data_ptr() if (env.state[k].numel() and k != "anomaly") else None)
+    bb.n_envs = fx.N
+    assert lib.cygym_bind(h, C.byref(bb)) == EINVAL and b"anomaly" in lib.cygym_last_error(h)
+    lib.cygym_destroy(h)
+    act, out = env.alloc_rollout(fx.T)
+    one = od.alloc_actions(fx.N, fx.G, fx.L)
+    for t_ in range(fx.T):
+        fx.actions(t_, one)                       # (no action=None ticks in this fixture: the state is not needed)
+        for k in act:
+            act[k][t_].copy_(torch.from_numpy(one[k]).reshape(act[k][t_].shape))
+    env.rollout(act, out)
+    np.testing.assert_allclose(out["raw"].cpu().numpy().T, fx.exp["raw"], rtol=0, atol=1e-9)
+    got = env.state_numpy()
+    got["ienv"] = got["ienv"].copy(); got["ienv"][:, S.I_FLAGS] &= ~0x80
+    assert not gio.compare_state(got, fx.expected_state(fx.T - 1), "s16_slowcoin rollout")
+    np.testing.assert_allclose(got["anomaly"], fx.exp["obs"][:, fx.T - 1, :, 3], rtol=0, atol=1e-6)
+    gio.assert_obs_equal(out["obs"][fx.T - 1].cpu().numpy().reshape(fx.N, -1), fx.exp["obs"][:, fx.T - 1].reshape(fx.N, -1), True, "last obs")
+    env.close()

@@ -67,14 +67,17 @@ def test_hip_matches_reference_fixture(name, detector):
         g["ienv"][:, S.I_FLAGS] &= ~0x80   # kernel-private STAR_OK bit
         bad = gio.compare_state(g, {k: v[sel] for k, v in exp.items()}, f"{name} t={t}")
         assert not bad, "\n".join(bad[:8])
-        np.testing.assert_array_equal(obs.cpu().numpy()[sel], fx.exp["obs"][sel, t], err_msg=f"{name} obs t={t}")
+        slow = not fx.cfg.fast_scan     # per-log scan path: the anomaly column holds decision_function floats (1e-6)
+        gio.assert_obs_equal(obs.cpu().numpy()[sel].reshape(len(sel), -1), fx.exp["obs"][sel, t].reshape(len(sel), -1), slow, f"{name} obs t={t}")
         np.testing.assert_allclose(raw.cpu().numpy()[sel], fx.exp["raw"][sel, t], rtol=0, atol=1e-9)
         np.testing.assert_allclose(shaped.cpu().numpy()[sel], fx.exp["shaped"][sel, t], rtol=0, atol=1e-9)
         np.testing.assert_array_equal(done.cpu().numpy()[sel], fx.exp["done"][sel, t])
-        np.testing.assert_array_equal(env.role_obs[view].cpu().numpy()[sel], fx.exp["obs_def" if view == "defender" else "obs_att"][sel, t],
-                                      err_msg=f"{name} fused {view} view t={t}")
+        if view == "defender":
+            gio.assert_obs_equal(env.role_obs[view].cpu().numpy()[sel], fx.exp["obs_def"][sel, t], slow, f"{name} fused defender view t={t}")
+        else:
+            np.testing.assert_array_equal(env.role_obs[view].cpu().numpy()[sel], fx.exp["obs_att"][sel, t], err_msg=f"{name} fused attacker view t={t}")
         if t % 7 == 0:
-            np.testing.assert_array_equal(env.observe(1).cpu().numpy()[sel], fx.exp["obs_def"][sel, t])
+            gio.assert_obs_equal(env.observe(1).cpu().numpy()[sel], fx.exp["obs_def"][sel, t], slow, f"{name} observe(1) t={t}")
             np.testing.assert_array_equal(env.observe(2).cpu().numpy()[sel], fx.exp["obs_att"][sel, t])
         checked += 1
     assert checked > 0
