@@ -31,6 +31,7 @@
 // only declared here.
 #define CG_MAIN_UNIT 1
 #include "cg_device.hpp"
+#include "cg_iforest.hpp"
 using namespace cygym_k;
 
 // every step_kernel variant lives in one of the instantiation units (cg_inst.hip): declared, not instantiated, here
@@ -635,6 +636,36 @@ int cygym_actor_head_decode(cygym_handle* h, const cygym_actor_head* head, const
   HIPCHK(h, hipLaunchKernel(k, dim3((src->n + rows_per_wg - 1) / rows_per_wg), dim3(HEAD_WAVES * WAVE), args, lds, (hipStream_t)stream));
   HIPCHK(h, hipGetLastError());
   return CYGYM_OK;
+}
+
+int cygym_fit_forests(const uint16_t* rows, const int64_t* row_ptr, const uint32_t* seeds, const int32_t* n_fits,
+                      const double* sstar, int32_t n, int32_t n_threads, uint32_t* out, uint8_t* failed) {
+  if (!rows || !row_ptr || !seeds || !sstar || !out || n < 0) return fail(nullptr, CYGYM_EINVAL, "cygym_fit_forests: bad argument%s", "");
+  for (int32_t i = 0; i < n; ++i)
+    if (row_ptr[i + 1] <= row_ptr[i] || row_ptr[i + 1] - row_ptr[i] > 65536)
+      return fail(nullptr, CYGYM_EINVAL, "cygym_fit_forests: every request needs between 1 and 65536 training rows%s", "");
+  if (n == 0) return 0;
+  int nt = n_threads < 1 ? 1 : n_threads;
+  if (nt > n) nt = n;
+  if (nt > 64) nt = 64;
+  std::vector<int> bad((size_t)nt, 0);
+  auto work = [&](int tid) {   // requests dealt round-robin: neighbours have similar sizes
+    for (int32_t i = tid; i < n; i += nt) {
+      const int rc = cg_iforest::fit_one(rows + 2 * row_ptr[i], (long)(row_ptr[i + 1] - row_ptr[i]), seeds[i], n_fits ? n_fits[i] : 1,
+                                         sstar, out + (size_t)i * CG_FOREST_WORDS);
+      if (failed) failed[i] = rc != 0;
+      bad[(size_t)tid] += rc != 0;
+    }
+  };
+  if (nt == 1) work(0);
+  else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t) th.emplace_back(work, t);
+    for (auto& t : th) t.join();
+  }
+  int total = 0;
+  for (int b : bad) total += b;
+  return total;
 }
 
 /* diagnostic builds only (-DCG_STAMPS): per-env phase stamps, [N][16] uint64 device buffer (NULL to disable) */

@@ -162,12 +162,67 @@ def fit_forest(X, seed32: int, n_fits: int = 1) -> np.ndarray:
     return flatten_forest(model)
 
 
-def fit_forests(rows_list, seeds, n_fits=None, workers: int | None = None) -> np.ndarray:
-    """`fit_forest` for a batch of requests -> u32 [n, FOREST_WORDS].  The fits are independent (each has its own
-    numpy stream), so they run on a thread pool; scikit-learn's tree builder releases the GIL, its Python layers do
-    not, so the speed-up is modest -- the gather / scatter around it is what no longer scales with the request count."""
+_SSTAR_TABLE = None
+NATIVE_SKLEARN = "1.7.2"     # the scikit-learn release whose fit csrc/cg_iforest.hpp restates (tests pin it against that one)
+
+
+def sstar_table() -> np.ndarray:
+    """S* by max_samples_ (0..256), f64 [257]: what the native fit writes into header words 0, 1."""
+    global _SSTAR_TABLE
+    if _SSTAR_TABLE is None:
+        _SSTAR_TABLE = np.array([0.0] + [score_threshold(m) for m in range(1, S.DET_APL_N)], np.float64)
+    return _SSTAR_TABLE
+
+
+def fit_forests_native(rows_list, seeds, n_fits=None, threads: int | None = None):
+    """The batch of Detector.train calls on the library's native estimator (cygym_fit_forests: csrc/cg_iforest.hpp,
+    multi-threaded, no Python per fit).  Returns (words u32 [n, FOREST_WORDS], failed bool [n]): `failed` marks requests
+    whose forest does not fit the flat layout -- fit those with `fit_forest` (scikit-learn)."""
+    import os
+    from . import _lib
+    lib = _lib.load()
+    n = len(rows_list)
+    out = np.zeros((n, S.FOREST_WORDS), np.uint32)
+    failed = np.zeros(n, np.uint8)
+    if n == 0:
+        return out, failed.astype(bool)
+    ptr = np.zeros(n + 1, np.int64)
+    ptr[1:] = np.cumsum([len(r) for r in rows_list])
+    rows = np.ascontiguousarray(np.concatenate([np.asarray(r).reshape(-1, 2) for r in rows_list]).astype(np.uint16))
+    sd = np.ascontiguousarray(np.asarray(seeds, np.uint32))
+    nf = np.ascontiguousarray(np.asarray([1] * n if n_fits is None else n_fits, np.int32))
+    tab = sstar_table()
+    threads = threads or min(32, os.cpu_count() or 1)
+    rc = lib.cygym_fit_forests(rows.ctypes.data, ptr.ctypes.data, sd.ctypes.data, nf.ctypes.data, tab.ctypes.data, n, int(threads),
+                               out.ctypes.data, failed.ctypes.data)
+    _lib.check(rc if rc < 0 else 0, None, "cygym_fit_forests")
+    return out, failed.astype(bool)
+
+
+def native_fit_available() -> bool:
+    """The native estimator restates one scikit-learn release: use it when that release (or none) is installed -- with
+    another one present scikit-learn itself fits, so that forests stay what the reference's own environment produces."""
+    try:
+        import sklearn
+    except ImportError:
+        return True
+    return sklearn.__version__ == NATIVE_SKLEARN
+
+
+def fit_forests(rows_list, seeds, n_fits=None, workers: int | None = None, engine: str = "auto") -> np.ndarray:
+    """`fit_forest` for a batch of requests -> u32 [n, FOREST_WORDS].  engine "native": the library's own restatement of
+    the estimator (cygym_fit_forests, csrc/cg_iforest.hpp: multi-threaded C++, tens of microseconds per forest);
+    "sklearn": scikit-learn itself on a thread pool (about 4 ms of Python per forest, GIL-bound); "auto": native when
+    the installed scikit-learn is the release it restates (or scikit-learn is absent), else scikit-learn."""
     n = len(rows_list)
     n_fits = [1] * n if n_fits is None else list(n_fits)
+    if engine not in ("auto", "native", "sklearn"):
+        raise ValueError("engine must be 'auto', 'native' or 'sklearn'")
+    if n and (engine == "native" or (engine == "auto" and native_fit_available())):
+        out, failed = fit_forests_native(rows_list, seeds, n_fits)
+        for j in np.nonzero(failed)[0]:       # (a forest outside the flat layout: let scikit-learn raise or fit it)
+            out[j] = fit_forest(rows_list[j], seeds[j], n_fits[j])
+        return out
     out = np.zeros((n, S.FOREST_WORDS), np.uint32)
     if n == 0:
         return out

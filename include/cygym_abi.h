@@ -314,6 +314,21 @@ typedef struct cygym_actor_head {
 int cygym_actor_head_decode(cygym_handle* h, const cygym_actor_head* head, const cygym_action_vectors* layout,
                             const cygym_actions* dst, void* stream);
 
+/* Replaces: Detector.train(logs) for a batch (CDSimulator.py:688-695: IsolationForest(n_estimators=2, max_samples=256).fit
+ * on the [from_device, to_device] pairs of the last <= 2000 log entries, volt_typhoon_env.py:955-961) -- HOST memory in,
+ * HOST memory out, no GPU work: the natively restated estimator (csrc/cg_iforest.hpp) on `n_threads` host threads.
+ *   rows     [row_ptr[n]][2] uint16: the training rows of the n requests, concatenated (request i: rows row_ptr[i] ..
+ *            row_ptr[i+1]); every request needs at least one row
+ *   seeds    [n] the 32-bit seed of the numpy stream each fit draws from (cygym_amd/detector.fit_seed)
+ *   n_fits   [n] consecutive fits on the same rows from that one stream (several action-10 groups in one step_grouped
+ *            tick refit on the same logs: the last forest stays), or NULL = 1 each
+ *   sstar    [257] f64: decision threshold S* by max_samples_ (cygym_spec.h forest header; detector.score_threshold)
+ *   out      [n][CG_FOREST_WORDS] flattened forests (header words 0-2 and 7 filled, 3-6 zero)
+ *   failed   [n] set to 1 where a forest does not fit the flat layout (the caller falls back to scikit-learn), or NULL
+ * Returns the number of failed requests (>= 0), or a negative CYGYM_E* code. */
+int cygym_fit_forests(const uint16_t* rows, const int64_t* row_ptr, const uint32_t* seeds, const int32_t* n_fits,
+                      const double* sstar, int32_t n, int32_t n_threads, uint32_t* out, uint8_t* failed);
+
 /* Synthetic action script of bench.py -- not a reference
  * interface: fills one tick's cygym_actions from Philox on device. */
 int cygym_gen_actions(cygym_handle* h, int32_t tick, int32_t* mode, int32_t* n_groups,

@@ -47,6 +47,8 @@ def main():
         if rs.rand() < 0.2:    # env.turbo: capped / ramped arrivals (short period so they happen), scans without detector
             over.update(turbo=True, workload_period_base=int(rs.choice([3, 50])), turbo_ramp_steps=int(rs.choice([200, 40, 1])),
                         turbo_fraction_clients=float(rs.choice([0.05, 0.13, 0.5])))
+        if rs.rand() < 0.25:   # the per-log scan path (fast_scan = False, volt_typhoon_env.py:1030-1050)
+            over.update(fast_scan=False)
         env0 = H.build_env(M, n_active, init_seed=int(rs.randint(1, 10000)), strip_vuln_frac=float(rs.choice([0.2, 0.5])),
                            extra_reachable=int(rs.randint(0, 3)), overrides=over)
         X = 3 if over.get("zero_day") else 2
@@ -79,8 +81,11 @@ def main():
             over["base_line"] = str(rs.choice(["Nash", "Nash", "No Defense", "No Attack", "Preset"]))
             env0.base_line = over["base_line"]
         shuffle = rs.rand() < 0.5
+        coin = rs.rand() < 0.15    # detector in random-detection mode from the start (Detector.train([]))
 
-        def pre(e, env, rs2, shuffle=shuffle):
+        def pre(e, env, rs2, shuffle=shuffle, coin=coin):
+            if coin:
+                env.simulator.detector.train([])
             if shuffle:
                 env.randomize_compromise_and_ownership()
                 return True

@@ -63,10 +63,11 @@ def main():
                        num_of_device=int(rs.randint(2, max(3, n_active))), min_network_size=2,
                        episode_limit=int(rs.choice([1000, 37])), auto_reset=int(rs.rand() < 0.5),
                        zero_day=int(rs.rand() < 0.2), zero_day_owned_mask=int(rs.randint(0, 4)),
+                       fast_scan=int(rs.rand() >= 0.12),      # 0: the per-log scan path (history + anomaly planes, full-feature kernels)
                        turbo=int(rs.rand() < 0.2), turbo_ramp_steps=int(rs.choice([200, 40, 1])),
                        turbo_fraction_clients=float(rs.choice([0.05, 0.13, 0.5])), workload_period_base=int(rs.choice([50, 50, 4]))))
         cfg = abi.EnvConfig(seed=int(rs.randint(1 << 30)), env_id_base=int(rs.randint(1 << 20)), baseline=baseline, **ck)
-        det = rs.rand() < 0.3         # trained-detector mode: action 10 -> host fit -> scans walk the forest (full-feature kernels)
+        det = rs.rand() < 0.3 or not ck["fast_scan"]   # trained-detector mode: action 10 -> host fit -> scans walk the forest (full-feature kernels)
         env = BatchedCyberDefenseEnv(topo, cfg, N, init, device="cuda:0", max_groups=G, max_devs=L, detector=det)
         fused = BatchedCyberDefenseEnv(topo, cfg, N, init, device="cuda:0", max_groups=G, max_devs=L, detector=det)
         ob = od.OracleBatch(topo, cfg, N, detector=det)
@@ -93,7 +94,7 @@ def main():
                                                   comp_scale=float(rs.choice([50.0, 10.0])))
                         env.set_config(cfg); ob.cfg = cfg
                 for role in (1, 2):
-                    if not np.array_equal(env.observe(role).cpu().numpy(), ob.observe(role)):
+                    if not np.allclose(env.observe(role).cpu().numpy(), ob.observe(role), rtol=0, atol=0.0 if ck["fast_scan"] else 1e-6):
                         print(f"case {case}: role-{role} observation differs at tick {t}")
                         sys.exit(1)
             act = gen_actions_numpy(cfg.seed, cfg.env_id_base, N, M, topo.X, t, L)
@@ -161,8 +162,10 @@ def main():
                 bad += gio.compare_state(got, ob.state, f"t={t}")
                 if not np.array_equal(got["ienv"][:, S.I_FLAGS] & S.E_TOPO_OVF, ob.state["ienv"][:, S.I_FLAGS] & S.E_TOPO_OVF):
                     bad.append("TOPO_OVF flags")
-                if not np.array_equal(obs.cpu().numpy(), o_obs):
+                if not (np.array_equal(obs.cpu().numpy(), o_obs) if ck["fast_scan"] else np.allclose(obs.cpu().numpy(), o_obs, rtol=0, atol=1e-6)):
                     bad.append("obs")
+                if not ck["fast_scan"] and not np.allclose(got["anomaly"], ob.state["anomaly"], rtol=0, atol=1e-6):
+                    bad.append("anomaly scores")
             if bad:
                 print(f"case {case}: MISMATCH at tick {t}: M={M} blocks={blocks} n_active={n_active} K={K} N={N} L={L} "
                       f"shuffle={shuffle} cfg={ck}\n  " + "\n  ".join(bad[:6]))
