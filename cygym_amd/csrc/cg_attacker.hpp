@@ -143,7 +143,7 @@ __device__ __forceinline__ int spread_x_counts(Env& e, const uint16_t* cur, cons
       for (int m = 0; !w.done() && m <= last; ++m) {
         const bool ex = w.at_extra(e);
         n += !(ex ? x_blocked(e, w.j) : e.blocked(w.k));
-        if (m == last && dc) byte_or(e.cby, ex ? (int)w.vx : (int)e.ocol[w.k], ebit);   // DC attribution :1163-1168
+        if (m == last && dc) cby_or(e, ex ? (int)w.vx : (int)e.ocol[w.k], ebit);   // DC attribution :1163-1168
         w.next(e, ex);
       }
       cntv[i] = (uint16_t)n;
@@ -443,7 +443,7 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
       int s = slist[i];
       if (!(e.dst[s] & CG_D_DC)) continue;
       if (COLD(xany && x_isout(e, s))) continue;   // attributed while its log entries were counted
-      if (cur[s] < e.optr[s + 1]) byte_or(e.cby, e.ocol[cur[s]], ebit);
+      if (cur[s] < e.optr[s + 1]) cby_or(e, e.ocol[cur[s]], ebit);
     }
     wsync();
     SUBSTAMP(14);

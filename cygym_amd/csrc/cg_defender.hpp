@@ -51,7 +51,7 @@ __device__ __forceinline__ void def_global(Env& e, const KP& P, int at, const in
         e.stash[d] = (uint8_t)(CG_S_VALID | (e.flags[d] & CG_S_KEEP));
         e.stash[M + d] = e.busy[d];
         e.stash[2 * M + d] = e.wl[d];
-        e.stash[3 * M + d] = e.cby[d];
+        e.stash[3 * M + d] = (uint8_t)cby_get(e, d);
       }
     }
     ie[CG_I_CKPT_CNT] += 1;
@@ -79,8 +79,8 @@ __device__ __forceinline__ void def_clean(Env& e, const KP& P, const int16_t* de
     b = __popcll(ballot(hit && !(f & CG_F_COMP)));
     int dl = 0;
     if (hit) {
-      dl = e.cby[d];
-      e.cby[d] = 0;
+      dl = (int)cby_get(e, d);
+      cby_clear(e, d);
       e.flags[d] = (uint8_t)(f & ~(CG_F_COMP | CG_F_WLADV));
       int b0 = 0;
       if (occ) { b0 = occ[d]; occ[d] = (uint8_t)(b0 + 1); }
@@ -107,8 +107,8 @@ __device__ __forceinline__ void def_clean(Env& e, const KP& P, const int16_t* de
       if (hit) {
         if (f & CG_F_COMP) ++n_first_comp; else ++n_first_clean;
         n_rest += k - 1;
-        disc |= e.cby[d];
-        e.cby[d] = 0;
+        disc |= (int)cby_get(e, d);
+        cby_clear(e, d);
         e.flags[d] = (uint8_t)(f & ~(CG_F_COMP | CG_F_WLADV));
         int b0 = occ ? occ[d] : 0;
         if (occ) occ[d] = (uint8_t)(b0 + k);
@@ -321,8 +321,8 @@ __device__ __forceinline__ float slow_scan(Env& e, const KP& P, int n_mult, doub
         }
       }
       if (anom && snd < M) {   // (a sender id outside the network: the reference would raise KeyError)
-        disc |= e.cby[snd];
-        e.cby[snd] = 0;
+        disc |= (int)cby_get(e, snd);
+        cby_clear(e, snd);
         atomicAnd((unsigned int*)(e.flags + (snd & ~3)), ~((uint32_t)CG_F_COMP << ((snd & 3) * 8)));
         e.busy[snd] = (uint8_t)cg_randint(e.draw(CG_SITE_STALL_SCAN, snd, ord), 0, P.c.default_high);
       }
@@ -457,7 +457,7 @@ __device__ __forceinline__ void def_per_device(Env& e, const KP& P, int at, cons
       if (n_iter == 1) {
         if (e.lane == 0) {
           e.flags[d0] = (uint8_t)((e.flags[d0] & ~CG_S_KEEP) | (sf & CG_S_KEEP));
-          e.busy[d0] = sb; e.wl[d0] = sw; e.cby[d0] = sc;
+          e.busy[d0] = sb; e.wl[d0] = sw; cby_put(e, d0, sc);
         }
         wsync();
       }
@@ -480,7 +480,7 @@ __device__ __forceinline__ void def_per_device(Env& e, const KP& P, int at, cons
         e.busy[d] = (uint8_t)cg_randint(e.draw(CG_SITE_STALL_PATCH, d, 0), 0, P.c.default_high);
     } else if (hit && at == 7) {  // :1082-1089
       e.flags[d] = (uint8_t)((f | CG_F_NYA) & ~(CG_F_COMP | CG_F_WLADV));
-      e.cby[d] = 0;
+      cby_clear(e, d);
       e.wl[d] = 0;
     }
   } else {   // device-major with multiplicities
@@ -498,7 +498,7 @@ __device__ __forceinline__ void def_per_device(Env& e, const KP& P, int at, cons
               e.busy[d] = (uint8_t)cg_randint(e.draw(CG_SITE_STALL_PATCH, d, k - 1), 0, P.c.default_high);
           } else if (at == 7) {
             e.flags[d] = (uint8_t)((f | CG_F_NYA) & ~(CG_F_COMP | CG_F_WLADV));
-            e.cby[d] = 0;
+            cby_clear(e, d);
             e.wl[d] = 0;
           }
         }
@@ -603,7 +603,7 @@ __device__ __forceinline__ void def_per_device(Env& e, const KP& P, int at, cons
     int d0 = dev[0];
     if (n_mult > 0 && d0 >= 0 && d0 < M && e.lane == 0) {
       e.flags[d0] &= (uint8_t)~(CG_F_COMP | CG_F_WLADV);
-      e.cby[d0] = 0;
+      cby_clear(e, d0);
       e.wl[d0] = 0;
       e.busy[d0] = (uint8_t)cg_randint(e.draw(CG_SITE_STALL_ISOLATE, d0, n_mult - 1), 3, P.c.default_high + 3);
     }

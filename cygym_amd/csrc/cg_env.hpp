@@ -28,6 +28,10 @@ struct Env {
   // in-CSR columns + slot<->entry maps: global memory (L2-resident blob), or LDS in the WIDE kernel; read by block/unblock only
   const uint16_t *icol_g, *ieid_g, *oeid_g;
   uint8_t* stash;    // global [4][M] of this env
+  // Device.compromised_by: staged in LDS like the other planes (`cby`), or -- run-time sizes, where the per-env LDS
+  // footprint decides how many waves a CU holds -- left in global memory (`cby_g`, plane 3 of the env's live block):
+  // only cleans, the stash actions and the domain-controller attribution touch it, a few lanes at a time.
+  uint8_t* cby_g;    // non-null: comp_by lives in global memory (word-aligned: M % 4 == 0)
   // misc
   int M, MC, MS, lane, env;
   int cbits;         // bits needed for a per-lane device count
@@ -51,6 +55,30 @@ struct Env {
 
 __device__ __forceinline__ void byte_or(uint8_t* base, int d, uint32_t bits) {
   atomicOr((unsigned int*)(base + (d & ~3)), bits << ((d & 3) * 8));
+}
+// comp_by accessors.  The global form goes through device-scope atomics / atomic loads: lanes of this wave read what other
+// lanes wrote earlier in the tick, and plain vector loads may be served from a stale L1 line.
+#ifndef CG_CBY_GLOBAL
+#define CG_CBY_GLOBAL 1
+#endif
+__device__ __forceinline__ uint32_t cby_get(const Env& e, int d) {
+  if (CG_CBY_GLOBAL && e.cby_g) {
+    const uint32_t w = __hip_atomic_load((const uint32_t*)(e.cby_g + (d & ~3)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (w >> ((d & 3) * 8)) & 0xFFu;
+  }
+  return e.cby[d];
+}
+__device__ __forceinline__ void cby_clear(Env& e, int d) {
+  if (CG_CBY_GLOBAL && e.cby_g) atomicAnd((unsigned int*)(e.cby_g + (d & ~3)), ~(0xFFu << ((d & 3) * 8)));
+  else e.cby[d] = 0;
+}
+__device__ __forceinline__ void cby_or(Env& e, int d, uint32_t bits) {
+  if (CG_CBY_GLOBAL && e.cby_g) atomicOr((unsigned int*)(e.cby_g + (d & ~3)), bits << ((d & 3) * 8));
+  else byte_or(e.cby, d, bits);
+}
+__device__ __forceinline__ void cby_put(Env& e, int d, uint32_t v) {   // (one writer per byte and phase)
+  if (CG_CBY_GLOBAL && e.cby_g) { cby_clear(e, d); if (v) cby_or(e, d, v); }
+  else e.cby[d] = (uint8_t)v;
 }
 
 // number of set bits of blk in slot range [a, b)  (uniform; broadcast LDS reads)

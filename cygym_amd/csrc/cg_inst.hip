@@ -1,5 +1,8 @@
 // cg_inst.hip -- one instantiation unit of the tick kernels: compiled once per group (-DCG_INST_GROUP=0..7, see
 // CG_STEP_KERNELS in cg_device.hpp) so that the ~80 step_kernel variants build in parallel.
+#if defined(CG_INST_GROUP) && CG_INST_GROUP < 4
+#define CG_CBY_GLOBAL 0   // groups 0-3 hold the compile-time sizes (64 / 256 devices): comp_by is always staged in LDS there,
+#endif                    // the global-memory arms of its accessors (cg_env.hpp) are not even compiled
 #include "cg_device.hpp"
 #ifndef CG_INST_GROUP
 #error "compile with -DCG_INST_GROUP=<0..7>"

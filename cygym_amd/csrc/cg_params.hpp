@@ -18,6 +18,7 @@ struct DevTopo {
   int o_optr, o_ocol, o_os, o_ver, o_ano, o_dst, o_vul, o_nap, o_iptr, o_icol, o_ieid, o_oeid;
   int blob_bytes, lds_bytes, in_lds, multi;
   int K, KW, x_bytes;   // extra-edge list: capacity, blocked-bit words, bytes of its per-wave LDS section
+  int cby_global;       // run-time sizes with M % 4 == 0: the comp_by plane stays in global memory (3 planes staged, Env::cby_g)
   const double* apl;    // [CG_DET_APL_N] leaf-term table of the trained detector (global; tail of the blob), or nullptr
   // global views (host-side convenience; kernels outside the tick use them)
   const uint8_t *dstatic, *vuln, *napps;

@@ -119,12 +119,13 @@ __device__ __forceinline__ void write_obs_att(const uint8_t* flags, const float*
 
 struct WaveAux { uint64_t* srcb; int32_t* park; };
 // MAPS: the in-CSR columns and slot maps are staged in LDS too (the WIDE per-tick kernel, one 16-wave workgroup per CU)
-template <bool MAPS, class KP>
+template <bool MAPS, bool RT, class KP>   // RT: run-time size (comp_by may stay in global memory: one plane less in LDS)
 __device__ __forceinline__ WaveAux env_setup(Env& e, uint8_t* smem, const KP& P, int M, int MC, int Mp, int MS,
                                              int wave, int lane, int env) {
   uint8_t* wb = smem + P.shared_lds + (size_t)wave * P.wave_lds;
   e.flags = wb; e.busy = wb + MS; e.wl = wb + 2 * MS; e.cby = wb + 3 * MS;
-  e.scr = (uint32_t*)(wb + ((4 * MS + 15) & ~15));
+  const int n_planes = (RT && P.t.cby_global) ? 3 : 4;   // (comp_by left in global memory: Env::cby_g)
+  e.scr = (uint32_t*)(wb + ((n_planes * MS + 15) & ~15));
   e.blk = e.scr + Mp + Mp / 2;   // scratch: [Mp] words + [Mp] halfwords (must match wave_lds_bytes on the host)
   e.bin = e.blk + ((P.t.EW + 3) & ~3);
   e.ring = (uint16_t*)(e.bin + ((P.t.EW + 3) & ~3));
@@ -154,6 +155,7 @@ __device__ __forceinline__ WaveAux env_setup(Env& e, uint8_t* smem, const KP& P,
   e.seed = P.c.seed;
   e.multi = P.t.multi != 0;
   e.stash = P.b.stash + (size_t)env * 4 * M;
+  e.cby_g = (RT && P.t.cby_global) ? P.b.live + (size_t)env * 4 * M + 3 * (size_t)M : nullptr;
   return x;
 }
 
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 &
   const int G = P.a.max_groups, L = P.a.max_devs;
 
   Env e;
-  WaveAux aux = env_setup<WIDE>(e, smem, P, M, MC, Mp, MS, wave, lane, live ? env : 0);
+  WaveAux aux = env_setup<WIDE, MT == 0>(e, smem, P, M, MC, Mp, MS, wave, lane, live ? env : 0);
   uint64_t* srcb = aux.srcb;
   int32_t* park = aux.park;
   e.env = env;
@@ -236,7 +238,14 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 &
   uint32_t bw[PF_BLK], bwi[PF_BLK];
   int16_t dv[PF_DEV];
   const bool vec = (M & 3) == 0;
-  const int items = M >> 2;   // uint4 items of the [4][M] live block when M % 4 == 0
+  // uint4 items of the live block when M % 4 == 0: all [4][M] bytes, or -- comp_by left in global memory (run-time sizes) --
+  // the first three planes, rounded up to whole items (the few bytes of plane 3 that come along land in the padding
+  // in front of the scratch area)
+  const bool cbg = MT == 0 && P.t.cby_global;
+  const int items = cbg ? (3 * M + 15) >> 4 : M >> 2;
+  const int items_all = M >> 2;                          // the whole [4][M] block (stash copies)
+  const int items_wb = cbg ? (3 * M) >> 4 : M >> 2;      // write-back: whole items of the staged planes only ...
+  const int tail_wb = cbg ? ((3 * M) & 15) >> 2 : 0;     // ... and the remaining words one by one (plane 3 is not ours to write)
   // Run-time sizes (up to 2048 devices, where one wave per SIMD is resident and nothing hides a round trip): every
   // prologue load is pinned before the first LDS store.  A load whose only use sits in a conditional block is
   // otherwise SUNK into that block, next to its s_waitcnt, and the staging runs as a chain of 8-16 dependent
@@ -408,7 +417,7 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 &
       asm volatile("" : "+s"(plo), "+s"(phi));   // opaque: nothing derived from it is hoisted out of the tick loop
       pk = (KPT*)(((uint64_t)phi << 32) | plo);
     }
-    aux = env_setup<WIDE>(e, smem, P, M, MC, Mp, MS, wave, lane, env);
+    aux = env_setup<WIDE, MT == 0>(e, smem, P, M, MC, Mp, MS, wave, lane, env);
     srcb = aux.srcb; park = aux.park;
     // parked in LDS: an LDS load lands in a VGPR; readfirstlane tells the compiler the value is uniform, so the
     // 22 per-env scalars live in SGPRs across the tick body instead of 22 of the 128 VGPRs
@@ -652,13 +661,20 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 &
     wsync();
     if (vec) {
       for (int i = lane; i < items; i += WAVE) ((uint4*)e.flags)[i] = ((const uint4*)(P.snap.live + ss))[i];
+      if (cbg) {   // comp_by of the reloaded env: snapshot -> global, word by word
+        const uint32_t* cs = (const uint32_t*)(P.snap.live + ss + 3 * (size_t)M);
+        uint32_t* cd = (uint32_t*)e.cby_g;
+#pragma nounroll
+        for (int i = lane; i < M / 4; i += WAVE) cd[i] = cs[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      }
     } else {
       for (int pl = 0; pl < 4; ++pl)
         for (int i = lane; i < M; i += WAVE) e.flags[pl * MS + i] = P.snap.live[ss + pl * M + i];
     }
     if (vec) {   // 16 bytes per lane and trip (byte by byte this copy was 128 dependent round trips at 2048 devices)
 #pragma nounroll
-      for (int i = lane; i < items; i += WAVE) ((uint4*)(P.b.stash + so))[i] = ((const uint4*)(P.snap.stash + ss))[i];
+      for (int i = lane; i < items_all; i += WAVE) ((uint4*)(P.b.stash + so))[i] = ((const uint4*)(P.snap.stash + ss))[i];
     } else {
       for (int i = lane; i < 4 * M; i += WAVE) P.b.stash[so + i] = P.snap.stash[ss + i];
     }
@@ -740,7 +756,8 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 &
   // kept -- or spilled -- from the prologue, where the same addresses were used for the loads)
   asm volatile("" : "+v"(lane));
   if (vec) {
-    for (int i = lane; i < items; i += WAVE) ((uint4*)(P.b.live + so))[i] = ((const uint4*)e.flags)[i];
+    for (int i = lane; i < items_wb; i += WAVE) ((uint4*)(P.b.live + so))[i] = ((const uint4*)e.flags)[i];
+    if (lane < tail_wb) ((uint32_t*)(P.b.live + so))[items_wb * 4 + lane] = ((const uint32_t*)e.flags)[items_wb * 4 + lane];
   } else {
     for (int pl = 0; pl < 4; ++pl)
       for (int i = lane; i < M; i += WAVE) P.b.live[so + pl * M + i] = e.flags[pl * MS + i];

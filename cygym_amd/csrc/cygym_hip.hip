@@ -153,7 +153,7 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // LDS budget: shared blob prefix + WPB per-wave regions.  Prefers staging the in-CSR too.
 static size_t wave_lds_bytes(const DevTopo& t, int max_devs) {
-  size_t w = align_up((size_t)4 * ((t.M + 3) & ~3), 16) + (size_t)t.Mp * 6 + (size_t)((t.EW + 3) & ~3) * 4 * 2 + CG_LOG_RING * 4 +
+  size_t w = align_up((size_t)(t.cby_global ? 3 : 4) * ((t.M + 3) & ~3), 16) + (size_t)t.Mp * 6 + (size_t)((t.EW + 3) & ~3) * 4 * 2 + CG_LOG_RING * 4 +
              (size_t)((t.Mp / 32 + 2) & ~1) * 4 + (size_t)t.MC * 8 + (size_t)t.Mp * 2 +
              align_up((size_t)max_devs * 2, 16) + (size_t)t.x_bytes + 128 /* scalar parking of the fused kernel */;
   return align_up(w, 16);
@@ -161,7 +161,24 @@ static size_t wave_lds_bytes(const DevTopo& t, int max_devs) {
 // The in-CSR columns and slot maps (icol/ieid/oeid, ~2/3 of the blob) are read by block/unblock only (~9 % of
 // env-ticks): they stay in global memory (L2-resident); the staged prefix ends before them (o_icol), or already
 // before the float columns (o_os).
+static int choose_launch_with(cygym_handle* h, int max_devs, int* waves_out);
 static int choose_launch(cygym_handle* h, int max_devs) {
+  // comp_by in LDS (as ever), or -- run-time sizes with M % 4 == 0 -- in global memory when that frees enough LDS for
+  // another resident wave per CU (2048 devices without an extra-edge list: 4 -> 5)
+  DevTopo& t = h->t;
+  int w_lds = 0, w_glob = 0;
+  t.cby_global = 0;
+  const int rc = choose_launch_with(h, max_devs, &w_lds);
+  const bool can = t.M != 64 && t.M != 256 && (t.M & 3) == 0 && !getenv("CYGYM_CBY_LDS");
+  if (can) {
+    t.cby_global = 1;
+    if (choose_launch_with(h, max_devs, &w_glob) == 0 && (rc != 0 || w_glob > w_lds || getenv("CYGYM_CBY_GLOBAL"))) return 0;   // (env: test aid)
+    t.cby_global = 0;
+    return choose_launch_with(h, max_devs, &w_lds);
+  }
+  return rc;
+}
+static int choose_launch_with(cygym_handle* h, int max_devs, int* waves_out) {
   DevTopo& t = h->t;
   const size_t lds_cap = 160 * 1024;
   const size_t wave = wave_lds_bytes(t, max_devs);
@@ -195,6 +212,7 @@ static int choose_launch(cygym_handle* h, int max_devs) {
     }
   }
   if (!best) return -1;
+  *waves_out = best_waves;
   const size_t shared = (size_t)(best_floats ? t.o_icol : t.o_os);
   h->wpb = best; h->wave_lds = (int)wave; h->shared_lds = (int)shared;
   // The rollout kernels are built for 4 waves per SIMD whatever the size: 16 resident waves per CU at most, and one
@@ -275,6 +293,11 @@ int cygym_create(const cygym_topology* topo, const cygym_config* cfg, int32_t n_
   t.M = M; t.X = X; t.E = E; t.EW = (E + 31) / 32 > 0 ? (E + 31) / 32 : 1;
   t.MC = (M + WAVE - 1) / WAVE; t.Mp = t.MC * WAVE;
   t.K = topo->max_extra_edges; t.KW = (t.K + 31) / 32;
+  // Run-time sizes (not one of the compile-time device counts), M % 4 == 0: Device.compromised_by is not staged -- the few
+  // actions that touch it go to global memory -- which buys LDS: at 2048 devices 2 KB per env, the difference between four
+  // and five resident waves per CU (the lean kernels; with an extra-edge list four either way)
+  // (decided in choose_launch: only where it buys a resident wave -- the global-memory accesses cost 3-6 % otherwise)
+  t.cby_global = 0;
   t.x_bytes = t.K > 0 ? (int)align_up((size_t)4 * (t.K + ((t.KW + 1) & ~1)) + (size_t)16 * t.MC, 16) : 0;
   // one blob, laid out exactly as the LDS-shared section (see DevTopo)
   size_t off = 0;
