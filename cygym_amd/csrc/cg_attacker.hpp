@@ -156,7 +156,8 @@ __device__ __forceinline__ int spread_x_counts(Env& e, const uint16_t* cur, cons
 // CR: long rows scanned per cooperative step (4 where the registers allow it: run-time sizes in workgroups of <= 8 waves;
 // CR > 1 also selects the staged per-lane scan)
 // GS: chunks per staged group of a chunk loop (4, or the whole env at a compile-time size)
-template <bool XE, int CR, int GS, class KP>
+// WIDE: the log counts read a row's blocked words nine at a time (rows of <= 256 slots, see range_popc_wide)
+template <bool XE, int CR, int GS, bool WIDE, class KP>
 __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32_t* expl, int ex0, int n_expl,
                                                 uint64_t* srcb) {
   const int M = e.M, MC = e.MC, Mp = MC * WAVE;
@@ -344,17 +345,20 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
     }
     wsync();
     // log entries of every source: unblocked out-entries up to and including its pick
+    // ... and, in the same pass, the domain-controller attribution (:1163-1185): a DC source marks its pick
     int total_new = 0;
     for (int b0 = 0; b0 < n_src; b0 += WAVE) {
       const int i = b0 + e.lane;
       int n = 0;
       if (i < n_src) {
-        int s = slist[i];
-        int o0 = e.optr[s], o1 = e.optr[s + 1];
-        if (COLD(xany && x_isout(e, s))) {   // counted by spread_x_counts below
+        const int s = slist[i];
+        const int o0 = e.optr[s], o1 = e.optr[s + 1], c = cur[s];
+        const uint8_t st = e.dst[s];
+        if (COLD(xany && x_isout(e, s))) {   // counted (and attributed) by spread_x_counts below
         } else {
-          int end = cur[s] < o1 ? cur[s] + 1 : o1;
-          n = (end - o0) - range_popc(e.blk, o0, end);
+          const int end = c < o1 ? c + 1 : o1;
+          n = (end - o0) - (WIDE ? range_popc_wide(e.blk, o0, end) : range_popc(e.blk, o0, end));
+          if ((st & CG_D_DC) && c < o1) cby_or(e, e.ocol[c], ebit);
         }
       }
       cntv[i < Mp ? i : 0] = (uint16_t)n;
@@ -438,14 +442,6 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
     }
     wsync();
     SUBSTAMP(13);
-    // DC attribution (:1163-1185)
-    for (int i = e.lane; i < n_src; i += WAVE) {
-      int s = slist[i];
-      if (!(e.dst[s] & CG_D_DC)) continue;
-      if (COLD(xany && x_isout(e, s))) continue;   // attributed while its log entries were counted
-      if (cur[s] < e.optr[s + 1]) cby_or(e, e.ocol[cur[s]], ebit);
-    }
-    wsync();
     SUBSTAMP(14);
   }
 }

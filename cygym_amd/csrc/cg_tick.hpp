@@ -507,7 +507,7 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 &
         int ne = nexp0;
         if (ne > CG_MAX_EXPLOITS) ne = CG_MAX_EXPLOITS;
         __builtin_amdgcn_s_setprio(3);   // the spread bounds the launch: win issue arbitration over short envs
-        attacker_spread<XE, (MT == 0 && WPB <= 8) ? 4 : 1, CGP>(e, P, P.a.exploit + te * G * CG_MAX_EXPLOITS, ex0, ne, srcb);
+        attacker_spread<XE, (MT == 0 && WPB <= 8) ? 4 : 1, CGP, WIDE>(e, P, P.a.exploit + te * G * CG_MAX_EXPLOITS, ex0, ne, srcb);
         __builtin_amdgcn_s_setprio(0);
       } else {
         attacker_probe<XE>(e, srcb, cost);
