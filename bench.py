@@ -58,7 +58,7 @@ DEFAULT_SUB = {"target": 1, "cfg2": 1, "cfg3": 2, "cfg4": 2, "cfg5": 4}
 DEFAULT_MAX_EXTRA = {"target": 0, "cfg2": 0, "cfg3": 0, "cfg4": 0, "cfg5": -1}
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PMC_SUMMARY = "r02_pmc_summary.json"   # profiles/: per workload and kernel class, bytes per launch from the --pmc passes
+PMC_SUMMARY = "r03_pmc_summary.json"   # profiles/: per workload and kernel class, bytes per launch from the --pmc passes
 
 
 def algorithmic_bytes(M: int, E: int) -> float:

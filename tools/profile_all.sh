@@ -10,7 +10,7 @@ mkdir -p "$OUT"
 OUT=$(cd "$OUT" && pwd)
 cd /tmp && export TMPDIR=/tmp
 for w in $WL; do
-  B="python3 $REPO/bench.py --workload $w --steps 20 --warmup 5 --reps 3 --no-cpu-baseline --no-configs"
+  B="python3 $REPO/bench.py --workload $w --steps 20 --warmup 5 --reps 3 --no-cpu-baseline --no-configs --no-closed-loop"
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$w/kt" -- $B > "$OUT/$w.kt.json" 2> "$OUT/$w.kt.err"
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/$w/pmc_fetch" -- $B > /dev/null 2> "$OUT/$w.pf.err"
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/$w/pmc_write" -- $B > /dev/null 2> "$OUT/$w.pw.err"
