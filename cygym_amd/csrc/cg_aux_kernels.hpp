@@ -353,6 +353,109 @@ __global__ __launch_bounds__(HEAD_WAVES * WAVE) void actor_head_kernel(cygym_act
   }
 }
 
+// The same on the matrix cores (H % 4 == 0): a workgroup of 16 waves owns 16 rows; the [16 x H] x [H x n_out_p] product
+// is cut into 16 x 16 output tiles (v_mfma_f32_16x16x4_f32, fp32 in, fp32 accumulate), tile t on wave t % 16; the A
+// fragments (hidden activations) and B fragments (weights, k-major: 64-byte runs per k) come straight from global
+// memory / L2 -- every weight is used once per workgroup, so there is nothing to stage; the 16 x n_out_p outputs pass
+// through LDS once to get each row into one wave, which decodes it as above.
+typedef float cg_floatx4 __attribute__((ext_vector_type(4)));
+template <int HEAD_OPL>
+__global__ __launch_bounds__(16 * WAVE) void actor_head_mfma_kernel(cygym_actor_head hd, cygym_action_vectors src, cygym_actions dst,
+                                                                    int n_envs, const int32_t* ienv, uint64_t seed, int64_t env_id_base) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  float* outs = (float*)smem;   // [16][n_out_p]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n_out = src.n_types + src.n_devices + src.n_exploits + src.n_apps;
+  constexpr int n_out_p = HEAD_OPL * WAVE, n_tiles = n_out_p / 16;
+  const int H = hd.H, nt = src.n_types;
+  const int row0 = blockIdx.x * 16;
+  // Everything the decode of this wave's row will need is requested NOW, ahead of the product: the row id, the env's rng
+  // tick (epsilon-greedy), the type map (one entry per lane) and the bias -- a wave decodes one row, so a chain of
+  // dependent global loads at the end (row id -> tick, arg-max -> type map) would be the kernel's whole duration.
+  const int srow = row0 + wave;
+  const bool have = srow < src.n;
+  int row = have ? (src.rows ? src.rows[srow] : srow) : -1;
+  if (row >= n_envs) row = -1;
+  uint32_t tick = 0;
+  if (src.epsilon_thr && row >= 0) tick = (uint32_t)ienv[(size_t)row * CG_I_COUNT + CG_I_RNG_TICK];
+  int tmap = lane;
+  if (src.type_map && lane < nt) tmap = src.type_map[lane];
+  float bias_r[HEAD_OPL];
+#pragma unroll
+  for (int i = 0; i < HEAD_OPL; ++i) { const int j = lane + i * WAVE; bias_r[i] = (hd.bias && j < n_out) ? hd.bias[j] : 0.f; }
+  // The 16 x H tile of hidden activations goes through LDS (wave w copies row w, coalesced; odd pitch): an A fragment
+  // wants one value per lane from 16 DIFFERENT rows, which straight from global memory is 16 cache lines per load.
+  float* hid = outs + 16 * n_out_p;   // [16][H + 1]
+  const int hp = H + 1;
+  for (int k = lane; k < H; k += WAVE) hid[wave * hp + k] = have ? hd.hidden[(size_t)srow * hd.hidden_stride + k] : 0.f;
+  __syncthreads();
+  const int ak = lane >> 4;          // k offset inside a k-step of 4 (A fragment: row lane % 16; B fragment: column lane % 16)
+  const float* ap = hid + (lane & 15) * hp + ak;
+  for (int t = wave; t < n_tiles; t += 16) {
+    cg_floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* bp = hd.weight_t + (size_t)ak * n_out_p + t * 16 + (lane & 15);
+#pragma unroll 16
+    for (int k0 = 0; k0 < H; k0 += 4) {
+      const float a = ap[k0];
+      const float b = bp[(size_t)k0 * n_out_p];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    }
+    // D fragment: lane holds rows 4 * (lane / 16) + v, column lane % 16
+#pragma unroll
+    for (int v = 0; v < 4; ++v) outs[(4 * (lane >> 4) + v) * n_out_p + t * 16 + (lane & 15)] = acc[v];
+  }
+  __syncthreads();
+  if (row < 0) return;
+  const int G = dst.max_groups, L = dst.max_devs, M = src.n_devices;
+  float v[HEAD_OPL];
+#pragma unroll
+  for (int i = 0; i < HEAD_OPL; ++i) {
+    const float x = outs[wave * n_out_p + lane + i * WAVE] + bias_r[i];
+    v[i] = hd.tanh_out ? tanhf(x) : x;
+  }
+  auto range_argmax = [&](int lo, int hi) -> int {
+    uint32_t bh = 0u, bl = 0u;
+#pragma unroll
+    for (int i = 0; i < HEAD_OPL; ++i) {
+      const int j = lane + i * WAVE;
+      const uint32_t ob = float_order_bits(v[i]);
+      if (j >= lo && j < hi && ob > bh) { bh = ob; bl = ~(uint32_t)(j - lo); }
+    }
+    dpp_pair_max(bh, bl);
+    const uint32_t rl = (uint32_t)__builtin_amdgcn_readlane((int)bl, 63), rh = (uint32_t)__builtin_amdgcn_readlane((int)bh, 63);
+    return rh == 0u ? 0 : (int)~rl;
+  };
+  int at = nt > 0 ? range_argmax(0, nt) : 0;
+  if (src.epsilon_thr && nt > 0) {   // epsilon-greedy (do_agent.py:972-973)
+    const cg_u32x4 rr = cg_philox4x32_10((uint32_t)(env_id_base + row), tick, CG_SITE_EPS_TYPE, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+    if ((uint64_t)rr.v[0] < src.epsilon_thr) at = (int)cg_index(rr.v[1], (uint32_t)nt);
+  }
+  if (nt > 0) at = nt <= WAVE ? __shfl(tmap, at) : (src.type_map ? src.type_map[at] : at);
+  int16_t* out = const_cast<int16_t*>(dst.dev_idx) + (size_t)row * L;
+  int base = 0;
+#pragma unroll
+  for (int i = 0; i < HEAD_OPL; ++i) {
+    const int d = lane + i * WAVE - nt;
+    const bool on = d >= 0 && d < M && v[i] > 0.f;
+    const uint64_t m = __ballot(on);
+    const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if (on && pos < L) out[pos] = (int16_t)d;
+    base += __popcll(m);
+  }
+  const int cnt = base < L ? base : L;
+  for (int q = cnt + lane; q < L; q += WAVE) out[q] = 0;
+  const int ex = src.n_exploits > 0 ? range_argmax(nt + M, nt + M + src.n_exploits) : 0;
+  const int app = src.n_apps > 0 ? range_argmax(nt + M + src.n_exploits, n_out) : 0;
+  if (lane == 0) {
+    const_cast<int32_t*>(dst.atype)[(size_t)row * G] = at;
+    const_cast<int32_t*>(dst.exploit)[(size_t)row * G * CG_MAX_EXPLOITS] = ex;
+    const_cast<int32_t*>(dst.n_exploit)[(size_t)row * G] = 1;
+    const_cast<int32_t*>(dst.app)[(size_t)row * G] = app;
+    const_cast<int32_t*>(dst.dev_cnt)[(size_t)row * G] = cnt;
+    if (base > L && src.status) atomicOr(src.status, CG_DECODE_TRUNCATED);
+  }
+}
+
 // Synthetic action script of bench.py: alternating defender / attacker turns.
 // Mirrored in numpy by cygym_amd/actions.py (tests check equality).
 __global__ void gen_actions_kernel(KParams P, int tick, int32_t* mode, int32_t* n_groups, int32_t* atype,

@@ -637,8 +637,22 @@ int cygym_actor_head_decode(cygym_handle* h, const cygym_actor_head* head, const
   HIPCHK(h, hipSetDevice(h->device_id));
   const int n_out_p = ((int)n_out + 63) & ~63;
   if (head->weight_pitch != n_out_p) return fail(h, CYGYM_EINVAL, "cygym_actor_head_decode: weight_pitch must be n_out rounded up to 64%s", "");
-  const size_t lds = (size_t)n_out_p * HEAD_KC * sizeof(float);
+  size_t lds = (size_t)n_out_p * HEAD_KC * sizeof(float);
   const void* k = nullptr;
+  const bool mfma = (head->H & 3) == 0 && !getenv("CYGYM_HEAD_SCALAR");   // matrix-core variant: 16 rows per workgroup
+  if (mfma) {
+    lds = ((size_t)16 * n_out_p + (size_t)16 * (head->H + 1)) * sizeof(float);   // outputs + the hidden tile
+    switch (n_out_p / WAVE) {
+      case 1: k = (const void*)actor_head_mfma_kernel<1>; break;
+      case 2: k = (const void*)actor_head_mfma_kernel<2>; break;
+      case 3: k = (const void*)actor_head_mfma_kernel<3>; break;
+      case 4: k = (const void*)actor_head_mfma_kernel<4>; break;
+      case 5: k = (const void*)actor_head_mfma_kernel<5>; break;
+      case 6: k = (const void*)actor_head_mfma_kernel<6>; break;
+      case 7: k = (const void*)actor_head_mfma_kernel<7>; break;
+      default: k = (const void*)actor_head_mfma_kernel<8>; break;
+    }
+  } else
   switch (n_out_p / WAVE) {   // outputs per lane
     case 1: k = (const void*)actor_head_kernel<1>; break;
     case 2: k = (const void*)actor_head_kernel<2>; break;
@@ -649,14 +663,14 @@ int cygym_actor_head_decode(cygym_handle* h, const cygym_actor_head* head, const
     case 7: k = (const void*)actor_head_kernel<7>; break;
     default: k = (const void*)actor_head_kernel<8>; break;
   }
-  HIPCHK(h, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, HEAD_OPL_MAX * WAVE * HEAD_KC * (int)sizeof(float)));
-  const int rows_per_wg = HEAD_WAVES;
+  if (!mfma) HIPCHK(h, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, HEAD_OPL_MAX * WAVE * HEAD_KC * (int)sizeof(float)));
+  const int rows_per_wg = 16;   // (both variants: 16 waves, one row each to decode)
   int n_envs = h->n_envs;
   const int32_t* ienv = h->b.ienv;
   uint64_t seed = h->c.seed;
   int64_t base = h->c.env_id_base;
   void* args[] = {(void*)head, (void*)src, (void*)dst, &n_envs, &ienv, &seed, &base};
-  HIPCHK(h, hipLaunchKernel(k, dim3((src->n + rows_per_wg - 1) / rows_per_wg), dim3(HEAD_WAVES * WAVE), args, lds, (hipStream_t)stream));
+  HIPCHK(h, hipLaunchKernel(k, dim3((src->n + rows_per_wg - 1) / rows_per_wg), dim3(16 * WAVE), args, lds, (hipStream_t)stream));
   HIPCHK(h, hipGetLastError());
   return CYGYM_OK;
 }

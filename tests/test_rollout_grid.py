@@ -310,7 +310,7 @@ def test_actor_head_kernel_equals_linear_plus_decode():
     float weights with tanh wherever the decision is not a near-tie."""
     from cygym_amd.batched_env import BatchedCyberDefenseEnv
     from cygym_amd.topology import make_topology
-    for M, H, n_types, n_apps in ((256, 64, 11, 4), (64, 160, 3, 0), (37, 32, 14, 7)):
+    for M, H, n_types, n_apps in ((256, 64, 11, 4), (64, 160, 3, 0), (37, 32, 14, 7), (64, 30, 5, 2)):   # (H % 4 != 0: the scalar variant)
         topo, init, ck = make_topology(M, 1 if M != 64 else 4, seed=2, n_active=max(8, M - 8))
         cfg = abi.EnvConfig(seed=2, **ck)
         N, X = 203, cfg.max_exploits
