@@ -18,6 +18,14 @@ __device__ __forceinline__ bool spread_ok(const uint32_t* T, int v, int s) {
 __device__ __forceinline__ void spread_take(uint32_t* T, int v, int s) {
   atomicMin(&T[v], ((uint32_t)(s + 1) << 2) | (T[v] & 3u));
 }
+// A take that reports whether `v` had ALREADY been taken by another source in this tick (its old time is neither "never"
+// nor "compromised before the action"): one of the two then holds a pick the other one overrides -- a conflict that a
+// verification sweep has to settle.  A sweep without a single conflict leaves every pick standing: it IS the fix point,
+// no confirming sweep needed (see attacker_spread).
+__device__ __forceinline__ bool spread_take_c(uint32_t* T, int v, int s, uint32_t low) {
+  const uint32_t old = atomicMin(&T[v], ((uint32_t)(s + 1) << 2) | low) >> 2;
+  return old != T_TIME_INF && old != 0u;
+}
 // first slot k in [from, o1) that source s can take, or o1
 __device__ __forceinline__ int spread_scan_lane(const Env& e, const uint32_t* T, int s, bool dc,
                                                 int from, int o1) {
@@ -223,10 +231,13 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
     // Sweep 0: every source scans its row from the start and takes its pick.  Sweeps >= 1: a source whose pick an
     // EARLIER source took (the only way to lose one: dc sources and reachable targets never lose) resumes behind it.
     // The sources are in id order and a take only matters to later sources, so within a sweep the blocks run in
-    // ascending order and see each other's takes; a sweep in which no source lost its pick proves the fix point.
+    // ascending order and see each other's takes.  Termination: a pick can only be invalidated by ANOTHER source taking
+    // the same target, and every take reports whether its target had been taken before (atomicMin's old value): a sweep
+    // in which no take hit a taken target -- very often sweep 0 itself -- has left every pick standing, which is the fix
+    // point; only sweeps with such a conflict are followed by a verification sweep (round 2 always ran a confirming one).
     for (int sweep = 0; sweep <= M + 1; ++sweep) {
       ++n_rounds;
-      bool lost_any = false;
+      bool lost_any = false;    // some pick is not settled yet: another sweep is needed
       for (int b0 = 0; b0 < n_src; b0 += WAVE) {
         const int i = b0 + e.lane;
         bool coop = false;
@@ -260,8 +271,7 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
                 if (k < o1) { v = (k - o0) + ((k - o0) >= s ? 1 : 0); low = T[v] & 3u; }
               }
               cur[s] = (uint16_t)k;
-              if (k < o1) atomicMin(&T[v], ((uint32_t)(s + 1) << 2) | low);
-              if (sweep > 0) lost_any = true;
+              if (k < o1 && spread_take_c(T, v, s, low)) lost_any = true;
             } else {
               coop = true;
             }
@@ -311,7 +321,6 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
             if (rm[j]) rk[j] = rfrom[j] + __builtin_ctzll(rm[j]);
             else rk[j] = rfrom[j] + WAVE < ro1[j] ? spread_scan_coop(e, T, rs[j], rdc[j], rfrom[j] + WAVE, ro1[j]) : ro1[j];
           }
-          if (sweep > 0) lost_any = true;
           if (e.lane < CR) {   // lane j records the pick of row j
             const int j = e.lane;
             bool hv = rhave[0]; int ls = rs[0], k = rk[0], lo1 = ro1[0];
@@ -319,15 +328,17 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
             for (int q = 1; q < CR; ++q) if (j == q) { hv = rhave[q]; ls = rs[q]; k = rk[q]; lo1 = ro1[q]; }
             if (hv) {
               cur[ls] = (uint16_t)k;
-              if (k < lo1) spread_take(T, e.ocol[k], ls);
+              if (k < lo1) { const int tv = e.ocol[k]; if (spread_take_c(T, tv, ls, T[tv] & 3u)) lost_any = true; }
             }
           }
         }
         if (sweep > 0) wsync();   // the next block must see this block's takes
       }
-      if constexpr (XE) { if (COLD(xany)) { if (spread_x_round(e, T, cur, slist, n_src, sweep) && sweep > 0) lost_any = true; } }
+      // (rows with added edges keep the conservative rule: any change of such a pick, and their whole first sweep, asks for
+      // a verification sweep)
+      if constexpr (XE) { if (COLD(xany)) { if (spread_x_round(e, T, cur, slist, n_src, sweep) || sweep == 0) lost_any = true; } }
       wsync();
-      if (sweep > 0 && !__any(lost_any)) break;
+      if (!__any(lost_any)) break;
     }
     SUBSTAMP(11);
     SUBVAL(15, n_rounds);

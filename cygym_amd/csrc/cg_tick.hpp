@@ -171,6 +171,9 @@ template <int WPB, int MT, bool FUSED, bool XE, bool WIDE>
 #ifndef CG_LEAN_LB
 #define CG_LEAN_LB 6
 #endif
+#ifndef CG_WIDE_CR
+#define CG_WIDE_CR 1
+#endif
 // (a one-wave workgroup at a run-time size is only chosen when LDS, not registers, limits residency: 3 there.)
 // Register budget (second launch-bound = minimum waves per SIMD): the fused kernel and the WIDE per-tick kernel must keep 4 waves per SIMD (16 per CU: with one wave
 // per env and <= 16 envs per CU that is the whole batch in ONE residency round -- at 3 per SIMD a quarter of the
@@ -507,7 +510,7 @@ __global__ __launch_bounds__(WPB * WAVE, FUSED ? CG_FUSED_LB : (XE ? (WPB == 1 &
         int ne = nexp0;
         if (ne > CG_MAX_EXPLOITS) ne = CG_MAX_EXPLOITS;
         __builtin_amdgcn_s_setprio(3);   // the spread bounds the launch: win issue arbitration over short envs
-        attacker_spread<XE, (MT == 0 && WPB <= 8) ? 4 : 1, CGP, WIDE>(e, P, P.a.exploit + te * G * CG_MAX_EXPLOITS, ex0, ne, srcb);
+        attacker_spread<XE, (MT == 0 && WPB <= 8) ? 4 : (WIDE ? CG_WIDE_CR : 1), CGP, WIDE>(e, P, P.a.exploit + te * G * CG_MAX_EXPLOITS, ex0, ne, srcb);
         __builtin_amdgcn_s_setprio(0);
       } else {
         attacker_probe<XE>(e, srcb, cost);

@@ -228,12 +228,19 @@ class CyberDefenseEnvView:
         obs, raw, shaped, done = b.step_range(i, 1)
         if b.detector and any(int(g[0]) == 10 for g in groups):
             b.service_detectors([i])     # Detector.train is synchronous in the reference (volt_typhoon_env.py:961); only THIS env's request
-        self.state = obs[i].reshape(-1).cpu().numpy().astype(np.float64)   # (.cpu() synchronises with the launch)
-        return float(raw[i].item()), float(shaped[i].item()), bool(done[i].item())
+        # ONE device-to-host copy for everything the 6-tuple and `info` need: the observation, the rewards, done and the
+        # env's counter rows (all exactly representable in f64), instead of a copy / .item() per field
+        st = b.state
+        pack = torch.cat([obs[i].reshape(-1).double(), raw[i:i + 1], shaped[i:i + 1], done[i:i + 1].double(),
+                          st["ienv"][i].double(), st["fenv"][i]]).cpu().numpy()      # (.cpu() synchronises with the launch)
+        n = 6 * b.M
+        self.state = pack[:n].copy()
+        self._last_ie = pack[n + 3: n + 3 + S.I_COUNT].astype(np.int64)
+        self._last_fe = pack[n + 3 + S.I_COUNT:]
+        return float(pack[n]), float(pack[n + 1]), bool(pack[n + 2])
 
     def _info(self, action_taken, executed=None, grouped=False, partial=False):
-        ie = self._b.state["ienv"][self._i].cpu().numpy()
-        fe = self._b.state["fenv"][self._i].cpu().numpy()
+        ie, fe = self._last_ie, self._last_fe      # the rows _launch fetched with the observation
         # step() builds info before step_num += 1 (:1272 vs :1308), step_grouped after (:751 vs :759)
         info = {
             "mode": self.mode, "step_count": int(ie[S.I_STEP_NUM]) - (0 if (grouped or partial) else 1),
@@ -248,13 +255,12 @@ class CyberDefenseEnvView:
             info["executed_atype"] = executed
         return info
 
-    def _logs(self):
+    def _logs(self, total=None):
         """The tail of `simulator.logger.logs` (CDSimulator.py:667-676): the last 32 entries, or the last 2048 when the
         batch keeps the long history (detector=True).  `time_step` is `simulator.system_time`, which only the base
         class's `step` advances (CyberDefenseEnv.py:408) -- on this path it stays 0; every entry is of kind 'A'
         (volt_typhoon_env.py:1161)."""
-        ie = self._b.state["ienv"][self._i]
-        total = int(ie[S.I_LOG_TOTAL].item())
+        total = int(self._b.state["ienv"][self._i, S.I_LOG_TOTAL].item()) if total is None else int(total)
         if getattr(self._b, "detector", False) and self._b.state["hist"].numel() > 0:
             cap, ring = S.HIST_RING, self._b.state["hist"][self._i].cpu().numpy().view(np.uint16).reshape(S.HIST_RING, 2)
         else:
@@ -275,8 +281,8 @@ class CyberDefenseEnvView:
         cfg = self._b.cfg
         norm = HL.validate_single(self.mode, cfg.baseline, action, self._b.M, cfg.n_def_actions, cfg.n_att_actions)
         raw, shaped, done = self._launch([norm], grouped=False, partial=partial)
-        executed = int(self._b.state["ienv"][self._i, S.I_LAST_ATYPE].item())
-        return self.state, raw, shaped, done, self._info(action, executed, partial=partial), self._logs()
+        executed = int(self._last_ie[S.I_LAST_ATYPE])
+        return self.state, raw, shaped, done, self._info(action, executed, partial=partial), self._logs(self._last_ie[S.I_LOG_TOTAL])
 
     def step_grouped(self, groups):                      # :694-779
         assert isinstance(groups, (list, tuple)) and len(groups) > 0
@@ -293,4 +299,4 @@ class CyberDefenseEnvView:
                 raise ValueError("Action 11 requires exactly one device index")
             norm.append((int(at), HL._as_list(ex), dv, HL.app_index_value(app)))
         raw, shaped, done = self._launch(norm, grouped=True)
-        return self.state, raw, shaped, done, self._info(groups, grouped=True), self._logs()
+        return self.state, raw, shaped, done, self._info(groups, grouped=True), self._logs(self._last_ie[S.I_LOG_TOTAL])
