@@ -468,8 +468,9 @@ def closed_loop_block(D: Dist, per_tick_value, seed, n_per_gpu, M=256, blocks=1,
         simulate_grid(batch, Dp, Ap, n_mc, 60, randomize=False, graph=False, timers=tm)
         rec["eager"]["split_us_per_tick"] = {k: tm[k] / 60 * 1e6 for k in ("observe", "policy+scatter", "step")}
         rec["mean_device_list"] = float(batch.act["dev_cnt"].float().mean())
-        rec["launches_per_tick"] = (f"per strategy of the acting role: {'row gather, ' if nD * nA > 1 else ''}1 GEMM (Linear+ReLU), 1 fused last layer + "
-                                    f"decode + scatter; then 1 cygym_step: {1 + 2 * (2 if nD * nA > 1 else 1)}-{1 + 3 * (2 if nD * nA > 1 else 1)} launches per tick")
+        rec["launches_per_tick"] = ("1 GEMM (Linear+ReLU), 1 fused last layer + decode + scatter, 1 cygym_step" if nD * nA == 1 else
+                                    "the acting role's actors as ONE population (same architecture): [row gather on attacker ticks,] 1 batched GEMM, 1 ReLU, "
+                                    "1 fused last layer + decode + scatter with n_groups, 1 cygym_step -- independent of the number of strategies")
         rec["frac_of_per_tick_stepping"] = rec["graph"]["steady_state"]["value"] / per_tick_value if per_tick_value else None
         rec["check_unpinned_or_truncated"] = bool(batch.take_status() & (0x200 | abi.DECODE_TRUNCATED))
         out[name] = rec

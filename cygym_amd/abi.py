@@ -89,7 +89,8 @@ class ActionVectors(C.Structure):
 
 class ActorHead(C.Structure):
     _fields_ = [("hidden", C.c_void_p), ("weight_t", C.c_void_p), ("bias", C.c_void_p), ("H", C.c_int32),
-                ("hidden_stride", C.c_int32), ("tanh_out", C.c_int32), ("weight_pitch", C.c_int32)]
+                ("hidden_stride", C.c_int32), ("tanh_out", C.c_int32), ("weight_pitch", C.c_int32),
+                ("n_groups", C.c_int32), ("rows_per_group", C.c_int32)]
 
 
 DECODE_TRUNCATED = 0x10000

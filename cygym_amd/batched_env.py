@@ -424,10 +424,12 @@ class BatchedCyberDefenseEnv:
 
     def actor_head_decode(self, rows, hidden: torch.Tensor, weight_t: torch.Tensor, bias, n_types: int,
                           n_exploits: int | None = None, n_apps: int = 0, type_map=None, act=None, epsilon: float = 0.0,
-                          tanh: bool = False):
+                          tanh: bool = False, n_groups: int = 1):
         """The actor's LAST linear layer fused with decode_actions (cygym_actor_head_decode): action vector of row r =
         act(hidden[r] @ weight_t + bias), weight_t = head_weights(nn.Linear.weight) ([H, n_out rounded up to 64], k-major), decoded from registers
-        -- the [n, n_out] vectors never reach HBM.  Limits: H <= 256, n_out = n_types + M + n_exploits + n_apps <= 512."""
+        -- the [n, n_out] vectors never reach HBM.  Limits: H <= 256, n_out = n_types + M + n_exploits + n_apps <= 512.
+        n_groups = S > 1: a population of S same-shaped actors in one launch -- row r is multiplied with the matrix of actor
+        r // (n / S); weight_t [S, H, pitch], bias [S, n_out], n / S a multiple of 16."""
         act = self.act if act is None else act
         dst = self.actions_struct(act)
         n_exploits = self.cfg.max_exploits if n_exploits is None else int(n_exploits)
@@ -437,14 +439,19 @@ class BatchedCyberDefenseEnv:
         if not ok(hidden) or hidden.dim() != 2 or hidden.stride(1) != 1:
             raise ValueError("hidden must be a [n, H] float32 tensor on the batch's device with unit inner stride")
         pitch = (n_out + 63) // 64 * 64
-        if not ok(weight_t) or tuple(weight_t.shape) != (H, pitch) or not weight_t.is_contiguous():
-            raise ValueError(f"weight_t must be a contiguous float32 [{H}, {pitch}] tensor (see head_weights())")
-        if bias is not None and (not ok(bias) or tuple(bias.shape) != (n_out,) or not bias.is_contiguous()):
-            raise ValueError(f"bias must be a contiguous float32 [{n_out}] tensor")
+        S_ = int(n_groups)
+        wshape, bshape = ((H, pitch), (n_out,)) if S_ <= 1 else ((S_, H, pitch), (S_, n_out))
+        if not ok(weight_t) or tuple(weight_t.shape) != wshape or not weight_t.is_contiguous():
+            raise ValueError(f"weight_t must be a contiguous float32 {list(wshape)} tensor (see head_weights())")
+        if bias is not None and (not ok(bias) or tuple(bias.shape) != bshape or not bias.is_contiguous()):
+            raise ValueError(f"bias must be a contiguous float32 {list(bshape)} tensor")
         n = int(hidden.shape[0])
+        if S_ > 1 and (n % S_ or (n // S_) % 16):
+            raise ValueError("a population launch needs the same number of rows per actor, a multiple of 16")
         hd = abi.ActorHead()
         hd.hidden, hd.weight_t, hd.bias = hidden.data_ptr(), weight_t.data_ptr(), (bias.data_ptr() if bias is not None else None)
         hd.H, hd.hidden_stride, hd.tanh_out, hd.weight_pitch = H, int(hidden.stride(0)), int(bool(tanh)), pitch
+        hd.n_groups, hd.rows_per_group = (S_, n // S_) if S_ > 1 else (1, 0)
         src = abi.ActionVectors()
         src.n_types, src.n_devices, src.n_exploits, src.n_apps, src.n = int(n_types), self.M, n_exploits, int(n_apps), n
         src.status = self.status.data_ptr()

@@ -270,6 +270,11 @@ __global__ __launch_bounds__(HEAD_WAVES * WAVE) void actor_head_kernel(cygym_act
   const int H = hd.H;
   const int srow = blockIdx.x * HEAD_WAVES + wave;   // this wave's source row
   const bool have = srow < src.n;
+  if (hd.n_groups > 1) {   // a population of actors: this workgroup's 16 rows belong to ONE of them (rows_per_group % 16 == 0)
+    const int grp = (blockIdx.x * HEAD_WAVES) / hd.rows_per_group;
+    hd.weight_t += (size_t)grp * hd.H * hd.weight_pitch;
+    if (hd.bias) hd.bias += (size_t)grp * (src.n_types + src.n_devices + src.n_exploits + src.n_apps);
+  }
   float acc[HEAD_OPL];
 #pragma unroll
   for (int i = 0; i < HEAD_OPL; ++i) {
@@ -369,6 +374,11 @@ __global__ __launch_bounds__(16 * WAVE) void actor_head_mfma_kernel(cygym_actor_
   constexpr int n_out_p = HEAD_OPL * WAVE, n_tiles = n_out_p / 16;
   const int H = hd.H, nt = src.n_types;
   const int row0 = blockIdx.x * 16;
+  if (hd.n_groups > 1) {   // a population of actors: this workgroup's 16 rows belong to ONE of them (rows_per_group % 16 == 0)
+    const int grp = row0 / hd.rows_per_group;
+    hd.weight_t += (size_t)grp * H * n_out_p;
+    if (hd.bias) hd.bias += (size_t)grp * n_out;
+  }
   // Everything the decode of this wave's row will need is requested NOW, ahead of the product: the row id, the env's rng
   // tick (epsilon-greedy), the type map (one entry per lane) and the bias -- a wave decodes one row, so a chain of
   // dependent global loads at the end (row id -> tick, arg-max -> type map) would be the kernel's whole duration.

@@ -637,6 +637,8 @@ int cygym_actor_head_decode(cygym_handle* h, const cygym_actor_head* head, const
   HIPCHK(h, hipSetDevice(h->device_id));
   const int n_out_p = ((int)n_out + 63) & ~63;
   if (head->weight_pitch != n_out_p) return fail(h, CYGYM_EINVAL, "cygym_actor_head_decode: weight_pitch must be n_out rounded up to 64%s", "");
+  if (head->n_groups > 1 && (head->rows_per_group < 16 || (head->rows_per_group & 15) || (long long)head->n_groups * head->rows_per_group < src->n))
+    return fail(h, CYGYM_EINVAL, "cygym_actor_head_decode: rows_per_group must be a multiple of 16 and the groups must cover the rows%s", "");
   size_t lds = (size_t)n_out_p * HEAD_KC * sizeof(float);
   const void* k = nullptr;
   const bool mfma = (head->H & 3) == 0 && !getenv("CYGYM_HEAD_SCALAR");   // matrix-core variant: 16 rows per workgroup

@@ -75,6 +75,73 @@ class ActorPolicy:
         return {"atype": at, "exploit": ex.to(torch.int32), "dev_mask": v[:, k: k + M] > 0, "app": app.to(torch.int32)}
 
 
+class ActorPolicyGroup:
+    """A population of ActorPolicy strategies of ONE architecture (same layer shapes, activations, decode layout, type map
+    and epsilon) evaluated together: every hidden layer is one batched GEMM over the stacked weights (torch.baddbmm) and the
+    last layer + decode + scatter of all of them is ONE launch (cygym_actor_head_decode with n_groups).  The cost of a tick
+    then does not grow with the number of strategies of a grid -- the |D| x |A| grids of a Double-Oracle population share
+    their architecture.  Built by simulate_grid when it applies; rows arrive ordered by strategy, equally many (a multiple of
+    16) per strategy."""
+
+    tick_free = True
+
+    def __init__(self, policies):
+        self.policies = list(policies)
+        p0 = self.policies[0]
+        self.n_types, self.n_exploits, self.n_apps, self.epsilon = p0.n_types, p0.n_exploits, p0.n_apps, p0.epsilon
+        self.action_types = sorted({t for p in self.policies for t in p.action_types})
+        self._cache = None
+
+    @staticmethod
+    def key(p, M):
+        """Hashable architecture signature of an ActorPolicy that the group forward can run, or None."""
+        if not isinstance(p, ActorPolicy) or not p.fuse_head or p._split_head(M) is None:
+            return None
+        body, last, tanh = p._split_head(M)
+        sig = []
+        for m in body:
+            if isinstance(m, nn.Linear):
+                if m.bias is None or m.weight.dtype != torch.float32:
+                    return None
+                sig.append(("L", m.in_features, m.out_features))
+            elif isinstance(m, nn.ReLU):
+                sig.append(("R",))
+            else:
+                return None
+        tm = None if p.type_map is None else tuple(int(x) for x in p.type_map.tolist())
+        return (tuple(sig), last.in_features, last.out_features, bool(tanh), p.n_types, p.n_exploits, p.n_apps, tm, p.epsilon)
+
+    def _stacked(self, batch):
+        heads = [p._split_head(batch.M) for p in self.policies]
+        mods = [[m for m in h[0] if isinstance(m, nn.Linear)] + [h[1]] for h in heads]
+        ver = tuple((m.weight._version, m.weight.data_ptr(), m.bias._version) for ms in mods for m in ms)
+        if self._cache is None or self._cache[0] != ver:
+            n_lin = len(mods[0]) - 1
+            Ws = [torch.stack([ms[l].weight.detach().t() for ms in mods]).contiguous() for l in range(n_lin)]      # [S, in, out]
+            bs = [torch.stack([ms[l].bias.detach() for ms in mods])[:, None, :].contiguous() for l in range(n_lin)]  # [S, 1, out]
+            Wh = torch.stack([batch.head_weights(ms[-1].weight) for ms in mods]).contiguous()                       # [S, H, pitch]
+            bh = torch.stack([ms[-1].bias.detach() for ms in mods]).contiguous()                                      # [S, n_out]
+            self._cache = (ver, Ws, bs, Wh, bh)
+        return self._cache[1:]
+
+    @torch.no_grad()
+    def write(self, batch, act, rows, obs):
+        S = len(self.policies)
+        body, last, tanh = self.policies[0]._split_head(batch.M)
+        Ws, bs, Wh, bh = self._stacked(batch)
+        x = obs.reshape(S, obs.shape[0] // S, obs.shape[1])
+        l = 0
+        for m in body:
+            if isinstance(m, nn.Linear):
+                x = torch.baddbmm(bs[l], x, Ws[l])
+                l += 1
+            else:
+                x = torch.relu_(x)
+        hidden = x.reshape(obs.shape[0], -1)
+        batch.actor_head_decode(rows, hidden, Wh, bh, self.n_types, self.n_exploits, self.n_apps, self.policies[0]._map(obs.device), act,
+                                epsilon=self.epsilon, tanh=tanh, n_groups=S)
+
+
 class FusedMLP(nn.Sequential):
     """nn.Sequential of Linear / ReLU / Tanh whose Linear + ReLU pairs run as ONE GEMM with a ReLU epilogue
     (torch._addmm_activation) on 2-D inputs -- one launch less per hidden layer of a closed-loop tick."""

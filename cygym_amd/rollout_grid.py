@@ -204,6 +204,22 @@ def _write_rows(batch, act, r, a, L):
     act["dev_idx"].index_copy_(0, r, a["dev_idx"].to(torch.int16))
 
 
+def _group_actors(batch, items, M):
+    """Strategies of one role and sub-batch that are actor networks of ONE architecture with equally many rows (a multiple
+    of 16) each are evaluated as a population: batched GEMMs + one head launch (policies.ActorPolicyGroup)."""
+    from .policies import ActorPolicyGroup
+    if len(items) < 2 or not hasattr(batch, "actor_head_decode"):
+        return items
+    keys = [ActorPolicyGroup.key(p, M) for p, _, _, _ in items]
+    n0 = int(items[0][1].numel())
+    if keys[0] is None or any(k != keys[0] for k in keys) or n0 % 16 or any(int(it[1].numel()) != n0 for it in items):
+        return items
+    r64 = torch.cat([it[1] for it in items])
+    ids = r64.cpu().numpy()
+    sl = slice(int(ids[0]), int(ids[-1]) + 1) if (np.diff(ids) == 1).all() else None      # (the defender's strategies: one ascending range)
+    return [(ActorPolicyGroup([it[0] for it in items]), r64, r64.to(torch.int32), sl)]
+
+
 def simulate_grid(batch, def_policies, att_policies, n_mc: int, T: int, randomize: bool = True,
                   group=None, n_total: int | None = None, cell_offset: int = 0, timers: dict | None = None,
                   graph: bool = False, streams: int = 1):
@@ -271,7 +287,7 @@ def simulate_grid(batch, def_policies, att_policies, n_mc: int, T: int, randomiz
                 sl = slice(int(ids[0]), int(ids[-1]) + 1) if ids[-1] - ids[0] + 1 == ids.size else None
                 t64 = torch.from_numpy(ids).to(dev)
                 items.append((p, t64, t64.to(torch.int32), sl))
-            plan[r].append(items)
+            plan[r].append(_group_actors(batch, items, M) if fused else items)
     bl = baseline_schedule(def_policies, att_policies, cell_np, n_mc, min(T, 4), _cfg_baseline_code(batch))
     # (ticks >= 2 repeat with period 2: rows 2 / 3 of the schedule; shorter runs only have the first rows)
     mode_words = [torch.from_numpy(((bl[t] + 1) << S.MODE_BASELINE_SHIFT) | (t % 2)).to(device=dev, dtype=torch.int32)

@@ -310,6 +310,10 @@ typedef struct cygym_actor_head {
   int32_t H, hidden_stride;
   int32_t tanh_out;
   int32_t weight_pitch;    /* floats per row of weight_t: n_out rounded up to a multiple of 64 (rows 16-byte aligned)  */
+  /* Several actors of ONE architecture in one launch (a population of strategies): source row r belongs to actor
+   * r / rows_per_group and is multiplied with that actor's matrix, weight_t + (r / rows_per_group) * H * weight_pitch, and
+   * bias + (r / rows_per_group) * n_out.  rows_per_group must be a multiple of 16; n_groups <= 1: one actor for all rows. */
+  int32_t n_groups, rows_per_group;
 } cygym_actor_head;
 int cygym_actor_head_decode(cygym_handle* h, const cygym_actor_head* head, const cygym_action_vectors* layout,
                             const cygym_actions* dst, void* stream);

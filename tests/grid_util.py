@@ -113,3 +113,18 @@ class IntActor(torch.nn.Module):
 
     def forward(self, x):
         return (torch.relu(x @ self.w1) @ self.w2) * 16 + self.pos
+
+
+def int_mlp_actor(state_dim, action_dim, hidden, seed, device="cpu"):
+    """cygym_amd.policies.mlp_actor with integer weights (exact in float32 on every device and in every summation order)
+    and a last-layer bias that makes every arg-max unique: the architecture the fused head / population paths take."""
+    from cygym_amd.policies import mlp_actor
+    net = mlp_actor(state_dim, action_dim, (hidden,), seed=seed)
+    rs = np.random.RandomState(seed)
+    lin = [m for m in net if isinstance(m, torch.nn.Linear)]
+    with torch.no_grad():
+        lin[0].weight.copy_(torch.tensor(rs.randint(-1, 2, size=lin[0].weight.shape), dtype=torch.float32))
+        lin[0].bias.copy_(torch.tensor(rs.randint(-2, 3, size=lin[0].bias.shape), dtype=torch.float32))
+        lin[1].weight.copy_(torch.tensor(rs.randint(-1, 2, size=lin[1].weight.shape) * 16, dtype=torch.float32))
+        lin[1].bias.copy_(torch.arange(action_dim, dtype=torch.float32) - action_dim // 3)
+    return net.to(device)

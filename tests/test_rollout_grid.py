@@ -342,6 +342,42 @@ def test_actor_head_kernel_equals_linear_plus_decode():
         env.close()
 
 
+def test_actor_population_is_one_batched_forward_and_one_head_launch():
+    """Strategies that are actor networks of one architecture are evaluated as a population (ActorPolicyGroup: batched GEMMs
+    + ONE cygym_actor_head_decode launch with n_groups) -- same payoffs and final state as the oracle loop, which runs every
+    actor on its own with the torch decode."""
+    from grid_util import int_mlp_actor
+    from cygym_amd.batched_env import BatchedCyberDefenseEnv
+    from cygym_amd.policies import ActorPolicy
+    from cygym_amd.rollout_grid import simulate_grid
+    topo, init, cfg = _setup()
+    M, X, T, n_mc = topo.M, cfg.max_exploits, 30, 16
+    def_types = [1, 4, 5, 6, 7, 8, 9, 13, 2, 12, 11, 3]
+    def make(dev):
+        D = [ActorPolicy(int_mlp_actor(6 * M, len(def_types) + M + X + 4, 16, 31 + i, dev), len(def_types), X, 4, type_map=def_types) for i in range(2)]
+        A = [ActorPolicy(int_mlp_actor(4 * M + X, 3 + M + X, 16, 41 + j, dev), 3, X, 0, type_map=[1, 2, 3]) for j in range(2)]
+        return D, A
+    N = 2 * 2 * n_mc
+    og = OracleGrid(topo, cfg, N, init, 1, M)
+    E_def, E_att = simulate_grid(og, *make("cpu"), n_mc, T, randomize=True)
+    batch = BatchedCyberDefenseEnv(topo, cfg, N, init, device="cuda:0", max_groups=1, max_devs=M)
+    calls = []
+    orig = batch.actor_head_decode
+    def spy(*a, **k):
+        calls.append(k.get("n_groups", 1))
+        return orig(*a, **k)
+    batch.actor_head_decode = spy
+    U_def, U_att = simulate_grid(batch, *make("cuda:0"), n_mc, T, randomize=True, graph=True)
+    assert calls and all(g == 2 for g in calls), calls          # one head launch per tick, both actors of the acting role in it
+    np.testing.assert_allclose(U_def, E_def, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(U_att, E_att, rtol=0, atol=1e-9)
+    got = batch.state_numpy()
+    got["ienv"] = got["ienv"].copy(); got["ienv"][:, S.I_FLAGS] &= ~0x80
+    assert not gio.compare_state(got, og.ob.state, "actor population")
+    assert len(np.unique(np.round(E_def, 6))) > 2
+    batch.close()
+
+
 def test_view_step_cost_does_not_grow_with_the_batch():
     """CyberDefenseEnvView.step launches only its own env (cygym_step_range) and writes only its own action row:
     the other envs of the batch neither tick nor have their action rows touched."""
