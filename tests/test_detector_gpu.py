@@ -87,3 +87,52 @@ def test_scan_without_current_forest_is_flagged(detector):
     assert (fl & S.E_UNPINNED).all()                      # the scan at tick 2 ran on a pending request
     assert bool((fl & S.E_DET_PENDING).any()) == (not detector)
     env.close()
+
+
+def test_foreign_sender_ids_count_towards_the_majority_like_in_the_oracle():
+    """A ring loaded from the host may hold sender ids outside the network (the reference would raise KeyError when it
+    touches them): in trained mode such an entry predicted "A" still counts towards the majority -- only the write is
+    skipped -- exactly as in the coin path and in the oracle."""
+    from cygym_amd import detector as D
+    from cygym_amd.batched_env import BatchedCyberDefenseEnv
+    from cygym_amd.topology import make_topology
+    from oracle import driver as od
+    M, N = 16, 40
+    topo, init, ck = make_topology(M, 2, seed=9, n_active=14)
+    cfg = abi.EnvConfig(seed=9, **ck)
+    rs = np.random.RandomState(9)
+    # a forest fitted on a dense block: the sampled "near" points are predicted "D", the "far" ones (foreign ids among them) "A"
+    tr = np.stack([rs.randint(0, 8, 400), rs.randint(0, 8, 400)], 1)
+    forest = D.fit_forest(tr, 123)
+    cand = np.array([[a, b] for a in range(8) for b in range(8)])
+    near = cand[~D.predict_flat(forest, cand)]
+    cand = np.array([[a, b] for a in list(range(8, M)) + list(range(3000, 3050)) for b in range(8, M)])
+    far_pts = cand[D.predict_flat(forest, cand)]
+    assert len(near) >= 4 and (far_pts[:, 0] >= M).any() and (far_pts[:, 0] < M).any()
+    st = {k: np.repeat(np.asarray(v), N, axis=0) for k, v in init.items()}
+    ring = np.zeros((N, S.LOG_RING, 2), np.int64)
+    for e in range(N):
+        n_far = 10 + e % 12                        # around the majority threshold of 16 of 30
+        ring[e] = near[rs.randint(0, len(near), S.LOG_RING)]
+        far = rs.permutation(S.SCAN_WINDOW)[:n_far] + (S.LOG_RING - S.SCAN_WINDOW)
+        ring[e, far] = far_pts[rs.randint(0, len(far_pts), n_far)]
+    st["ring"] = ring
+    st["ienv"] = st["ienv"].copy()
+    st["ienv"][:, S.I_LOG_TOTAL] = S.LOG_RING
+    st["ienv"][:, S.I_FLAGS] |= S.E_DET_TRAIN
+    st["flags"] = st["flags"] | S.F_COMP
+    st["forest"] = np.repeat(forest[None], N, axis=0)
+    env = BatchedCyberDefenseEnv(topo, cfg, N, st, device="cuda:0", max_groups=1, max_devs=4, detector=True)
+    ob = od.OracleBatch(topo, cfg, N, detector=True)
+    ob.load_state(st)
+    act = od.alloc_actions(N, 1, 4)
+    act["mode"][:] = S.MODE_DEFENDER; act["atype"][:] = 5; act["dev_cnt"][:] = 2; act["dev_idx"][:, :2] = [1, 2]
+    env.set_actions_numpy(act)
+    env.step(); ob.step(act)
+    got = env.state_numpy()
+    got["ienv"] = got["ienv"].copy(); got["ienv"][:, S.I_FLAGS] &= ~0x80
+    bad = gio.compare_state(got, ob.state, "foreign senders")
+    assert not bad, "\n".join(bad[:6])
+    cleaned = ((st["flags"] & S.F_COMP) != 0) & ((ob.state["flags"] & S.F_COMP) == 0)
+    assert 0 < cleaned.any(axis=1).sum() < N, "the cases must straddle the majority threshold"
+    env.close()
