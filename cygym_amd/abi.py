@@ -93,6 +93,17 @@ class ActorHead(C.Structure):
                 ("n_groups", C.c_int32), ("rows_per_group", C.c_int32)]
 
 
+MLP_MAX_HIDDEN = 3
+
+
+class ActorMlp(C.Structure):
+    _fields_ = [("obs", C.c_void_p), ("w", C.c_void_p * MLP_MAX_HIDDEN), ("b", C.c_void_p * MLP_MAX_HIDDEN),
+                ("w_head", C.c_void_p), ("b_head", C.c_void_p), ("obs_stride", C.c_int32), ("K", C.c_int32),
+                ("n_hidden", C.c_int32), ("width", C.c_int32 * MLP_MAX_HIDDEN), ("tanh_out", C.c_int32),
+                ("obs_by_env", C.c_int32), ("obs_role", C.c_int32), ("reserved", C.c_int32), ("n_groups", C.c_int32),
+                ("rows_per_group", C.c_int32)]
+
+
 DECODE_TRUNCATED = 0x10000
 
 BASELINES = {"Nash": 0, "No Defense": 1, "Preset": 2, "No Attack": 3}

@@ -484,6 +484,101 @@ class BatchedCyberDefenseEnv:
         out[:, :n_out] = weight.detach().t()
         return out
 
+    @staticmethod
+    def pack_linear(weight: torch.Tensor, pad_out_to: int = 16) -> torch.Tensor:
+        """nn.Linear.weight [N, K] -> the fragment-ordered copy cygym_actor_mlp_decode reads (cygym_abi.h):
+        [ceil(N / 16)][ceil(K / 16)][64][4] with packed[t][g][lane][i] = W[16 t + lane % 16][16 g + 4 (lane // 16) + i],
+        zeros outside; N rounded up to a multiple of `pad_out_to` (64 for the last layer)."""
+        N, K = weight.shape
+        Np, Kp = (N + pad_out_to - 1) // pad_out_to * pad_out_to, (K + 15) // 16 * 16
+        w = torch.zeros((Np, Kp), dtype=torch.float32, device=weight.device)
+        w[:N, :K] = weight.detach()
+        # [t, c, g, kk, i] -> [t, g, kk, c, i]  (lane = 16 kk + c)
+        return w.reshape(Np // 16, 16, Kp // 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous().reshape(-1)
+
+    def actor_mlp_decode(self, rows, obs: torch.Tensor, hidden_layers, head, n_types: int, n_exploits: int | None = None,
+                         n_apps: int = 0, type_map=None, act=None, epsilon: float = 0.0, tanh: bool = False, n_groups: int = 1,
+                         obs_by_env: bool = False, obs_role: str | None = None):
+        """The WHOLE actor (Linear-ReLU stack + last Linear layer, do_agent.py:357-370) fused with decode_actions
+        (cygym_actor_mlp_decode): ONE launch per acting role -- hidden activations and action vectors never reach HBM.
+          obs            [n, K] float32 (unit inner stride); with obs_by_env the batch's [N, K] role view, read at rows `rows`
+          hidden_layers  [(packed weights, bias, width), ...] 1 to 3 of them: pack_linear(nn.Linear.weight), widths multiples of
+                         16 up to 256
+          head           (pack_linear(last.weight, 64), bias): n_out = n_types + M + n_exploits + n_apps <= 512
+        n_groups = S > 1: a population of S same-shaped actors (packed tensors / biases of all actors concatenated, actor
+        after actor), row r belongs to actor r // (n / S), n / S a multiple of 16.
+        obs_role = "defender" / "attacker": `obs` is not read (pass None) -- the kernel builds the role's view of env rows[r]
+        (or r) on chip from the batch's CURRENT state (flag plane + static columns: 256 bytes per env instead of a 6 KB view;
+        _get_defender_state / _get_attacker_state, CyberDefenseEnv.py:194-257), so the tick need not write role views. M even."""
+        act = self.act if act is None else act
+        dst = self.actions_struct(act)
+        n_exploits = self.cfg.max_exploits if n_exploits is None else int(n_exploits)
+        n_out = int(n_types) + self.M + n_exploits + int(n_apps)
+        ok = lambda t: t.dtype == torch.float32 and t.device == self.device  # noqa: E731
+        if not 1 <= len(hidden_layers) <= abi.MLP_MAX_HIDDEN:
+            raise ValueError(f"1 to {abi.MLP_MAX_HIDDEN} hidden layers")
+        S_ = max(1, int(n_groups))
+        ml = abi.ActorMlp()
+        if obs_role is not None:
+            if obs_role not in ("defender", "attacker") or self.M % 2:
+                raise ValueError("obs_role is 'defender' or 'attacker', on batches with an even device count")
+            K = self.role_width(obs_role)
+            ml.obs, ml.obs_stride, ml.K, ml.obs_role = None, K, K, (1 if obs_role == "defender" else 2)
+            obs_by_env = True
+        else:
+            if not ok(obs) or obs.dim() != 2 or obs.stride(1) != 1:
+                raise ValueError("obs must be a [n, K] float32 tensor on the batch's device with unit inner stride")
+            K = int(obs.shape[1])
+            ml.obs, ml.obs_stride, ml.K = obs.data_ptr(), int(obs.stride(0)), K
+        ml.n_hidden, ml.tanh_out, ml.obs_by_env = len(hidden_layers), int(bool(tanh)), int(bool(obs_by_env))
+        kin = (K + 15) // 16
+        for l, (w, b, width) in enumerate(hidden_layers):
+            width = int(width)
+            if width % 16 or not 16 <= width <= 256:
+                raise ValueError("hidden widths must be multiples of 16 up to 256")
+            if not ok(w) or not w.is_contiguous() or w.numel() != S_ * (width // 16) * kin * 256:
+                raise ValueError(f"hidden layer {l}: packed weights have the wrong size (see pack_linear)")
+            if b is not None and (not ok(b) or not b.is_contiguous() or b.numel() != S_ * width):
+                raise ValueError(f"hidden layer {l}: bias must hold {S_ * width} float32 values")
+            ml.w[l], ml.b[l], ml.width[l] = w.data_ptr(), (b.data_ptr() if b is not None else None), width
+            kin = width // 16
+        wh, bh = head
+        n_out_p = (n_out + 63) // 64 * 64
+        if not ok(wh) or not wh.is_contiguous() or wh.numel() != S_ * (n_out_p // 16) * kin * 256:
+            raise ValueError("head: packed weights have the wrong size (pack_linear(weight, 64))")
+        if bh is not None and (not ok(bh) or not bh.is_contiguous() or bh.numel() != S_ * n_out):
+            raise ValueError(f"head: bias must hold {S_ * n_out} float32 values")
+        ml.w_head, ml.b_head = wh.data_ptr(), (bh.data_ptr() if bh is not None else None)
+        n = int(rows.shape[0]) if (obs_by_env and rows is not None) else (self.N if obs_role is not None else int(obs.shape[0]))
+        if S_ > 1 and (n % S_ or (n // S_) % 16):
+            raise ValueError("a population launch needs the same number of rows per actor, a multiple of 16")
+        ml.n_groups, ml.rows_per_group = (S_, n // S_) if S_ > 1 else (1, 0)
+        src = abi.ActionVectors()
+        src.n_types, src.n_devices, src.n_exploits, src.n_apps, src.n = int(n_types), self.M, n_exploits, int(n_apps), n
+        src.status = self.status.data_ptr()
+        if epsilon > 0.0:
+            from . import rng as R
+            src.epsilon_thr = R.bernoulli_threshold(float(epsilon))
+        keep = [obs]
+        if rows is not None:
+            r = rows if (rows.dtype == torch.int32 and rows.is_contiguous()) else rows.to(torch.int32).contiguous()
+            if int(r.shape[0]) != n or r.device != self.device:
+                raise ValueError("rows must be a device tensor with one entry per source row")
+            keep.append(r)
+            src.rows = r.data_ptr()
+        elif n > self.N:
+            raise ValueError("more action rows than envs")
+        if obs_role is None and obs_by_env and int(obs.shape[0]) < self.N:
+            raise ValueError("obs_by_env needs the batch's [N, K] role view")
+        if type_map is not None:
+            tm = type_map if (type_map.dtype == torch.int32 and type_map.is_contiguous()) else type_map.to(torch.int32).contiguous()
+            if int(tm.numel()) != int(n_types) or tm.device != self.device:
+                raise ValueError("type_map must hold n_types int32 entries on the batch's device")
+            keep.append(tm)
+            src.type_map = tm.data_ptr()
+        _lib.check(self.lib.cygym_actor_mlp_decode(self._h, C.byref(ml), C.byref(src), C.byref(dst), self._stream()),
+                   self._h, "cygym_actor_mlp_decode")
+
     def take_status(self) -> int:
         """Read and clear the batch's status word: the OR of CG_E_TOPO_OVF | CG_E_BUSY_SAT | CG_E_DET_PENDING |
         CG_E_UNPINNED over the envs ticked since the last call (one 4-byte device-to-host copy; synchronises)."""

@@ -1,0 +1,370 @@
+// cg_actor_mlp.hpp -- cygym_actor_mlp_decode: the actor network of a closed-loop strategy (Linear-ReLU stack + last Linear layer,
+// do_agent.py:357-370) and decode_action (do_agent.py:970-998) in ONE launch.  Included by cg_aux_kernels.hpp (C-ABI unit).
+//
+// A workgroup of 16 waves owns 16 observation rows (= 16 envs).
+//   * Layer 0, [16 x K] x [K x N0]: the observation tile is requested from HBM in one go (up to 1536 columns = 96 KB per
+//     workgroup, 6 x 16 bytes per thread in flight: one workgroup per CU has to keep ~60 KB in flight to draw its share of the
+//     HBM bandwidth), lands in LDS in stages of 512 columns, and each stage is multiplied as soon as it has landed
+//     (v_mfma_f32_16x16x4_f32).  Output tile t (16 columns) and k-slice q go to wave q * n_tiles + t; the k-slices' partial
+//     sums meet in LDS, where bias + ReLU are applied.
+//   * LDS rows are XOR-swizzled at 16-byte granularity (slot ^ row): an A fragment is ONE ds_read_b128 per four
+//     matrix instructions -- lane (row r = lane % 16, kk = lane / 16) reads A[r][16 g + 4 kk .. + 3] -- and the four
+//     16-lane groups of that instruction hit 16 different slots (MI355X_MICROARCH.md, LDS table).
+//   * Weights come PACKED in fragment order (cygym_abi.h): lane reads B[16 g + 4 kk + i][16 t + lane % 16], i = 0..3, as one
+//     global_load_dwordx4, 1 KB contiguous per wave.  Every weight is read once per workgroup (from L2).
+//   * Further hidden layers and the last layer read their A fragments from the hidden tile in LDS the same way; the
+//     16 x n_out_p action vectors pass through LDS once to get each row into one wave, which decodes it (head_decode_row).
+constexpr int MLP_NB = 8, MLP_NB_SMALL = 4;   // k-groups per batch of weight requests: layer 0 / the later layers
+constexpr int MLP_KT = 1536, MLP_STAGE = 512, MLP_STAGES = MLP_KT / MLP_STAGE, MLP_THREADS = 16 * WAVE;
+
+// LDS plan (floats), the same arithmetic on both sides of the launch
+struct MlpPlan {
+  int kt;        // columns of the observation tile held at once: min(K rounded up to whole stages, MLP_KT)
+  int region_a;  // observation tile, later the [16][n_out_p] action vectors
+  int hp;        // pitch of a hidden tile: the widest hidden layer rounded up to 64
+  int total;     // floats
+};
+__host__ __device__ inline MlpPlan mlp_plan(int K, int n_hidden, const int32_t* width, int n_out_p) {
+  MlpPlan p;
+  const int ks = (K + MLP_STAGE - 1) / MLP_STAGE * MLP_STAGE;   // (whole stages: the stage stores need no column guard)
+  p.kt = ks < MLP_KT ? ks : MLP_KT;
+  p.region_a = 16 * (p.kt > n_out_p ? p.kt : n_out_p);
+  int wmax = 0;
+#pragma unroll
+  for (int l = 0; l < CG_MLP_MAX_HIDDEN; ++l) wmax = (l < n_hidden && width[l] > wmax) ? width[l] : wmax;   // (constant indices: the kernel reads kernarg words)
+  p.hp = (wmax + 63) & ~63;
+  p.total = p.region_a + 16 * 256 + 2 * 16 * p.hp;
+  return p;
+}
+
+// obs_role != 0: the role view is not read from HBM but built in LDS from the batch's state -- the flag plane of the 16 envs
+// (256 bytes per env at M = 256 instead of a 6 KB view) and the topology's static columns, exactly as the tick kernel's
+// write_obs_def / write_obs_att build it (CyberDefenseEnv.py:194-257).
+struct MlpView {
+  const uint8_t* live;     // [N][4][M], plane 0 = flags
+  const float *osv, *ver, *ano;   // [M] static columns
+  const float* ano_dyn;    // [N][M] per-env anomaly plane (fast_scan = False) or nullptr
+  int M, X, max_exploits, role;
+};
+
+// acc += A[16 x (16 per group)] x B over the k-groups g0, g0 + gstep, ... < g1, in batches of NB groups: the B fragments of a
+// batch are requested together (one 16-byte load each, no branches: a group past the end re-reads the last valid one and
+// is skipped by a scalar branch), then consumed.  a_row = this lane's row of the swizzled LDS tile, r = lane % 16,
+// kk = lane / 16; wp = packed weights of this output tile, already offset by the lane, indexed by GLOBAL group
+// (gofs = global index of the tile's local group 0; gmax = last global group of the tile).  g0, g1, gstep are wave-uniform.
+template <int NB>
+__device__ __forceinline__ void mlp_b_load(float4 (&b)[NB], const float4* wp, const int gofs, const int gmax, const int g0, const int gstep) {
+#pragma unroll
+  for (int u = 0; u < NB; ++u) {
+    const int g = gofs + g0 + u * gstep;
+    b[u] = wp[(size_t)(g < gmax ? g : gmax) * WAVE];
+  }
+}
+template <int NB>
+__device__ __forceinline__ void mlp_mfma_batch(cg_floatx4& acc, const float* a_row, const int r, const int kk, const float4 (&b)[NB],
+                                               const int g0, const int g1, const int gstep) {
+#pragma unroll
+  for (int u = 0; u < NB; ++u) {
+    const int g = g0 + u * gstep;
+    if (g < g1) {   // (scalar branch)
+      const float4 a = *reinterpret_cast<const float4*>(a_row + ((((g << 2) + kk) ^ r) << 2));
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[u].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[u].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[u].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[u].w, acc, 0, 0, 0);
+    }
+  }
+}
+template <int NB>
+__device__ __forceinline__ void mlp_mfma_groups(cg_floatx4& acc, const float* a_row, const int r, const int kk, const float4* wp,
+                                                const int gofs, const int gmax, const int g0, const int g1, const int gstep) {
+  for (int g = g0; g < g1; g += NB * gstep) {
+    float4 b[NB];
+    mlp_b_load<NB>(b, wp, gofs, gmax, g, gstep);
+    mlp_mfma_batch<NB>(acc, a_row, r, kk, b, g, g1, gstep);
+  }
+}
+
+// k-slice partial sums of a hidden layer (part[wave][16][16]) -> bias + ReLU -> swizzled hidden tile `out` (pitch hp)
+__device__ __forceinline__ void mlp_finish_hidden(const float* part, const float* bias, const int N, const int n_tiles, const int ksplit,
+                                                  float* out, const int hp) {
+  for (int o = threadIdx.x; o < 16 * N; o += MLP_THREADS) {
+    const int row = o / N, c = o - row * N, t = c >> 4;
+    float s = bias ? bias[c] : 0.f;
+    for (int q = 0; q < ksplit; ++q) s += part[((q * n_tiles + t) << 8) + (row << 4) + (c & 15)];
+    out[row * hp + ((((c >> 2) ^ row) << 2) | (c & 3))] = s > 0.f ? s : 0.f;
+  }
+}
+
+template <int HEAD_OPL, int VW>
+__global__ __launch_bounds__(MLP_THREADS) void actor_mlp_kernel(cygym_actor_mlp ml, cygym_action_vectors src, cygym_actions dst, int n_envs,
+                                                                const int32_t* ienv, uint64_t seed, int64_t env_id_base, int dbg, unsigned long long* st, MlpView vw) {
+#ifdef CG_STAMPS
+#define MSTAMP(k) do { if (st && threadIdx.x == 0) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); st[(size_t)blockIdx.x * 16 + (k)] = _t; } } while (0)
+#else
+#define MSTAMP(k) do { } while (0)
+#endif
+  MSTAMP(0);
+  extern __shared__ __align__(16) uint8_t smem[];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // (wave: an SGPR, so are the tile / k-slice indices)
+  const int r = lane & 15, kk = lane >> 4;
+  constexpr int n_out_p = HEAD_OPL * WAVE;
+  const int K = ml.K, nt = src.n_types;
+  const int n_out = nt + src.n_devices + src.n_exploits + src.n_apps;
+  const MlpPlan pl = mlp_plan(K, ml.n_hidden, ml.width, n_out_p);
+  const int kt = pl.kt, hp = pl.hp;
+  float* At = reinterpret_cast<float*>(smem);
+  float* outs = At;                       // (the observation tile is dead by the time the last layer writes)
+  float* part = At + pl.region_a;         // [16 waves][16][16]
+  float* hin = part + 16 * 256;            // hidden tiles [16][hp], swizzled like the observation tile
+  float* hout = hin + 16 * hp;
+  const int row0 = blockIdx.x * 16;
+  const int G0 = (K + 15) >> 4;           // k-groups of layer 0
+  // per-layer pointers (constant indices only: a dynamically indexed kernarg struct would be copied to scratch)
+  const float* wl[CG_MLP_MAX_HIDDEN];
+  const float* bl[CG_MLP_MAX_HIDDEN];
+  const float* w_head = ml.w_head;
+  const float* b_head = ml.b_head;
+  {
+    const size_t grp = ml.n_groups > 1 ? (size_t)(row0 / ml.rows_per_group) : 0;   // a population of actors: this workgroup's 16 rows belong to ONE of them
+    int kin = G0;
+#pragma unroll
+    for (int l = 0; l < CG_MLP_MAX_HIDDEN; ++l) {
+      wl[l] = nullptr; bl[l] = nullptr;
+      if (l < ml.n_hidden) {
+        wl[l] = ml.w[l] + grp * (size_t)(ml.width[l] >> 4) * kin * 256;
+        bl[l] = ml.b[l] ? ml.b[l] + grp * ml.width[l] : nullptr;
+        kin = ml.width[l] >> 4;
+      }
+    }
+    w_head += grp * (size_t)(n_out_p >> 4) * kin * 256;
+    if (b_head) b_head += grp * n_out;
+  }
+  // What the decode of this wave's row will need from global memory (row id, rng tick, type-map entry per lane) is requested
+  // after layer 0 -- late enough not to delay the observation requests (the memory counters retire in order), early enough
+  // to have landed by the decode.
+  int row = -1, tmap = lane;
+  uint32_t tick = 0;
+  int w_last = ml.width[0];   // width of the last hidden layer
+#pragma unroll
+  for (int l = 1; l < CG_MLP_MAX_HIDDEN; ++l) w_last = l < ml.n_hidden ? ml.width[l] : w_last;
+  const int Gh = w_last >> 4;   // k-groups of the last layer
+  constexpr int n_tiles_out = n_out_p / 16;   // (<= 32: at most two output tiles per wave)
+  const float4* whp = reinterpret_cast<const float4*>(w_head) + lane;
+  float4 hb0[MLP_NB_SMALL], hb1[MLP_NB_SMALL];   // first weight batches of the last layer's tiles `wave` and `wave + 16`
+  // ---------------- layer 0: observation tile from HBM through LDS ----------------
+  {
+    const int N = ml.width[0], n_tiles = N >> 4, ksplit = 16 / n_tiles;
+    const int t = wave % n_tiles, q = wave / n_tiles;
+    const bool active = q < ksplit;
+    const float4* wp = reinterpret_cast<const float4*>(wl[0]) + (size_t)t * G0 * WAVE + lane;
+    const float* a_row = At + r * kt;
+    cg_floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+    // Each thread copies MLP_STAGE * 16 / 1024 / VW vectors of VW floats per stage: vector i = tid + 1024 * hh of the stage is
+    // row i / (MLP_STAGE / VW) of the tile, vector i % (MLP_STAGE / VW) of the stage's columns (consecutive lanes, consecutive
+    // addresses).  VW = 4 / 2 / 1 by what the rows' alignment allows: base address and row stride (a dense attacker view of
+    // 4 M + 6 floats: 2; the batch pads its rows to a multiple of 4 floats).
+    constexpr int VPS = MLP_STAGE / VW, NV = VPS * 16 / MLP_THREADS;   // vectors per row and stage; vectors per thread and stage
+    typedef float vec_t __attribute__((ext_vector_type(VW)));
+    if (vw.role == 0) {
+      // (branch-free requests: a row or column outside the source is read from a valid address and replaced by zeros)
+      size_t rbase[NV];
+      bool rok[NV];
+  #pragma unroll
+      for (int hh = 0; hh < NV; ++hh) {
+        const int sr = row0 + (tid + MLP_THREADS * hh) / VPS;
+        bool ok = sr < src.n;
+        long orow = ok ? sr : 0;
+        if (ml.obs_by_env) {
+          orow = (ok && src.rows) ? src.rows[sr] : orow;
+          ok = ok && orow >= 0 && orow < n_envs;
+          orow = ok ? orow : 0;
+        }
+        rbase[hh] = (dbg & 1) ? 0 : (size_t)orow * ml.obs_stride;
+        rok[hh] = ok;
+      }
+      for (int kc0 = 0; kc0 < K; kc0 += MLP_KT) {
+        const int rem64 = (K - kc0 + 63) & ~63;
+        const int kcur = rem64 < kt ? rem64 : kt;   // columns of this tile that hold data (a multiple of 64)
+        vec_t x[MLP_STAGES][NV];
+        const int gofs = kc0 >> 4, gw = G0 - gofs, gk = kcur >> 4;
+        float4 b0[MLP_NB];
+        // Request order = arrival order (the memory counters retire in order): stage 0 of the tile, the weights of stage 0,
+        // then the rest of the tile.
+  #pragma unroll
+        for (int s = 0; s < MLP_STAGES; ++s) {
+  #pragma unroll
+          for (int hh = 0; hh < NV; ++hh) {
+            const int col = kc0 + MLP_STAGE * s + VW * ((tid + MLP_THREADS * hh) % VPS);
+            const bool in = col < K;   // (a vector that straddles K reads into the row's padding: obs_stride % VW == 0; zeroed below)
+            x[s][hh] = *reinterpret_cast<const vec_t*>(ml.obs + rbase[hh] + (in ? col : 0));   // (zeroed when stored: no wait here)
+          }
+          if (s == 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            mlp_b_load<MLP_NB>(b0, wp, gofs, (dbg & 2) ? 0 : G0 - 1, q, ksplit);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        MSTAMP(1);
+  #pragma unroll
+        for (int s = 0; s < MLP_STAGES; ++s) {
+          if (MLP_STAGE * s < kcur) {   // (uniform)
+            const int gl1 = (MLP_STAGE / 16) * (s + 1);
+            int g1 = gl1 < gk ? gl1 : gk;
+            g1 = active ? (g1 < gw ? g1 : gw) : 0;   // (no groups for an idle wave)
+            const int g0 = (MLP_STAGE / 16) * s + q;
+            float4 b[MLP_NB];
+            if (s == 0) {
+  #pragma unroll
+              for (int u = 0; u < MLP_NB; ++u) b[u] = b0[u];
+            } else
+            mlp_b_load<MLP_NB>(b, wp, gofs, (dbg & 2) ? 0 : G0 - 1, g0, ksplit);   // the stage's first weights fly under the stores and the barrier
+  #pragma unroll
+            for (int hh = 0; hh < NV; ++hh) {
+              const int i = tid + MLP_THREADS * hh, trow = i / VPS, c = MLP_STAGE * s + VW * (i % VPS);
+              vec_t v = x[s][hh];
+  #pragma unroll
+              for (int j = 0; j < VW; ++j) v[j] = (kc0 + c + j < K && rok[hh]) ? v[j] : 0.f;
+              *reinterpret_cast<vec_t*>(At + trow * kt + ((((c >> 2) ^ trow) << 2) | (c & 3))) = v;
+            }
+            __syncthreads();
+            MSTAMP(2 + 2 * s);
+            mlp_mfma_batch<MLP_NB>(acc, a_row, r, kk, b, g0, g1, ksplit);
+            mlp_mfma_groups<MLP_NB>(acc, a_row, r, kk, wp, gofs, G0 - 1, g0 + MLP_NB * ksplit, g1, ksplit);
+            MSTAMP(3 + 2 * s);
+          }
+        }
+        if (kc0 + MLP_KT < K) __syncthreads();   // the next tile overwrites this one
+      }
+    } else {
+      // ---- the role view of the 16 envs, built in LDS from their flag planes ----
+      const int M = vw.M;
+      for (int kc0 = 0; kc0 < K; kc0 += MLP_KT) {
+        const int rem64 = (K - kc0 + 63) & ~63;
+        const int kcur = rem64 < kt ? rem64 : kt;
+        const int c4max = kt >> 2;
+        if (vw.role == 1) {   // defender view: one lane per device PAIR, three 16-byte stores (M even)
+          const int p0 = kc0 / 12;
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const int i = tid + MLP_THREADS * hh, trow = i >> 7, pl = i & 127, p = p0 + pl, sr = row0 + trow;
+            long env = sr < src.n ? (src.rows ? src.rows[sr] : sr) : -1;
+            if (env >= n_envs) env = -1;
+            float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = o0, o2 = o0;
+            if (env >= 0 && 2 * p < M) {
+              const uint32_t f2 = reinterpret_cast<const uint16_t*>(vw.live + (size_t)env * 4 * M)[p];
+              const float2 o = reinterpret_cast<const float2*>(vw.osv)[p], v = reinterpret_cast<const float2*>(vw.ver)[p];
+              const float2 a = vw.ano_dyn ? reinterpret_cast<const float2*>(vw.ano_dyn + (size_t)env * M)[p] : reinterpret_cast<const float2*>(vw.ano)[p];
+              const uint32_t fa = f2 & 0xFFu, fb = f2 >> 8;
+              const bool ha = (fa & CG_F_NYA) || !(fa & CG_F_OWNED), hb = (fb & CG_F_NYA) || !(fb & CG_F_OWNED);
+              const float ka = (float)((fa >> 2) & 1u), kb = (float)((fb >> 2) & 1u);
+              o0 = ha ? make_float4(-1.f, -1.f, -1.f, -1.f) : make_float4(o.x, v.x, -1.f, a.x);
+              o1 = make_float4(ha ? -1.f : ka, ha ? -1.f : 0.f, hb ? -1.f : o.y, hb ? -1.f : v.y);
+              o2 = hb ? make_float4(-1.f, -1.f, -1.f, -1.f) : make_float4(-1.f, a.y, kb, 0.f);
+            }
+            float* arow = At + trow * kt;
+            const int c4 = 3 * pl;
+            if (c4 + 0 < c4max) *reinterpret_cast<float4*>(arow + (((c4 + 0) ^ trow) << 2)) = o0;
+            if (c4 + 1 < c4max) *reinterpret_cast<float4*>(arow + (((c4 + 1) ^ trow) << 2)) = o1;
+            if (c4 + 2 < c4max) *reinterpret_cast<float4*>(arow + (((c4 + 2) ^ trow) << 2)) = o2;
+          }
+        } else {   // attacker view: one 16-byte store per device, then the exploit availability bits
+          const int d0 = kc0 >> 2;
+#pragma unroll
+          for (int hh = 0; hh < 6; ++hh) {
+            const int i = tid + MLP_THREADS * hh, trow = i / (MLP_KT / 4), dl = i - trow * (MLP_KT / 4), d = d0 + dl, sr = row0 + trow;
+            long env = sr < src.n ? (src.rows ? src.rows[sr] : sr) : -1;
+            if (env >= n_envs) env = -1;
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (env >= 0) {
+              if (d < M) {
+                const uint32_t f = vw.live[(size_t)env * 4 * M + d];
+                const bool vis = (f & CG_F_KNOWN) && !(f & CG_F_NYA) && (f & CG_F_OWNED);
+                o = vis ? make_float4(vw.osv[d], vw.ver[d], (float)(f & 1u), 1.f) : make_float4(-1.f, -1.f, -1.f, -1.f);
+              } else {
+                const int e0 = 4 * (d - M);   // MaxExploits availability bits (CyberDefenseEnv.py:226-233)
+                o.x = (e0 + 0 < vw.max_exploits && e0 + 0 < vw.X) ? 1.f : 0.f; o.y = (e0 + 1 < vw.max_exploits && e0 + 1 < vw.X) ? 1.f : 0.f;
+                o.z = (e0 + 2 < vw.max_exploits && e0 + 2 < vw.X) ? 1.f : 0.f; o.w = (e0 + 3 < vw.max_exploits && e0 + 3 < vw.X) ? 1.f : 0.f;
+              }
+            }
+            if (dl < c4max) *reinterpret_cast<float4*>(At + trow * kt + ((dl ^ trow) << 2)) = o;
+          }
+        }
+        __syncthreads();
+        MSTAMP(2);
+        const int gofs = kc0 >> 4, gw = G0 - gofs, gk = kcur >> 4;
+        const int g1 = active ? (gk < gw ? gk : gw) : 0;
+        mlp_mfma_groups<MLP_NB>(acc, a_row, r, kk, wp, gofs, G0 - 1, q, g1, ksplit);
+        MSTAMP(7);
+        if (kc0 + MLP_KT < K) __syncthreads();   // the next tile overwrites this one
+      }
+    }
+    {
+      const int srow = row0 + wave;
+      row = srow < src.n ? (src.rows ? src.rows[srow] : srow) : -1;
+      if (row >= n_envs) row = -1;
+      if (src.epsilon_thr && row >= 0) tick = (uint32_t)ienv[(size_t)row * CG_I_COUNT + CG_I_RNG_TICK];
+      if (src.type_map && lane < nt) tmap = src.type_map[lane];
+      const int t0 = wave < n_tiles_out ? wave : 0, t1 = wave + 16 < n_tiles_out ? wave + 16 : 0;   // (a tile this wave does not have: any valid address)
+      mlp_b_load<MLP_NB_SMALL>(hb0, whp + (size_t)t0 * Gh * WAVE, 0, Gh - 1, 0, 1);
+      mlp_b_load<MLP_NB_SMALL>(hb1, whp + (size_t)t1 * Gh * WAVE, 0, Gh - 1, 0, 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (active) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) part[(wave << 8) + ((4 * kk + v) << 4) + r] = acc[v];   // D fragment: rows 4 * (lane / 16) + v, column lane % 16
+    }
+    __syncthreads();
+    MSTAMP(8);
+    mlp_finish_hidden(part, bl[0], N, n_tiles, ksplit, hin, hp);
+    __syncthreads();
+    MSTAMP(9);
+  }
+  // ---------------- further hidden layers: A fragments from the hidden tile ----------------
+#pragma unroll
+  for (int l = 1; l < CG_MLP_MAX_HIDDEN; ++l) {
+    if (l < ml.n_hidden) {   // (uniform)
+      const int Gin = ml.width[l - 1] >> 4, N = ml.width[l], n_tiles = N >> 4, ksplit = 16 / n_tiles;
+      const int t = wave % n_tiles, q = wave / n_tiles;
+      if (q < ksplit) {
+        cg_floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+        mlp_mfma_groups<MLP_NB_SMALL>(acc, hin + r * hp, r, kk, reinterpret_cast<const float4*>(wl[l]) + (size_t)t * Gin * WAVE + lane, 0, Gin - 1, q, Gin, ksplit);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) part[(wave << 8) + ((4 * kk + v) << 4) + r] = acc[v];
+      }
+      __syncthreads();
+      mlp_finish_hidden(part, bl[l], N, n_tiles, ksplit, hout, hp);
+      __syncthreads();
+      float* sw = hin; hin = hout; hout = sw;
+    }
+  }
+  if (dbg & 4) return;
+  // ---------------- last layer -> outs [16][n_out_p] ----------------
+  float bias_r[HEAD_OPL];   // (requested here: the loads fly under the last product)
+#pragma unroll
+  for (int i = 0; i < HEAD_OPL; ++i) { const int j = lane + i * WAVE; bias_r[i] = (b_head && j < n_out) ? b_head[j] : 0.f; }
+  {
+    const float* a_row = hin + r * hp;
+    if (wave < n_tiles_out) {
+      cg_floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+      mlp_mfma_batch<MLP_NB_SMALL>(acc, a_row, r, kk, hb0, 0, Gh, 1);
+      mlp_mfma_groups<MLP_NB_SMALL>(acc, a_row, r, kk, whp + (size_t)wave * Gh * WAVE, 0, Gh - 1, MLP_NB_SMALL, Gh, 1);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) outs[(4 * kk + v) * n_out_p + wave * 16 + r] = acc[v];
+    }
+    if (wave + 16 < n_tiles_out) {
+      cg_floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+      mlp_mfma_batch<MLP_NB_SMALL>(acc, a_row, r, kk, hb1, 0, Gh, 1);
+      mlp_mfma_groups<MLP_NB_SMALL>(acc, a_row, r, kk, whp + (size_t)(wave + 16) * Gh * WAVE, 0, Gh - 1, MLP_NB_SMALL, Gh, 1);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) outs[(4 * kk + v) * n_out_p + (wave + 16) * 16 + r] = acc[v];
+    }
+  }
+  __syncthreads();
+  MSTAMP(10);
+  if (row < 0) return;
+  head_decode_row<HEAD_OPL>(outs + wave * n_out_p, bias_r, ml.tanh_out, row, tick, tmap, src, dst, lane, seed, env_id_base);
+  MSTAMP(11);
+#undef MSTAMP
+}

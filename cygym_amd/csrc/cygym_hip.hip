@@ -144,6 +144,7 @@ int cygym_sizeof(int32_t which) {
     case 5: return (int)sizeof(cygym_action_rows);
     case 6: return (int)sizeof(cygym_action_vectors);
     case 7: return (int)sizeof(cygym_actor_head);
+    case 8: return (int)sizeof(cygym_actor_mlp);
     default: return -1;
   }
 }
@@ -673,6 +674,63 @@ int cygym_actor_head_decode(cygym_handle* h, const cygym_actor_head* head, const
   int64_t base = h->c.env_id_base;
   void* args[] = {(void*)head, (void*)src, (void*)dst, &n_envs, &ienv, &seed, &base};
   HIPCHK(h, hipLaunchKernel(k, dim3((src->n + rows_per_wg - 1) / rows_per_wg), dim3(16 * WAVE), args, lds, (hipStream_t)stream));
+  HIPCHK(h, hipGetLastError());
+  return CYGYM_OK;
+}
+
+int cygym_actor_mlp_decode(cygym_handle* h, const cygym_actor_mlp* mlp, const cygym_action_vectors* src, const cygym_actions* dst,
+                           void* stream) {
+  if (!h) return fail(h, CYGYM_EINVAL, "cygym_actor_mlp_decode: null handle%s", "");
+  if (!mlp || !src || !dst || (!mlp->obs && !mlp->obs_role) || !mlp->w_head) return fail(h, CYGYM_EINVAL, "cygym_actor_mlp_decode: null source pointer%s", "");
+  if (!dst->atype || !dst->n_exploit || !dst->exploit || !dst->app || !dst->dev_cnt || !dst->dev_idx || dst->max_groups < 1 ||
+      dst->max_devs < 1)
+    return fail(h, CYGYM_EINVAL, "cygym_actor_mlp_decode: bad destination%s", "");
+  if (src->n_types < 0 || src->n_exploits < 0 || src->n_apps < 0 || src->n_devices != h->t.M || mlp->K < 1 || (!mlp->obs_role && mlp->obs_stride < mlp->K))
+    return fail(h, CYGYM_EINVAL, "cygym_actor_mlp_decode: bad layout%s", "");
+  if (mlp->obs_role) {
+    if (!h->bound) return fail(h, CYGYM_ENOTBOUND, "cygym_actor_mlp_decode: obs_role needs a bound handle%s", "");
+    if (mlp->obs_role < 1 || mlp->obs_role > 2 || (h->t.M & 1) ||
+        mlp->K != (mlp->obs_role == 1 ? 6 * h->t.M : 4 * h->t.M + h->c.max_exploits))
+      return fail(h, CYGYM_EUNSUPPORTED, "cygym_actor_mlp_decode: obs_role 1 / 2 with K = 6 M / 4 M + MaxExploits and an even device count%s", "");
+  }
+  if (mlp->n_hidden < 1 || mlp->n_hidden > CG_MLP_MAX_HIDDEN) return fail(h, CYGYM_EUNSUPPORTED, "cygym_actor_mlp_decode: 1 to 3 hidden layers%s", "");
+  for (int l = 0; l < mlp->n_hidden; ++l) {
+    if (!mlp->w[l]) return fail(h, CYGYM_EINVAL, "cygym_actor_mlp_decode: null weight pointer%s", "");
+    if (mlp->width[l] < 16 || mlp->width[l] > 256 || (mlp->width[l] & 15))
+      return fail(h, CYGYM_EUNSUPPORTED, "cygym_actor_mlp_decode: hidden widths must be multiples of 16 up to 256%s", "");
+  }
+  const long long n_out = (long long)src->n_types + src->n_devices + src->n_exploits + src->n_apps;
+  if (n_out > (long long)HEAD_OPL_MAX * WAVE) return fail(h, CYGYM_EUNSUPPORTED, "cygym_actor_mlp_decode: more than 512 outputs%s", "");
+  if (src->n < 0 || (!src->rows && src->n > h->n_envs)) return fail(h, CYGYM_EINVAL, "cygym_actor_mlp_decode: bad row count%s", "");
+  if (src->epsilon_thr && !h->bound) return fail(h, CYGYM_ENOTBOUND, "cygym_actor_mlp_decode: epsilon > 0 needs a bound handle%s", "");
+  if (mlp->n_groups > 1 && (mlp->rows_per_group < 16 || (mlp->rows_per_group & 15) || (long long)mlp->n_groups * mlp->rows_per_group < src->n))
+    return fail(h, CYGYM_EINVAL, "cygym_actor_mlp_decode: rows_per_group must be a multiple of 16 and the groups must cover the rows%s", "");
+  if (src->n == 0) return CYGYM_OK;
+  HIPCHK(h, hipSetDevice(h->device_id));
+  const int n_out_p = ((int)n_out + 63) & ~63;
+  const MlpPlan pl = mlp_plan(mlp->K, mlp->n_hidden, mlp->width, n_out_p);
+  const size_t lds = (size_t)pl.total * sizeof(float);
+  if (lds > 160 * 1024) return fail(h, CYGYM_EUNSUPPORTED, "cygym_actor_mlp_decode: the layer shapes do not fit in LDS%s", "");
+  // widest vector the observation rows allow (base address and row stride)
+  const uintptr_t al = mlp->obs_role ? 0 : ((uintptr_t)mlp->obs | ((uintptr_t)mlp->obs_stride * 4));   // (K itself may be anything <= obs_stride)
+  const int vw = (al & 15) == 0 ? 4 : (al & 7) == 0 ? 2 : 1;
+  const void* k = nullptr;
+#define CG_MLP_CASE(O) case O: k = vw == 4 ? (const void*)actor_mlp_kernel<O, 4> : vw == 2 ? (const void*)actor_mlp_kernel<O, 2> : (const void*)actor_mlp_kernel<O, 1>; break;
+  switch (n_out_p / WAVE) {
+    CG_MLP_CASE(1) CG_MLP_CASE(2) CG_MLP_CASE(3) CG_MLP_CASE(4) CG_MLP_CASE(5) CG_MLP_CASE(6) CG_MLP_CASE(7)
+    default: k = vw == 4 ? (const void*)actor_mlp_kernel<8, 4> : vw == 2 ? (const void*)actor_mlp_kernel<8, 2> : (const void*)actor_mlp_kernel<8, 1>; break;
+  }
+#undef CG_MLP_CASE
+  HIPCHK(h, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  int n_envs = h->n_envs;
+  const int32_t* ienv = h->b.ienv;
+  uint64_t seed = h->c.seed;
+  int64_t base = h->c.env_id_base;
+  int dbg = getenv("CYGYM_MLP_DEBUG") ? atoi(getenv("CYGYM_MLP_DEBUG")) : 0;
+  unsigned long long* st = h->dbg;   // (diagnostic builds: cygym_set_debug)
+  MlpView view = {h->b.live, h->t.os_val, h->t.version, h->t.anomaly, h->b.anomaly, h->t.M, h->t.X, h->c.max_exploits, mlp->obs_role};
+  void* args[] = {(void*)mlp, (void*)src, (void*)dst, &n_envs, &ienv, &seed, &base, &dbg, &st, &view};
+  HIPCHK(h, hipLaunchKernel(k, dim3((src->n + 15) / 16), dim3(MLP_THREADS), args, lds, (hipStream_t)stream));
   HIPCHK(h, hipGetLastError());
   return CYGYM_OK;
 }

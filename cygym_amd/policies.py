@@ -20,6 +20,8 @@ class ActorPolicy:
         self.net, self.n_types, self.n_exploits, self.n_apps = net, int(n_types), int(n_exploits), int(n_apps)
         self.epsilon = float(epsilon)      # epsilon-greedy action type (do_agent.py:972-973), fused path only
         self.fuse_head = True              # run the last Linear layer inside the decode launch when it fits
+        self.fuse_mlp = True               # ... and the whole network when it is a plain Linear-ReLU stack (cygym_actor_mlp_decode)
+        self.from_state = True             # ... which then builds the role view on chip from the batch's state (no view tensor)
         self.type_map = None if type_map is None else torch.as_tensor(type_map, dtype=torch.int32)
         # what the policy can emit (simulate_grid asks: action 10 needs a detector batch)
         self.action_types = list(range(self.n_types)) if type_map is None else sorted({int(x) for x in self.type_map.tolist()})
@@ -43,10 +45,61 @@ class ActorPolicy:
                     self._head = (type(self.net)(*mods[: -2 if tanh else -1]), last, tanh)
         return self._head
 
+    def _split_mlp(self, M):
+        """(hidden nn.Linear layers, last nn.Linear, tanh?) when the WHOLE actor is a Linear-ReLU stack the fused actor kernel
+        can take (cygym_actor_mlp_decode: 1 to 3 hidden layers, widths multiples of 16 up to 256, <= 512 outputs), else None."""
+        if not hasattr(self, "_mlp"):
+            self._mlp = None
+            head = self._split_head(M)
+            if head is not None:
+                body, last, tanh = head
+                mods = list(body)
+                lins = mods[0::2]
+                if (len(mods) % 2 == 0 and 1 <= len(lins) <= 3 and all(isinstance(m, nn.ReLU) for m in mods[1::2])
+                        and all(isinstance(m, nn.Linear) and m.weight.dtype == torch.float32 and m.out_features % 16 == 0
+                                and 16 <= m.out_features <= 256 for m in lins)):
+                    self._mlp = (lins, last, tanh)
+        return self._mlp
+
+    def _packed(self, batch, M):
+        """Fragment-ordered copies of the actor's weights (batch.pack_linear), redone when a parameter changes."""
+        lins, last, tanh = self._split_mlp(M)
+        ver = tuple((m.weight._version, m.weight.data_ptr(), None if m.bias is None else m.bias._version) for m in lins + [last])
+        if getattr(self, "_pk_ver", None) != ver:
+            self._pk = ([(batch.pack_linear(m.weight), None if m.bias is None else m.bias.detach().contiguous(), m.out_features) for m in lins],
+                        (batch.pack_linear(last.weight, 64), None if last.bias is None else last.bias.detach().contiguous()))
+            self._pk_ver = ver
+        return self._pk
+
+    def fused_mlp(self, batch) -> bool:
+        return bool(self.fuse_head and self.fuse_mlp and hasattr(batch, "actor_mlp_decode") and self._split_mlp(batch.M) is not None)
+
+    def reads_state(self, batch) -> bool:
+        """May the fused actor build its observation on chip from the batch's state (cygym_actor_mlp.obs_role) instead of
+        reading a role-view tensor?  (Then the tick need not write that view.)"""
+        return self.fused_mlp(batch) and self.from_state and batch.M % 2 == 0
+
+    @torch.no_grad()
+    def write_by_env(self, batch, act, rows, obs_all, role=None):
+        """The whole actor + decode + scatter in ONE launch (cygym_actor_mlp_decode), for the envs `rows`: the observation is
+        built on chip from the batch's state when `role` is given and reads_state(batch), else read in place from the batch's
+        role view `obs_all` [N, K]; only when fused_mlp(batch)."""
+        hidden, head = self._packed(batch, batch.M)
+        from_state = role is not None and self.reads_state(batch)
+        batch.actor_mlp_decode(rows, None if from_state else obs_all, hidden, head, self.n_types, self.n_exploits, self.n_apps,
+                               self._map(batch.device), act, epsilon=self.epsilon, tanh=self._split_mlp(batch.M)[2], obs_by_env=True,
+                               obs_role=role if from_state else None)
+
     @torch.no_grad()
     def write(self, batch, act, rows, obs):
-        """Fused path: actor forward, then one decode-and-scatter launch into rows `rows` of the action tensors; when the
-        actor ends in a Linear layer of at most 512 outputs that layer runs inside the decode launch as well."""
+        """Fused path: when the actor is a plain Linear-ReLU stack, ONE launch for the network, the decode and the scatter
+        into rows `rows` of the action tensors (cygym_actor_mlp_decode); otherwise the actor's body in torch, then one
+        decode-and-scatter launch that also runs the last Linear layer when it has at most 512 outputs."""
+        if self.fused_mlp(batch) and obs.dtype == torch.float32 and obs.dim() == 2 and obs.stride(1) == 1:
+            hidden, head_p = self._packed(batch, batch.M)
+            batch.actor_mlp_decode(rows, obs, hidden, head_p, self.n_types, self.n_exploits, self.n_apps, self._map(obs.device), act,
+                                   epsilon=self.epsilon, tanh=self._split_mlp(batch.M)[2])
+            return
         head = self._split_head(batch.M) if (self.fuse_head and hasattr(batch, "actor_head_decode")) else None
         if head is not None:
             body, last, tanh = head
@@ -124,9 +177,43 @@ class ActorPolicyGroup:
             self._cache = (ver, Ws, bs, Wh, bh)
         return self._cache[1:]
 
+    def fused_mlp(self, batch) -> bool:
+        return all(p.fused_mlp(batch) for p in self.policies)
+
+    def _packed_all(self, batch):
+        packs = [p._packed(batch, batch.M) for p in self.policies]
+        ver = tuple(p._pk_ver for p in self.policies)
+        if getattr(self, "_pk_ver", None) != ver:
+            n_h = len(packs[0][0])
+            cat = lambda ts: None if ts[0] is None else torch.cat([t.reshape(-1) for t in ts]).contiguous()  # noqa: E731
+            hidden = [(cat([pk[0][l][0] for pk in packs]), cat([pk[0][l][1] for pk in packs]), packs[0][0][l][2]) for l in range(n_h)]
+            head = (cat([pk[1][0] for pk in packs]), cat([pk[1][1] for pk in packs]))
+            self._pk, self._pk_ver = (hidden, head), ver
+        return self._pk
+
+    def reads_state(self, batch) -> bool:
+        return all(p.reads_state(batch) for p in self.policies)
+
+    @torch.no_grad()
+    def write_by_env(self, batch, act, rows, obs_all, role=None):
+        """All the actors of the population, whole networks + decode + scatter, in ONE launch (observations as in
+        ActorPolicy.write_by_env)."""
+        hidden, head = self._packed_all(batch)
+        p0 = self.policies[0]
+        from_state = role is not None and self.reads_state(batch)
+        batch.actor_mlp_decode(rows, None if from_state else obs_all, hidden, head, self.n_types, self.n_exploits, self.n_apps,
+                               p0._map(batch.device), act, epsilon=self.epsilon, tanh=p0._split_mlp(batch.M)[2],
+                               n_groups=len(self.policies), obs_by_env=True, obs_role=role if from_state else None)
+
     @torch.no_grad()
     def write(self, batch, act, rows, obs):
         S = len(self.policies)
+        if self.fused_mlp(batch) and obs.dtype == torch.float32 and obs.dim() == 2 and obs.stride(1) == 1:
+            hidden, head_p = self._packed_all(batch)
+            p0 = self.policies[0]
+            batch.actor_mlp_decode(rows, obs, hidden, head_p, self.n_types, self.n_exploits, self.n_apps, p0._map(obs.device), act,
+                                   epsilon=self.epsilon, tanh=p0._split_mlp(batch.M)[2], n_groups=S)
+            return
         body, last, tanh = self.policies[0]._split_head(batch.M)
         Ws, bs, Wh, bh = self._stacked(batch)
         x = obs.reshape(S, obs.shape[0] // S, obs.shape[1])

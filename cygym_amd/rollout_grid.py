@@ -301,9 +301,14 @@ def simulate_grid(batch, def_policies, att_policies, n_mc: int, T: int, randomiz
         acts[r]["mode"] = torch.zeros_like(batch.act["mode"])
     batch.act["n_groups"].zero_()
     batch.act["n_exploit"].zero_()
+    # a role whose strategies all build their observation on chip from the state (policies.ActorPolicy.reads_state) needs no
+    # role-view tensor: the tick then does not write one
+    needs_view = {r: not fused or any(not (hasattr(p, "reads_state") and p.reads_state(batch)) for items in plan[r] for p, _, _, _ in items)
+                  for r in ROLES}
     if fused:
         batch.reset_returns()
-        batch.prime_view(HL.DEFENDER)             # the first actor's observation (every later one comes from the tick itself)
+        if needs_view[HL.DEFENDER]:
+            batch.prime_view(HL.DEFENDER)         # the first actor's observation (every later one comes from the tick itself)
     else:
         totals = torch.zeros((N, 2), dtype=torch.float64, device=dev)
         alive = torch.ones(N, dtype=torch.bool, device=dev)
@@ -325,11 +330,14 @@ def simulate_grid(batch, def_policies, att_policies, n_mc: int, T: int, randomiz
         act = acts[role]
         lo, hi = bounds[j]
         mark()
-        obs = batch.role_obs[role] if fused else batch.observe(1 if role == HL.DEFENDER else 2)
+        obs = (batch.role_obs[role] if needs_view[role] else None) if fused else batch.observe(1 if role == HL.DEFENDER else 2)
         mark()
         if t < 4 and t < len(mode_words):
             act["mode"][lo:hi].copy_(mode_words[t][lo:hi])
         for p, r64, r32, sl in plan[role][j]:
+            if fused and hasattr(p, "write_by_env") and p.fused_mlp(batch):
+                p.write_by_env(batch, act, r32, obs, role)      # whole actor + decode + scatter: one launch, no gather
+                continue
             o = obs[sl] if sl is not None else obs.index_select(0, r64)
             if fused and hasattr(p, "write"):
                 p.write(batch, act, r32, o)
@@ -341,7 +349,7 @@ def simulate_grid(batch, def_policies, att_policies, n_mc: int, T: int, randomiz
                     _write_rows(batch, batch.act, r64, a, L)
         mark()
         if fused:
-            batch.step_range(lo, hi - lo, act, view=nxt, full_obs=False, returns=True)
+            batch.step_range(lo, hi - lo, act, view=nxt if needs_view[nxt] else None, full_obs=False, returns=True)
         else:
             batch.act["mode"].copy_(act["mode"])
             _, raw, _, done = batch.step()

@@ -191,7 +191,7 @@ typedef struct cygym_handle cygym_handle;
 
 int cygym_version(void);
 /* sizeof of the ABI structs as this library was compiled (which: 0 cygym_topology, 1 cygym_config, 2 cygym_buffers,
- * 3 cygym_actions, 4 cygym_outputs, 5 cygym_action_rows, 6 cygym_action_vectors, 7 cygym_actor_head; -1 for anything else): lets a
+ * 3 cygym_actions, 4 cygym_outputs, 5 cygym_action_rows, 6 cygym_action_vectors, 7 cygym_actor_head, 8 cygym_actor_mlp; -1 for anything else): lets a
  * binding check its own struct layouts at load time. */
 int cygym_sizeof(int32_t which);
 const char* cygym_last_error(const cygym_handle* h);  /* h may be NULL */
@@ -317,6 +317,42 @@ typedef struct cygym_actor_head {
 } cygym_actor_head;
 int cygym_actor_head_decode(cygym_handle* h, const cygym_actor_head* head, const cygym_action_vectors* layout,
                             const cygym_actions* dst, void* stream);
+
+/* The WHOLE actor network of the reference's policies (do_agent.py:357-370: Linear-ReLU stacks ending in a Linear layer,
+ * optionally tanh) fused with cygym_decode_actions -- ONE launch per acting role and tick of a closed loop: a workgroup owns
+ * 16 observation rows, stages them through LDS, runs every layer on the matrix cores (fp32 in, fp32 accumulate; hidden
+ * activations stay in LDS) and decodes the rows from registers like cygym_actor_head_decode.  Neither the hidden
+ * activations nor the action vectors touch HBM.
+ *   layer l (0 <= l < n_hidden):  x <- relu(x W_l^T + b_l),  width[l] outputs (a multiple of 16, <= 256)
+ *   head:                         v  = act(x W_head^T + b_head),  n_out = n_types + n_devices + n_exploits + n_apps <= 512
+ * Weights are PACKED in the order the matrix-core fragments read them (cygym_amd.batched_env.pack_linear): for a layer
+ * with K inputs and N outputs, [ceil(N / 16)][ceil(K / 16)][64][4] floats with
+ *   packed[t][g][lane][i] = W[16 t + lane % 16][16 g + 4 (lane / 16) + i]      (W = nn.Linear.weight [N][K]; 0 outside)
+ * -- the head's N rounded up to a multiple of 64.  K of layer 0 is the observation width; K of layer l is width[l-1]. */
+#define CG_MLP_MAX_HIDDEN 3
+typedef struct cygym_actor_mlp {
+  const float* obs;        /* [n][obs_stride] role observations (or, with obs_by_env, [n_envs][obs_stride] indexed by env id) */
+  const float* w[CG_MLP_MAX_HIDDEN];   /* packed weights of the hidden layers                                            */
+  const float* b[CG_MLP_MAX_HIDDEN];   /* [width[l]] or NULL                                                             */
+  const float* w_head;     /* packed weights of the last layer                                                           */
+  const float* b_head;     /* [n_out] or NULL                                                                            */
+  int32_t obs_stride, K;   /* floats per observation row; observation width (K <= obs_stride)                            */
+  int32_t n_hidden;        /* 1 .. CG_MLP_MAX_HIDDEN                                                                     */
+  int32_t width[CG_MLP_MAX_HIDDEN];
+  int32_t tanh_out;
+  int32_t obs_by_env;      /* 0: observation of source row r is obs[r];  1: obs[rows[r]] (rows of cygym_action_vectors:
+                              the policy reads the batch's role-view tensor in place, no gather)                         */
+  int32_t obs_role;        /* 0: read `obs`.  1 / 2: `obs` is not read -- the defender / attacker view of env rows[r] (or r) is built
+                              on chip from the handle's BOUND state (flag plane + static columns; CyberDefenseEnv.py:194-257), 256
+                              bytes per env instead of a 6 KB view, and the tick need not write role views at all.  K must be
+                              6 M resp. 4 M + MaxExploits, M even.                                                        */
+  int32_t reserved;
+  /* A population of same-shaped actors in one launch, as in cygym_actor_head: source row r belongs to actor
+   * r / rows_per_group; every packed matrix / bias of actor a follows that of actor a - 1 contiguously. */
+  int32_t n_groups, rows_per_group;
+} cygym_actor_mlp;
+int cygym_actor_mlp_decode(cygym_handle* h, const cygym_actor_mlp* mlp, const cygym_action_vectors* layout,
+                           const cygym_actions* dst, void* stream);
 
 /* Replaces: Detector.train(logs) for a batch (CDSimulator.py:688-695: IsolationForest(n_estimators=2, max_samples=256).fit
  * on the [from_device, to_device] pairs of the last <= 2000 log entries, volt_typhoon_env.py:955-961) -- HOST memory in,

@@ -342,10 +342,129 @@ def test_actor_head_kernel_equals_linear_plus_decode():
         env.close()
 
 
+def test_actor_mlp_kernel_equals_torch_forward_plus_decode():
+    """cygym_actor_mlp_decode (the whole Linear-ReLU stack + last layer + decode in ONE launch, matrix cores, observation
+    tile through LDS) against the torch forward followed by cygym_decode_actions: exact on integer-valued weights -- one to
+    three hidden layers, observation widths that are one stage, several stages, several tiles and not a multiple of 16,
+    16-, 8- and 4-byte aligned rows (the three copy variants), rows read in place by env id, and a population of actors."""
+    from cygym_amd.batched_env import BatchedCyberDefenseEnv
+    from cygym_amd.topology import make_topology
+    dev = "cuda:0"
+    #       M   widths          K     stride  n_types n_apps  by_env  groups
+    cases = ((256, (64,),         1536, 1536,   11,     4,      True,   1),
+             (256, (64,),         1030, 1030,   3,      0,      True,   1),      # attacker view: 8-byte aligned rows
+             (64,  (256, 256),    384,  388,    14,     2,      False,  1),
+             (37,  (48, 32, 16),  229,  229,    5,      7,      False,  1),      # odd width and stride: dword copies; 3 tiles of 16
+             (64,  (128,),        3400, 3400,   4,      0,      False,  1),      # three observation tiles, the last one partial
+             (256, (64, 32),      1536, 1536,   9,      3,      True,   3))
+    for M, widths, K, stride, n_types, n_apps, by_env, S_ in cases:
+        topo, init, ck = make_topology(M, 1 if M != 64 else 4, seed=2, n_active=max(8, M - 8))
+        cfg = abi.EnvConfig(seed=2, **ck)
+        N, X = 208, cfg.max_exploits
+        env = BatchedCyberDefenseEnv(topo, cfg, N, init, device=dev, max_groups=1, max_devs=M)
+        other = {k: v.clone() for k, v in env.act.items()}
+        n_out = n_types + M + X + n_apps
+        g = torch.Generator().manual_seed(M + K)
+        obs = torch.randint(-1, 3, (N, stride), generator=g).float().to(dev)[:, :K]
+        n = 144 if S_ > 1 else 150
+        rows = torch.randperm(N, generator=g)[:n].sort().values.to(dev)
+        tm = torch.arange(n_types, dtype=torch.int32, device=dev) + 1
+        actors = []
+        for a in range(S_):
+            Ws, bs, d = [], [], K
+            for w in widths:
+                Ws.append(torch.randint(-1, 2, (w, d), generator=g).float().to(dev))
+                bs.append(torch.randint(-3, 4, (w,), generator=g).float().to(dev))
+                d = w
+            Wh = (torch.randint(-1, 2, (n_out, d), generator=g) * 16).float().to(dev)
+            bh = (torch.arange(n_out) - n_out // 3 + a).float().to(dev)
+            actors.append((Ws, bs, Wh, bh))
+        cat = lambda ts: torch.cat([t.reshape(-1) for t in ts]).contiguous()  # noqa: E731
+        hidden = [(cat([env.pack_linear(a[0][l]) for a in actors]), cat([a[1][l] for a in actors]), widths[l]) for l in range(len(widths))]
+        head = (cat([env.pack_linear(a[2], 64) for a in actors]), cat([a[3] for a in actors]))
+        src = obs if by_env else obs.index_select(0, rows.long())
+        env.actor_mlp_decode(rows, src, hidden, head, n_types, X, n_apps, tm, epsilon=0.3, n_groups=S_, obs_by_env=by_env)
+        x_all = obs.index_select(0, rows.long())
+        vecs = []
+        for a, (Ws, bs, Wh, bh) in enumerate(actors):
+            x = x_all[a * (n // S_):(a + 1) * (n // S_)]
+            for W, b in zip(Ws, bs):
+                x = torch.relu(torch.addmm(b, x, W.t()))
+            vecs.append(torch.addmm(bh, x, Wh.t()))
+        env.decode_actions(rows, torch.cat(vecs), n_types, X, n_apps, tm, act=other, epsilon=0.3)
+        for k in other:
+            assert torch.equal(env.act[k], other[k]), f"M={M} widths={widths} K={K}: {k}"
+        assert int(env.act["dev_cnt"][rows.long(), 0].max()) > 0
+        # float weights + tanh: compare with torch (float64) on the rows whose decisions are clear
+        if S_ == 1:
+            Ws, bs, d = [], [], K
+            for w in widths:
+                Ws.append(torch.randn((w, d), generator=g).to(dev) / d ** 0.5)
+                bs.append(torch.randn((w,), generator=g).to(dev) * 0.1)
+                d = w
+            Wf = torch.randn((n_out, d), generator=g).to(dev) / d ** 0.5
+            bf = torch.randn((n_out,), generator=g).to(dev) * 0.1
+            hidden = [(env.pack_linear(W), b, w) for W, b, w in zip(Ws, bs, widths)]
+            env.actor_mlp_decode(None, obs.contiguous() if not by_env else obs, hidden, (env.pack_linear(Wf, 64), bf), n_types, X, n_apps, None, tanh=True)
+            x = obs.double()
+            for W, b in zip(Ws, bs):
+                x = torch.relu(torch.addmm(b.double(), x, W.double().t()))
+            v = torch.tanh(torch.addmm(bf.double(), x, Wf.double().t()))
+            top2 = torch.topk(v[:, :n_types], 2, dim=1).values
+            clear = (top2[:, 0] - top2[:, 1]) > 1e-4
+            assert clear.sum() > N // 2
+            assert torch.equal(env.act["atype"][clear, 0], torch.argmax(v[:, :n_types], dim=1).to(torch.int32)[clear])
+            dv = v[:, n_types:n_types + M]
+            sure = (dv.abs() > 1e-4).all(dim=1)
+            assert torch.equal(env.act["dev_cnt"][sure, 0], (dv > 0).sum(dim=1).to(torch.int32)[sure]) and sure.sum() > N // 4
+        env.close()
+
+
+def test_actor_mlp_builds_the_role_view_on_chip_from_the_state():
+    """cygym_actor_mlp.obs_role: the fused actor builds the defender / attacker view of its 16 envs in LDS from the flag plane
+    and the static columns instead of reading a view tensor -- same actions as the same actor run on cygym_observe's view
+    (integer weights: exact), at 64 / 256 devices (one tile) and 400 (two tiles, the second one partial), also with rows
+    given by env id and with the per-env anomaly plane of the slow-scan mode."""
+    from cygym_amd.batched_env import BatchedCyberDefenseEnv
+    from cygym_amd.topology import make_topology
+    dev = "cuda:0"
+    for M, N, slow in ((256, 203, False), (64, 96, True), (400, 40, False)):
+        topo, init, ck = make_topology(M, 1 if M != 64 else 4, seed=5, n_active=M - 6)
+        cfg = abi.EnvConfig(seed=5, **({**ck, "fast_scan": 0} if slow else ck))
+        env = BatchedCyberDefenseEnv(topo, cfg, N, init, device=dev, max_groups=1, max_devs=max(4, M // 8), **({"detector": True} if slow else {}))
+        env.randomize()
+        for t in range(6):
+            env.gen_actions(t); env.step()              # flags, known / not-yet-added bits and (slow scan) anomaly scores move
+        X = cfg.max_exploits
+        g = torch.Generator().manual_seed(M)
+        for role, code, n_types, n_apps in (("defender", 1, 12, 3), ("attacker", 2, 3, 0)):
+            K = env.role_width(role)
+            n_out = n_types + M + X + n_apps
+            if n_out > 512:
+                continue
+            view = env.observe(code)
+            assert view.shape == (N, K)
+            W1 = torch.randint(-1, 2, (32, K), generator=g).float().to(dev)
+            b1 = torch.randint(-3, 4, (32,), generator=g).float().to(dev)
+            Wh = (torch.randint(-1, 2, (n_out, 32), generator=g) * 16).float().to(dev)
+            bh = (torch.arange(n_out) - n_out // 3).float().to(dev)
+            hidden, head = [(env.pack_linear(W1), b1, 32)], (env.pack_linear(Wh, 64), bh)
+            rows = torch.randperm(N, generator=g)[: N - 7].sort().values.to(dev)
+            a_view = {k: v.clone() for k, v in env.act.items()}
+            a_state = {k: v.clone() for k, v in env.act.items()}
+            env.actor_mlp_decode(rows, view, hidden, head, n_types, X, n_apps, None, act=a_view, epsilon=0.25, obs_by_env=True)
+            env.actor_mlp_decode(rows, None, hidden, head, n_types, X, n_apps, None, act=a_state, epsilon=0.25, obs_role=role)
+            for k in a_view:
+                assert torch.equal(a_view[k], a_state[k]), f"M={M} {role}: {k}"
+            assert int(a_state["dev_cnt"][rows.long(), 0].max()) > 0 and len(torch.unique(a_state["atype"][rows.long(), 0])) > 1
+        env.close()
+
+
 def test_actor_population_is_one_batched_forward_and_one_head_launch():
-    """Strategies that are actor networks of one architecture are evaluated as a population (ActorPolicyGroup: batched GEMMs
-    + ONE cygym_actor_head_decode launch with n_groups) -- same payoffs and final state as the oracle loop, which runs every
-    actor on its own with the torch decode."""
+    """Strategies that are actor networks of one architecture are evaluated as a population (ActorPolicyGroup: ONE
+    cygym_actor_mlp_decode launch with n_groups for the whole networks; with fuse_mlp off, batched GEMMs + ONE
+    cygym_actor_head_decode launch) -- same payoffs and final state as the oracle loop, which runs every actor on its own with
+    the torch decode."""
     from grid_util import int_mlp_actor
     from cygym_amd.batched_env import BatchedCyberDefenseEnv
     from cygym_amd.policies import ActorPolicy
@@ -362,19 +481,32 @@ def test_actor_population_is_one_batched_forward_and_one_head_launch():
     E_def, E_att = simulate_grid(og, *make("cpu"), n_mc, T, randomize=True)
     batch = BatchedCyberDefenseEnv(topo, cfg, N, init, device="cuda:0", max_groups=1, max_devs=M)
     calls = []
-    orig = batch.actor_head_decode
+    orig = batch.actor_mlp_decode
     def spy(*a, **k):
         calls.append(k.get("n_groups", 1))
         return orig(*a, **k)
-    batch.actor_head_decode = spy
+    batch.actor_mlp_decode = spy
     U_def, U_att = simulate_grid(batch, *make("cuda:0"), n_mc, T, randomize=True, graph=True)
-    assert calls and all(g == 2 for g in calls), calls          # one head launch per tick, both actors of the acting role in it
+    assert calls and all(g == 2 for g in calls), calls          # one actor launch per tick, both actors of the acting role in it
     np.testing.assert_allclose(U_def, E_def, rtol=0, atol=1e-9)
     np.testing.assert_allclose(U_att, E_att, rtol=0, atol=1e-9)
     got = batch.state_numpy()
     got["ienv"] = got["ienv"].copy(); got["ienv"][:, S.I_FLAGS] &= ~0x80
     assert not gio.compare_state(got, og.ob.state, "actor population")
     assert len(np.unique(np.round(E_def, 6))) > 2
+    # the same with the body in torch (batched GEMMs) and only the last layer in the decode launch
+    batch.close()
+    batch = BatchedCyberDefenseEnv(topo, cfg, N, init, device="cuda:0", max_groups=1, max_devs=M)
+    D, A = make("cuda:0")
+    for p in D + A:
+        p.fuse_mlp = False
+    heads = []
+    orig_h = batch.actor_head_decode
+    batch.actor_head_decode = lambda *a, **k: (heads.append(k.get("n_groups", 1)), orig_h(*a, **k))[1]
+    U_def, U_att = simulate_grid(batch, D, A, n_mc, T, randomize=True, graph=True)
+    assert heads and all(g == 2 for g in heads), heads
+    np.testing.assert_allclose(U_def, E_def, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(U_att, E_att, rtol=0, atol=1e-9)
     batch.close()
 
 
