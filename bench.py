@@ -396,12 +396,14 @@ def cpu_baseline(topo, init, cfg, M, L, scripts, W, budget_s):
 
 
 def closed_loop_block(D: Dist, per_tick_value, seed, n_per_gpu, M=256, blocks=1, hidden=64):
-    """The closed-loop consumer timed end to end (cygym_amd/rollout_grid.simulate_grid at the `target` size): per tick one
-    actor forward per distinct strategy of the acting role (torch: Linear(obs, hidden)+ReLU as one GEMM; the last Linear
-    layer runs inside the library's decode launch), one fused last-layer + decode-and-scatter launch
-    (cygym_actor_head_decode = do_agent.decode_action for the batch) and one cygym_step launch that also writes the next
-    actor's role view and the episode returns -- the shape of do_agent.py:206-272 / :2035-2073 with the actors evaluated
-    for all cells at once.  Grid = |D| x |A| x n_mc cells = one env each.
+    """The closed-loop consumer timed end to end (cygym_amd/rollout_grid.simulate_grid at the `target` size): per tick ONE
+    actor launch for the acting role (cygym_actor_mlp_decode: the whole Linear-ReLU-Linear network on the matrix cores, its
+    observation built on chip from the envs' flag planes, + decode_action + the scatter into the action tensors = the
+    reference's actor forward and do_agent.decode_action for the batch; a population of same-shaped actors shares the launch)
+    and one cygym_step launch that also adds the episode returns -- the shape of do_agent.py:206-272 / :2035-2073 with the
+    actors evaluated for all cells at once.  Grid = |D| x |A| x n_mc cells = one env each.  `torch_body` times the same loop
+    with the actor's first layer as a torch GEMM on the role view the tick writes and only the last layer in the decode
+    launch (cygym_actor_head_decode): what the fused actor launch replaces.
 
     Workload notes: fixed topology like the rest of the bench (lambda_events = 0, no ownership reshuffle at the start:
     with max_extra_edges = 0 a reshuffled attacker star cannot be re-linked); the actors are randomly initialised, so
@@ -433,8 +435,9 @@ def closed_loop_block(D: Dist, per_tick_value, seed, n_per_gpu, M=256, blocks=1,
             calibrate_device_head(p, batch.observe(role), M, 1.0 / 16.0)
         return Dp, Ap
 
-    out = {"what": "simulate_grid, closed loop: actor forward (torch GEMM) -> cygym_actor_head_decode (last layer + decode + scatter) "
-                   "-> cygym_step (+ next role view, + episode returns) per tick; all tensors on the device; no ownership reshuffle",
+    out = {"what": "simulate_grid, closed loop: cygym_actor_mlp_decode (whole actor on the matrix cores, role view built on chip from the "
+                   "flag planes, + decode + scatter) -> cygym_step (+ episode returns) per tick: 2 launches; all tensors on the device; "
+                   "no ownership reshuffle",
            "envs": n_per_gpu, "devices": M,
            "policy": f"per role: Linear(obs, {hidden})-ReLU-Linear({hidden}, action vector) fp32, random weights, epsilon-greedy types "
                      f"(epsilon = 1), device head calibrated to ~M/16 devices; obs = 6M (defender) / 4M + {X} (attacker) floats",
@@ -468,9 +471,29 @@ def closed_loop_block(D: Dist, per_tick_value, seed, n_per_gpu, M=256, blocks=1,
         simulate_grid(batch, Dp, Ap, n_mc, 60, randomize=False, graph=False, timers=tm)
         rec["eager"]["split_us_per_tick"] = {k: tm[k] / 60 * 1e6 for k in ("observe", "policy+scatter", "step")}
         rec["mean_device_list"] = float(batch.act["dev_cnt"].float().mean())
-        rec["launches_per_tick"] = ("1 GEMM (Linear+ReLU), 1 fused last layer + decode + scatter, 1 cygym_step" if nD * nA == 1 else
-                                    "the acting role's actors as ONE population (same architecture): [row gather on attacker ticks,] 1 batched GEMM, 1 ReLU, "
-                                    "1 fused last layer + decode + scatter with n_groups, 1 cygym_step -- independent of the number of strategies")
+        rec["launches_per_tick"] = ("1 cygym_actor_mlp_decode, 1 cygym_step" if nD * nA == 1 else
+                                    "the acting role's actors as ONE population (same architecture): 1 cygym_actor_mlp_decode with n_groups, "
+                                    "1 cygym_step -- independent of the number of strategies")
+        if nD * nA == 1:      # the loop this replaces: first layer as a torch GEMM on the role view, last layer in the decode launch
+            for p in Dp + Ap:
+                p.fuse_mlp = False
+            simulate_grid(batch, Dp, Ap, n_mc, 16, randomize=False, graph=True)
+            tb = {}
+            for T in (106, 306):
+                best = None
+                for _ in range(3):
+                    tm = {}
+                    D.barrier()
+                    simulate_grid(batch, Dp, Ap, n_mc, T, randomize=False, graph=True, timers=tm)
+                    t = D.max_over_ranks([tm["loop_s"]])[0]
+                    best = t if best is None else min(best, t)
+                tb[T] = best
+            st_tb = (tb[306] - tb[106]) / 200
+            rec["torch_body"] = {"what": "actor body as a torch GEMM (+ReLU epilogue) on the role view written by the tick, last layer + decode in "
+                                         "cygym_actor_head_decode: 3 launches per tick",
+                                 "steady_state": {"value": N * D.world / st_tb, "ms_per_tick": st_tb * 1e3}}
+            for p in Dp + Ap:
+                p.fuse_mlp = True
         rec["frac_of_per_tick_stepping"] = rec["graph"]["steady_state"]["value"] / per_tick_value if per_tick_value else None
         rec["check_unpinned_or_truncated"] = bool(batch.take_status() & (0x200 | abi.DECODE_TRUNCATED))
         out[name] = rec
@@ -479,8 +502,10 @@ def closed_loop_block(D: Dist, per_tick_value, seed, n_per_gpu, M=256, blocks=1,
     out["value"] = out["grid_1x1"]["graph"]["steady_state"]["value"]
     out["frac_of_per_tick_stepping"] = out["grid_1x1"]["frac_of_per_tick_stepping"]
     out["frac_note"] = ("value / per_tick_stepping of this run's synthetic script (one launch per tick).  What the loop adds to a tick at this "
-                        "size: ~13 us hipBLASLt fp32 GEMM [envs x obs] x [obs x hidden], ~9 us fused last layer + decode, ~3 us of "
-                        "graph-node gaps per kernel; the tick kernel itself runs ~22 us here (it also writes the role view)")
+                        "size: the actor launch, ~19-21 us for Linear(obs, 64)-ReLU-Linear(64, action vector) on 4096 rows (fp32 matrix "
+                        "instructions at their issue limit ~6 us + their weight fragments through the vector-memory path ~3 us, not overlapped; "
+                        "view build, layer hand-offs, last layer and the one-wave-per-row decode ~9 us; DESIGN.md section 8), and ~2.5 us of "
+                        "graph-node gap per kernel")
     return out
 
 

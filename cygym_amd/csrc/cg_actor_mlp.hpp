@@ -14,7 +14,7 @@
 //     global_load_dwordx4, 1 KB contiguous per wave.  Every weight is read once per workgroup (from L2).
 //   * Further hidden layers and the last layer read their A fragments from the hidden tile in LDS the same way; the
 //     16 x n_out_p action vectors pass through LDS once to get each row into one wave, which decodes it (head_decode_row).
-constexpr int MLP_NB = 8, MLP_NB_SMALL = 4;   // k-groups per batch of weight requests: layer 0 / the later layers
+constexpr int MLP_NB = 8, MLP_NB_SMALL = 4, MLP_NB_ROLE = 8;   // k-groups per batch of weight requests: layer 0 / the later layers
 constexpr int MLP_KT = 1536, MLP_STAGE = 512, MLP_STAGES = MLP_KT / MLP_STAGE, MLP_THREADS = 16 * WAVE;
 
 // LDS plan (floats), the same arithmetic on both sides of the launch
@@ -60,45 +60,84 @@ __device__ __forceinline__ void mlp_b_load(float4 (&b)[NB], const float4* wp, co
     b[u] = wp[(size_t)(g < gmax ? g : gmax) * WAVE];
   }
 }
+// TWO accumulator chains per wave (the matrix instructions of a k-group alternate between them; summed at the end): a
+// dependent v_mfma_f32_16x16x4_f32 can issue every 40 cycles, an independent one every 32, and the SIMD runs the oldest ready
+// wave -- with one chain per wave the matrix pipe idles a fifth of the time and the waves of a SIMD finish one after another.
+struct MlpAcc {
+  cg_floatx4 c[2];
+  __device__ __forceinline__ void zero() { c[0] = cg_floatx4{0.f, 0.f, 0.f, 0.f}; c[1] = c[0]; }
+  __device__ __forceinline__ cg_floatx4 sum() const { return c[0] + c[1]; }
+};
 template <int NB>
-__device__ __forceinline__ void mlp_mfma_batch(cg_floatx4& acc, const float* a_row, const int r, const int kk, const float4 (&b)[NB],
+__device__ __forceinline__ void mlp_mfma_batch(MlpAcc& acc, const float* a_row, const int r, const int kk, const float4 (&b)[NB],
                                                const int g0, const int g1, const int gstep) {
+  // branch-free: the A fragments of four k-groups are requested from LDS together (a group past the end re-reads group
+  // g1 - 1 and contributes zeros), then their sixteen matrix instructions run back to back
+  constexpr int CH = NB < 4 ? NB : 4;
+  const int gl = g1 > 0 ? g1 - 1 : 0;
 #pragma unroll
-  for (int u = 0; u < NB; ++u) {
-    const int g = g0 + u * gstep;
-    if (g < g1) {   // (scalar branch)
-      const float4 a = *reinterpret_cast<const float4*>(a_row + ((((g << 2) + kk) ^ r) << 2));
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[u].x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[u].y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[u].z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[u].w, acc, 0, 0, 0);
+  for (int c = 0; c < NB; c += CH) {
+    float4 a[CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int g = g0 + (c + u) * gstep, gc = g < gl ? g : gl;
+      a[u] = *reinterpret_cast<const float4*>(a_row + ((((gc << 2) + kk) ^ r) << 2));
+    }
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const bool ok = g0 + (c + u) * gstep < g1;   // (wave-uniform)
+      const float ax = ok ? a[u].x : 0.f, ay = ok ? a[u].y : 0.f, az = ok ? a[u].z : 0.f, aw = ok ? a[u].w : 0.f;
+      acc.c[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax, b[c + u].x, acc.c[0], 0, 0, 0);
+      acc.c[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ay, b[c + u].y, acc.c[1], 0, 0, 0);
+      acc.c[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(az, b[c + u].z, acc.c[0], 0, 0, 0);
+      acc.c[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw, b[c + u].w, acc.c[1], 0, 0, 0);
     }
   }
 }
+// The same over any number of groups, software-pipelined in half batches: while one half batch is multiplied the weights of
+// the next one are in flight (requests past the end re-read the tile's last group and are never used).
 template <int NB>
-__device__ __forceinline__ void mlp_mfma_groups(cg_floatx4& acc, const float* a_row, const int r, const int kk, const float4* wp,
+__device__ __forceinline__ void mlp_mfma_groups(MlpAcc& acc, const float* a_row, const int r, const int kk, const float4* wp,
                                                 const int gofs, const int gmax, const int g0, const int g1, const int gstep) {
+  constexpr int NH = NB / 2;
+  if (g0 >= g1) return;
+  float4 b0[NH], b1[NH];
+  mlp_b_load<NH>(b0, wp, gofs, gmax, g0, gstep);
   for (int g = g0; g < g1; g += NB * gstep) {
-    float4 b[NB];
-    mlp_b_load<NB>(b, wp, gofs, gmax, g, gstep);
-    mlp_mfma_batch<NB>(acc, a_row, r, kk, b, g, g1, gstep);
+    mlp_b_load<NH>(b1, wp, gofs, gmax, g + NH * gstep, gstep);
+    mlp_mfma_batch<NH>(acc, a_row, r, kk, b0, g, g1, gstep);
+    mlp_b_load<NH>(b0, wp, gofs, gmax, g + NB * gstep, gstep);
+    mlp_mfma_batch<NH>(acc, a_row, r, kk, b1, g + NH * gstep, g1, gstep);
   }
 }
 
-// k-slice partial sums of a hidden layer (part[wave][16][16]) -> bias + ReLU -> swizzled hidden tile `out` (pitch hp)
-__device__ __forceinline__ void mlp_finish_hidden(const float* part, const float* bias, const int N, const int n_tiles, const int ksplit,
+// k-slice partial sums of a hidden layer (part[wave][16][16]) -> bias + ReLU -> swizzled hidden tile `out` (pitch hp).
+// A thread owns outputs o = tid, tid + 1024, ... (< 16 N <= 4096); their biases are requested BEFORE the barrier that
+// publishes the partial sums (mlp_bias_prefetch), so the round trip is not part of the chain.
+__device__ __forceinline__ void mlp_bias_prefetch(float (&bv)[4], const float* bias, const int N) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int o = threadIdx.x + MLP_THREADS * i;
+    bv[i] = (bias && o < 16 * N) ? bias[o % N] : 0.f;
+  }
+}
+__device__ __forceinline__ void mlp_finish_hidden(const float* part, const float (&bv)[4], const int N, const int n_tiles, const int ksplit,
                                                   float* out, const int hp) {
-  for (int o = threadIdx.x; o < 16 * N; o += MLP_THREADS) {
-    const int row = o / N, c = o - row * N, t = c >> 4;
-    float s = bias ? bias[c] : 0.f;
-    for (int q = 0; q < ksplit; ++q) s += part[((q * n_tiles + t) << 8) + (row << 4) + (c & 15)];
-    out[row * hp + ((((c >> 2) ^ row) << 2) | (c & 3))] = s > 0.f ? s : 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int o = threadIdx.x + MLP_THREADS * i;
+    if (o < 16 * N) {
+      const int row = o / N, c = o - row * N, t = c >> 4;
+      float s = bv[i];
+      for (int q = 0; q < ksplit; ++q) s += part[((q * n_tiles + t) << 8) + (row << 4) + (c & 15)];
+      out[row * hp + ((((c >> 2) ^ row) << 2) | (c & 3))] = s > 0.f ? s : 0.f;
+    }
   }
 }
 
 template <int HEAD_OPL, int VW>
 __global__ __launch_bounds__(MLP_THREADS) void actor_mlp_kernel(cygym_actor_mlp ml, cygym_action_vectors src, cygym_actions dst, int n_envs,
-                                                                const int32_t* ienv, uint64_t seed, int64_t env_id_base, int dbg, unsigned long long* st, MlpView vw) {
+                                                                const int32_t* ienv, uint64_t seed, int64_t env_id_base, unsigned long long* st, MlpView vw) {
 #ifdef CG_STAMPS
 #define MSTAMP(k) do { if (st && threadIdx.x == 0) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); st[(size_t)blockIdx.x * 16 + (k)] = _t; } } while (0)
 #else
@@ -130,15 +169,15 @@ __global__ __launch_bounds__(MLP_THREADS) void actor_mlp_kernel(cygym_actor_mlp 
     int kin = G0;
 #pragma unroll
     for (int l = 0; l < CG_MLP_MAX_HIDDEN; ++l) {
-      wl[l] = nullptr; bl[l] = nullptr;
-      if (l < ml.n_hidden) {
-        wl[l] = ml.w[l] + grp * (size_t)(ml.width[l] >> 4) * kin * 256;
-        bl[l] = ml.b[l] ? ml.b[l] + grp * ml.width[l] : nullptr;
-        kin = ml.width[l] >> 4;
-      }
+      // (no nullptr constants in these selects: the compiler then keeps the pointers in the global address space -- global_load,
+      //  not flat_load, whose completion cannot be counted in order)
+      const int wd = l < ml.n_hidden ? ml.width[l] : 0;
+      wl[l] = ml.w[l] + grp * (size_t)(wd >> 4) * kin * 256;
+      bl[l] = ml.b[l] + (ml.b[l] ? grp * wd : 0);
+      kin = l < ml.n_hidden ? wd >> 4 : kin;
     }
     w_head += grp * (size_t)(n_out_p >> 4) * kin * 256;
-    if (b_head) b_head += grp * n_out;
+    b_head += b_head ? grp * n_out : 0;
   }
   // What the decode of this wave's row will need from global memory (row id, rng tick, type-map entry per lane) is requested
   // after layer 0 -- late enough not to delay the observation requests (the memory counters retire in order), early enough
@@ -159,7 +198,8 @@ __global__ __launch_bounds__(MLP_THREADS) void actor_mlp_kernel(cygym_actor_mlp 
     const bool active = q < ksplit;
     const float4* wp = reinterpret_cast<const float4*>(wl[0]) + (size_t)t * G0 * WAVE + lane;
     const float* a_row = At + r * kt;
-    cg_floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+    MlpAcc acc;
+    acc.zero();
     // Each thread copies MLP_STAGE * 16 / 1024 / VW vectors of VW floats per stage: vector i = tid + 1024 * hh of the stage is
     // row i / (MLP_STAGE / VW) of the tile, vector i % (MLP_STAGE / VW) of the stage's columns (consecutive lanes, consecutive
     // addresses).  VW = 4 / 2 / 1 by what the rows' alignment allows: base address and row stride (a dense attacker view of
@@ -180,7 +220,7 @@ __global__ __launch_bounds__(MLP_THREADS) void actor_mlp_kernel(cygym_actor_mlp 
           ok = ok && orow >= 0 && orow < n_envs;
           orow = ok ? orow : 0;
         }
-        rbase[hh] = (dbg & 1) ? 0 : (size_t)orow * ml.obs_stride;
+        rbase[hh] = (size_t)orow * ml.obs_stride;
         rok[hh] = ok;
       }
       for (int kc0 = 0; kc0 < K; kc0 += MLP_KT) {
@@ -201,7 +241,7 @@ __global__ __launch_bounds__(MLP_THREADS) void actor_mlp_kernel(cygym_actor_mlp 
           }
           if (s == 0) {
             __builtin_amdgcn_sched_barrier(0);
-            mlp_b_load<MLP_NB>(b0, wp, gofs, (dbg & 2) ? 0 : G0 - 1, q, ksplit);
+            mlp_b_load<MLP_NB>(b0, wp, gofs, G0 - 1, q, ksplit);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -219,7 +259,7 @@ __global__ __launch_bounds__(MLP_THREADS) void actor_mlp_kernel(cygym_actor_mlp 
   #pragma unroll
               for (int u = 0; u < MLP_NB; ++u) b[u] = b0[u];
             } else
-            mlp_b_load<MLP_NB>(b, wp, gofs, (dbg & 2) ? 0 : G0 - 1, g0, ksplit);   // the stage's first weights fly under the stores and the barrier
+            mlp_b_load<MLP_NB>(b, wp, gofs, G0 - 1, g0, ksplit);   // the stage's first weights fly under the stores and the barrier
   #pragma unroll
             for (int hh = 0; hh < NV; ++hh) {
               const int i = tid + MLP_THREADS * hh, trow = i / VPS, c = MLP_STAGE * s + VW * (i % VPS);
@@ -239,6 +279,7 @@ __global__ __launch_bounds__(MLP_THREADS) void actor_mlp_kernel(cygym_actor_mlp 
       }
     } else {
       // ---- the role view of the 16 envs, built in LDS from their flag planes ----
+      MSTAMP(1);
       const int M = vw.M;
       for (int kc0 = 0; kc0 < K; kc0 += MLP_KT) {
         const int rem64 = (K - kc0 + 63) & ~63;
@@ -246,23 +287,32 @@ __global__ __launch_bounds__(MLP_THREADS) void actor_mlp_kernel(cygym_actor_mlp 
         const int c4max = kt >> 2;
         if (vw.role == 1) {   // defender view: one lane per device PAIR, three 16-byte stores (M even)
           const int p0 = kc0 / 12;
+          uint32_t f2[2];
+          float2 o[2], v[2], an[2];
+          bool okp[2];
 #pragma unroll
-          for (int hh = 0; hh < 2; ++hh) {
-            const int i = tid + MLP_THREADS * hh, trow = i >> 7, pl = i & 127, p = p0 + pl, sr = row0 + trow;
+          for (int hh = 0; hh < 2; ++hh) {   // every request of both pairs first (branch-free: clamped addresses), then the arithmetic
+            const int i = tid + MLP_THREADS * hh, trow = i >> 7, p = p0 + (i & 127), sr = row0 + trow;
             long env = sr < src.n ? (src.rows ? src.rows[sr] : sr) : -1;
             if (env >= n_envs) env = -1;
-            float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = o0, o2 = o0;
-            if (env >= 0 && 2 * p < M) {
-              const uint32_t f2 = reinterpret_cast<const uint16_t*>(vw.live + (size_t)env * 4 * M)[p];
-              const float2 o = reinterpret_cast<const float2*>(vw.osv)[p], v = reinterpret_cast<const float2*>(vw.ver)[p];
-              const float2 a = vw.ano_dyn ? reinterpret_cast<const float2*>(vw.ano_dyn + (size_t)env * M)[p] : reinterpret_cast<const float2*>(vw.ano)[p];
-              const uint32_t fa = f2 & 0xFFu, fb = f2 >> 8;
-              const bool ha = (fa & CG_F_NYA) || !(fa & CG_F_OWNED), hb = (fb & CG_F_NYA) || !(fb & CG_F_OWNED);
-              const float ka = (float)((fa >> 2) & 1u), kb = (float)((fb >> 2) & 1u);
-              o0 = ha ? make_float4(-1.f, -1.f, -1.f, -1.f) : make_float4(o.x, v.x, -1.f, a.x);
-              o1 = make_float4(ha ? -1.f : ka, ha ? -1.f : 0.f, hb ? -1.f : o.y, hb ? -1.f : v.y);
-              o2 = hb ? make_float4(-1.f, -1.f, -1.f, -1.f) : make_float4(-1.f, a.y, kb, 0.f);
-            }
+            okp[hh] = env >= 0 && 2 * p < M;
+            const int pc = 2 * p < M ? p : 0;
+            const size_t ec = env >= 0 ? (size_t)env : 0;
+            f2[hh] = reinterpret_cast<const uint16_t*>(vw.live + ec * 4 * M)[pc];
+            o[hh] = reinterpret_cast<const float2*>(vw.osv)[pc];
+            v[hh] = reinterpret_cast<const float2*>(vw.ver)[pc];
+            an[hh] = vw.ano_dyn ? reinterpret_cast<const float2*>(vw.ano_dyn + ec * M)[pc] : reinterpret_cast<const float2*>(vw.ano)[pc];
+          }
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const int i = tid + MLP_THREADS * hh, trow = i >> 7, pl = i & 127;
+            const uint32_t fa = f2[hh] & 0xFFu, fb = f2[hh] >> 8;
+            const bool ha = (fa & CG_F_NYA) || !(fa & CG_F_OWNED), hb = (fb & CG_F_NYA) || !(fb & CG_F_OWNED);
+            const float ka = (float)((fa >> 2) & 1u), kb = (float)((fb >> 2) & 1u);
+            float4 o0 = ha ? make_float4(-1.f, -1.f, -1.f, -1.f) : make_float4(o[hh].x, v[hh].x, -1.f, an[hh].x);
+            float4 o1 = make_float4(ha ? -1.f : ka, ha ? -1.f : 0.f, hb ? -1.f : o[hh].y, hb ? -1.f : v[hh].y);
+            float4 o2 = hb ? make_float4(-1.f, -1.f, -1.f, -1.f) : make_float4(-1.f, an[hh].y, kb, 0.f);
+            if (!okp[hh]) { o0 = make_float4(0.f, 0.f, 0.f, 0.f); o1 = o0; o2 = o0; }
             float* arow = At + trow * kt;
             const int c4 = 3 * pl;
             if (c4 + 0 < c4max) *reinterpret_cast<float4*>(arow + (((c4 + 0) ^ trow) << 2)) = o0;
@@ -271,23 +321,32 @@ __global__ __launch_bounds__(MLP_THREADS) void actor_mlp_kernel(cygym_actor_mlp 
           }
         } else {   // attacker view: one 16-byte store per device, then the exploit availability bits
           const int d0 = kc0 >> 2;
+          uint32_t fl[6];
+          float ov[6], vv[6];
+          int st_[6];   // 0: zeros (no env), 1: device, 2: availability bits
 #pragma unroll
-          for (int hh = 0; hh < 6; ++hh) {
+          for (int hh = 0; hh < 6; ++hh) {   // requests first (clamped addresses), arithmetic after
             const int i = tid + MLP_THREADS * hh, trow = i / (MLP_KT / 4), dl = i - trow * (MLP_KT / 4), d = d0 + dl, sr = row0 + trow;
             long env = sr < src.n ? (src.rows ? src.rows[sr] : sr) : -1;
             if (env >= n_envs) env = -1;
-            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (env >= 0) {
-              if (d < M) {
-                const uint32_t f = vw.live[(size_t)env * 4 * M + d];
-                const bool vis = (f & CG_F_KNOWN) && !(f & CG_F_NYA) && (f & CG_F_OWNED);
-                o = vis ? make_float4(vw.osv[d], vw.ver[d], (float)(f & 1u), 1.f) : make_float4(-1.f, -1.f, -1.f, -1.f);
-              } else {
-                const int e0 = 4 * (d - M);   // MaxExploits availability bits (CyberDefenseEnv.py:226-233)
-                o.x = (e0 + 0 < vw.max_exploits && e0 + 0 < vw.X) ? 1.f : 0.f; o.y = (e0 + 1 < vw.max_exploits && e0 + 1 < vw.X) ? 1.f : 0.f;
-                o.z = (e0 + 2 < vw.max_exploits && e0 + 2 < vw.X) ? 1.f : 0.f; o.w = (e0 + 3 < vw.max_exploits && e0 + 3 < vw.X) ? 1.f : 0.f;
-              }
+            st_[hh] = env < 0 ? 0 : d < M ? 1 : 2;
+            const int dc = d < M ? d : 0;
+            fl[hh] = vw.live[(env >= 0 ? (size_t)env : 0) * 4 * M + dc];
+            ov[hh] = vw.osv[dc];
+            vv[hh] = vw.ver[dc];
+          }
+#pragma unroll
+          for (int hh = 0; hh < 6; ++hh) {
+            const int i = tid + MLP_THREADS * hh, trow = i / (MLP_KT / 4), dl = i - trow * (MLP_KT / 4), d = d0 + dl;
+            const uint32_t f = fl[hh];
+            const bool vis = (f & CG_F_KNOWN) && !(f & CG_F_NYA) && (f & CG_F_OWNED);
+            float4 o = vis ? make_float4(ov[hh], vv[hh], (float)(f & 1u), 1.f) : make_float4(-1.f, -1.f, -1.f, -1.f);
+            if (st_[hh] == 2) {   // MaxExploits availability bits (CyberDefenseEnv.py:226-233)
+              const int e0 = 4 * (d - M);
+              o.x = (e0 + 0 < vw.max_exploits && e0 + 0 < vw.X) ? 1.f : 0.f; o.y = (e0 + 1 < vw.max_exploits && e0 + 1 < vw.X) ? 1.f : 0.f;
+              o.z = (e0 + 2 < vw.max_exploits && e0 + 2 < vw.X) ? 1.f : 0.f; o.w = (e0 + 3 < vw.max_exploits && e0 + 3 < vw.X) ? 1.f : 0.f;
             }
+            if (st_[hh] == 0) o = make_float4(0.f, 0.f, 0.f, 0.f);
             if (dl < c4max) *reinterpret_cast<float4*>(At + trow * kt + ((dl ^ trow) << 2)) = o;
           }
         }
@@ -295,8 +354,11 @@ __global__ __launch_bounds__(MLP_THREADS) void actor_mlp_kernel(cygym_actor_mlp 
         MSTAMP(2);
         const int gofs = kc0 >> 4, gw = G0 - gofs, gk = kcur >> 4;
         const int g1 = active ? (gk < gw ? gk : gw) : 0;
-        mlp_mfma_groups<MLP_NB>(acc, a_row, r, kk, wp, gofs, G0 - 1, q, g1, ksplit);
+        mlp_mfma_groups<MLP_NB_ROLE>(acc, a_row, r, kk, wp, gofs, G0 - 1, q, g1, ksplit);
         MSTAMP(7);
+#ifdef CG_STAMPS
+        if (st && lane == 0 && (wave & 3) == 3) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); st[(size_t)blockIdx.x * 16 + 12 + (wave >> 2)] = _t; }
+#endif
         if (kc0 + MLP_KT < K) __syncthreads();   // the next tile overwrites this one
       }
     }
@@ -312,12 +374,15 @@ __global__ __launch_bounds__(MLP_THREADS) void actor_mlp_kernel(cygym_actor_mlp 
     }
     __builtin_amdgcn_sched_barrier(0);
     if (active) {
+      const cg_floatx4 accs = acc.sum();
 #pragma unroll
-      for (int v = 0; v < 4; ++v) part[(wave << 8) + ((4 * kk + v) << 4) + r] = acc[v];   // D fragment: rows 4 * (lane / 16) + v, column lane % 16
+      for (int v = 0; v < 4; ++v) part[(wave << 8) + ((4 * kk + v) << 4) + r] = accs[v];   // D fragment: rows 4 * (lane / 16) + v, column lane % 16
     }
+    float bv[4];
+    mlp_bias_prefetch(bv, bl[0], N);
     __syncthreads();
     MSTAMP(8);
-    mlp_finish_hidden(part, bl[0], N, n_tiles, ksplit, hin, hp);
+    mlp_finish_hidden(part, bv, N, n_tiles, ksplit, hin, hp);
     __syncthreads();
     MSTAMP(9);
   }
@@ -328,18 +393,21 @@ __global__ __launch_bounds__(MLP_THREADS) void actor_mlp_kernel(cygym_actor_mlp 
       const int Gin = ml.width[l - 1] >> 4, N = ml.width[l], n_tiles = N >> 4, ksplit = 16 / n_tiles;
       const int t = wave % n_tiles, q = wave / n_tiles;
       if (q < ksplit) {
-        cg_floatx4 acc = {0.f, 0.f, 0.f, 0.f};
-        mlp_mfma_groups<MLP_NB_SMALL>(acc, hin + r * hp, r, kk, reinterpret_cast<const float4*>(wl[l]) + (size_t)t * Gin * WAVE + lane, 0, Gin - 1, q, Gin, ksplit);
+        MlpAcc acc4;
+        acc4.zero();
+        mlp_mfma_groups<MLP_NB_SMALL>(acc4, hin + r * hp, r, kk, reinterpret_cast<const float4*>(wl[l]) + (size_t)t * Gin * WAVE + lane, 0, Gin - 1, q, Gin, ksplit);
+        const cg_floatx4 acc = acc4.sum();
 #pragma unroll
         for (int v = 0; v < 4; ++v) part[(wave << 8) + ((4 * kk + v) << 4) + r] = acc[v];
       }
+      float bv[4];
+      mlp_bias_prefetch(bv, bl[l], N);
       __syncthreads();
-      mlp_finish_hidden(part, bl[l], N, n_tiles, ksplit, hout, hp);
+      mlp_finish_hidden(part, bv, N, n_tiles, ksplit, hout, hp);
       __syncthreads();
       float* sw = hin; hin = hout; hout = sw;
     }
   }
-  if (dbg & 4) return;
   // ---------------- last layer -> outs [16][n_out_p] ----------------
   float bias_r[HEAD_OPL];   // (requested here: the loads fly under the last product)
 #pragma unroll
@@ -347,16 +415,20 @@ __global__ __launch_bounds__(MLP_THREADS) void actor_mlp_kernel(cygym_actor_mlp 
   {
     const float* a_row = hin + r * hp;
     if (wave < n_tiles_out) {
-      cg_floatx4 acc = {0.f, 0.f, 0.f, 0.f};
-      mlp_mfma_batch<MLP_NB_SMALL>(acc, a_row, r, kk, hb0, 0, Gh, 1);
-      mlp_mfma_groups<MLP_NB_SMALL>(acc, a_row, r, kk, whp + (size_t)wave * Gh * WAVE, 0, Gh - 1, MLP_NB_SMALL, Gh, 1);
+      MlpAcc acc4;
+      acc4.zero();
+      mlp_mfma_batch<MLP_NB_SMALL>(acc4, a_row, r, kk, hb0, 0, Gh, 1);
+      mlp_mfma_groups<MLP_NB_SMALL>(acc4, a_row, r, kk, whp + (size_t)wave * Gh * WAVE, 0, Gh - 1, MLP_NB_SMALL, Gh, 1);
+      const cg_floatx4 acc = acc4.sum();
 #pragma unroll
       for (int v = 0; v < 4; ++v) outs[(4 * kk + v) * n_out_p + wave * 16 + r] = acc[v];
     }
     if (wave + 16 < n_tiles_out) {
-      cg_floatx4 acc = {0.f, 0.f, 0.f, 0.f};
-      mlp_mfma_batch<MLP_NB_SMALL>(acc, a_row, r, kk, hb1, 0, Gh, 1);
-      mlp_mfma_groups<MLP_NB_SMALL>(acc, a_row, r, kk, whp + (size_t)(wave + 16) * Gh * WAVE, 0, Gh - 1, MLP_NB_SMALL, Gh, 1);
+      MlpAcc acc4;
+      acc4.zero();
+      mlp_mfma_batch<MLP_NB_SMALL>(acc4, a_row, r, kk, hb1, 0, Gh, 1);
+      mlp_mfma_groups<MLP_NB_SMALL>(acc4, a_row, r, kk, whp + (size_t)(wave + 16) * Gh * WAVE, 0, Gh - 1, MLP_NB_SMALL, Gh, 1);
+      const cg_floatx4 acc = acc4.sum();
 #pragma unroll
       for (int v = 0; v < 4; ++v) outs[(4 * kk + v) * n_out_p + (wave + 16) * 16 + r] = acc[v];
     }

@@ -726,10 +726,9 @@ int cygym_actor_mlp_decode(cygym_handle* h, const cygym_actor_mlp* mlp, const cy
   const int32_t* ienv = h->b.ienv;
   uint64_t seed = h->c.seed;
   int64_t base = h->c.env_id_base;
-  int dbg = getenv("CYGYM_MLP_DEBUG") ? atoi(getenv("CYGYM_MLP_DEBUG")) : 0;
   unsigned long long* st = h->dbg;   // (diagnostic builds: cygym_set_debug)
   MlpView view = {h->b.live, h->t.os_val, h->t.version, h->t.anomaly, h->b.anomaly, h->t.M, h->t.X, h->c.max_exploits, mlp->obs_role};
-  void* args[] = {(void*)mlp, (void*)src, (void*)dst, &n_envs, &ienv, &seed, &base, &dbg, &st, &view};
+  void* args[] = {(void*)mlp, (void*)src, (void*)dst, &n_envs, &ienv, &seed, &base, &st, &view};
   HIPCHK(h, hipLaunchKernel(k, dim3((src->n + 15) / 16), dim3(MLP_THREADS), args, lds, (hipStream_t)stream));
   HIPCHK(h, hipGetLastError());
   return CYGYM_OK;

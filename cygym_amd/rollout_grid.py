@@ -336,7 +336,8 @@ def simulate_grid(batch, def_policies, att_policies, n_mc: int, T: int, randomiz
             act["mode"][lo:hi].copy_(mode_words[t][lo:hi])
         for p, r64, r32, sl in plan[role][j]:
             if fused and hasattr(p, "write_by_env") and p.fused_mlp(batch):
-                p.write_by_env(batch, act, r32, obs, role)      # whole actor + decode + scatter: one launch, no gather
+                whole = sl is not None and sl.start == 0 and sl.stop == N      # (every env, in order: no row-id indirection)
+                p.write_by_env(batch, act, None if whole else r32, obs, role)      # whole actor + decode + scatter: one launch, no gather
                 continue
             o = obs[sl] if sl is not None else obs.index_select(0, r64)
             if fused and hasattr(p, "write"):

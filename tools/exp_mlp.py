@@ -29,12 +29,14 @@ hid = [(env.pack_linear(W1), b1, H)]
 hd = (env.pack_linear(W, 64), b)
 tag = os.environ.get("CYGYM_MLP_DEBUG", "0")
 run(f"[dbg={tag}] defender 1536->64->out", lambda: env.actor_mlp_decode(None, obs, hid, hd, n_types, X, n_apps, tm, epsilon=1.0))
+run(f"[dbg={tag}] defender, view built on chip (obs_role)", lambda: env.actor_mlp_decode(None, None, hid, hd, n_types, X, n_apps, tm, epsilon=1.0, obs_role="defender"))
 Ka = 4 * M + X
 obs_a = torch.randn((N, Ka + 2), generator=g).cuda()[:, :Ka]; Wa = (torch.randn((H, Ka), generator=g) * 0.02).cuda()
 n_out_a = 3 + M + X
 Wha = (torch.randn((n_out_a, H), generator=g) * 0.1).cuda(); bha = torch.zeros(n_out_a).cuda()
 hid_a, hd_a = [(env.pack_linear(Wa), b1, H)], (env.pack_linear(Wha, 64), bha)
 run(f"[dbg={tag}] attacker 1030->64->out (padded stride)", lambda: env.actor_mlp_decode(None, obs_a, hid_a, hd_a, 3, X, 0, None))
+run(f"[dbg={tag}] attacker, view built on chip (obs_role)", lambda: env.actor_mlp_decode(None, None, hid_a, hd_a, 3, X, 0, None, obs_role="attacker"))
 obs_d = obs_a.contiguous()
 run(f"[dbg={tag}] attacker 1030->64->out (dense rows)", lambda: env.actor_mlp_decode(None, obs_d, hid_a, hd_a, 3, X, 0, None))
 if tag == "0":

@@ -27,13 +27,23 @@ W1 = (torch.randn((H, 6 * M), generator=g) * 0.02).cuda(); b1 = torch.zeros(H).c
 W = (torch.randn((n_out, H), generator=g) * 0.1).cuda(); b = (torch.randn((n_out,), generator=g) * 0.1 - 0.3).cuda()
 hid = [(env.pack_linear(W1), b1, H)]
 hd = (env.pack_linear(W, 64), b)
+role = os.environ.get("ROLE")   # "defender": build the view on chip (obs_role)
 for _ in range(5):
-    env.actor_mlp_decode(None, obs, hid, hd, n_types, X, n_apps, tm, epsilon=1.0)
+    env.actor_mlp_decode(None, None if role else obs, hid, hd, n_types, X, n_apps, tm, epsilon=1.0, obs_role=role)
 torch.cuda.synchronize()
 d = dbg.cpu().numpy().astype(np.int64)
 names = ["requests", "stage0 wait+store", "stage0 mfma", "stage1 wait+store", "stage1 mfma", "stage2 wait+store", "stage2 mfma", "partials+sync",
          "finish hidden", "head mfma + sync", "decode"]
 seg = np.diff(d[:, :12], axis=1)
+if role:   # (stamps 0, 2, 7 .. 11 only)
+    print('  end of layer-0 mfma of waves 3, 7, 11, 15 relative to wave 0 (mean):', [int((d[:, 12 + j] - d[:, 7]).mean()) for j in range(4)])
+    d = d[:, [0, 1, 2, 7, 8, 9, 10, 11]]
+    names = ["prologue (kernarg, pointers)", "view fill + sync", "layer-0 mfma (wave 0)", "partials + sync (waits for the slowest wave)", "finish hidden", "head mfma + sync", "decode"]
+    seg = np.diff(d, axis=1)
+    for i, n in enumerate(names):
+        print(f"  {n:46s} {seg[:, i].mean():8.0f} {np.median(seg[:, i]):8.0f} {seg[:, i].max():8d}")
+    print("  total per workgroup   ", int((d[:, -1] - d[:, 0]).mean()))
+    sys.exit(0)
 print("cycles (s_memtime) per phase, mean / p50 / max over workgroups; kernel span:", int(d[:, 11].max() - d[:, 0].min()))
 for i, n in enumerate(names):
     print(f"  {n:22s} {seg[:, i].mean():8.0f} {np.median(seg[:, i]):8.0f} {seg[:, i].max():8d}")
