@@ -32,6 +32,9 @@
 #define CG_MAIN_UNIT 1
 #include "cg_device.hpp"
 #include "cg_iforest.hpp"
+#include <mutex>
+#include <set>
+#include <utility>
 using namespace cygym_k;
 
 // every step_kernel variant lives in one of the instantiation units (cg_inst.hip): declared, not instantiated, here
@@ -721,7 +724,15 @@ int cygym_actor_mlp_decode(cygym_handle* h, const cygym_actor_mlp* mlp, const cy
     default: k = vw == 4 ? (const void*)actor_mlp_kernel<8, 4> : vw == 2 ? (const void*)actor_mlp_kernel<8, 2> : (const void*)actor_mlp_kernel<8, 1>; break;
   }
 #undef CG_MLP_CASE
-  HIPCHK(h, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  {   // raise the kernel's dynamic-LDS limit once per variant and device (not per launch: this sits in a closed loop's tick)
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> raised;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!raised.count({k, h->device_id})) {
+      HIPCHK(h, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      raised.insert({k, h->device_id});
+    }
+  }
   int n_envs = h->n_envs;
   const int32_t* ienv = h->b.ienv;
   uint64_t seed = h->c.seed;
