@@ -20,6 +20,7 @@ ap.add_argument("--no-randomize", action="store_true"); ap.add_argument("--maxde
 ap.add_argument("--eps", type=float, default=1.0); ap.add_argument("--streams", type=int, default=1)
 ap.add_argument("--no-mlp", action="store_true", help="actor body in torch, only the last layer in the decode launch")
 ap.add_argument("--no-state", action="store_true", help="fused actor reads the role-view tensor instead of building the view from the state")
+ap.add_argument("--loop-only", action="store_true", help="stop after the timed loops (profiling: no split, no script-stepping section)")
 a = ap.parse_args()
 nD, nA = (int(x) for x in a.grid.split("x"))
 M = a.M
@@ -41,6 +42,8 @@ for rep in range(3):
     simulate_grid(batch, Dp, Ap, n_mc, a.ticks, graph=not a.eager, timers=tm, streams=a.streams, randomize=not a.no_randomize)
     print(f"grid {a.grid} hidden {a.hidden} mlp={not a.no_mlp} state={not a.no_state} graph={tm['graph']} streams={tm['streams']}: {tm['loop_s'] / a.ticks * 1e6:.1f} us/tick, {N * a.ticks / tm['loop_s']:.3e} env-steps/s, "
           f"mean list {float(batch.act['dev_cnt'].float().mean()):.1f}")
+if a.loop_only:
+    sys.exit(0)
 tm = {"split": True}
 simulate_grid(batch, Dp, Ap, n_mc, 60, timers=tm, randomize=not a.no_randomize)
 print({k: round(tm[k] / 60 * 1e6, 1) for k in ("observe", "policy+scatter", "step")})
