@@ -104,6 +104,12 @@ class ActorMlp(C.Structure):
                 ("rows_per_group", C.c_int32)]
 
 
+class DeviceTypes(C.Structure):
+    _fields_ = [("rows", C.c_void_p), ("types", C.c_void_p), ("visible", C.c_void_p), ("exploit", C.c_void_p), ("app", C.c_void_p),
+                ("n", C.c_int32), ("n_types", C.c_int32), ("noop", C.c_int32), ("role", C.c_int32), ("single_mask", C.c_uint32),
+                ("reserved", C.c_int32), ("status", C.c_void_p)]
+
+
 DECODE_TRUNCATED = 0x10000
 
 BASELINES = {"Nash": 0, "No Defense": 1, "Preset": 2, "No Attack": 3}

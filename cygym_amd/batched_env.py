@@ -579,6 +579,55 @@ class BatchedCyberDefenseEnv:
         _lib.check(self.lib.cygym_actor_mlp_decode(self._h, C.byref(ml), C.byref(src), C.byref(dst), self._stream()),
                    self._h, "cygym_actor_mlp_decode")
 
+    def group_actions(self, rows, types: torch.Tensor, exploit=None, app=None, role: str = "defender", n_types: int | None = None,
+                      noop: int | None = None, single_types=(11, 12), visible: torch.Tensor | None = None, act=None):
+        """The grouping of per-device decisions into `env.step(groups)` (IPPO.py:560-572 / MAPPO.py) for a batch, ONE launch
+        (cygym_group_actions): `types` [n, M] (any integer dtype) = the action type every device sampled; for each type in
+        ascending order except `noop` (default: 8 defender / 3 attacker) the visible devices that sampled it become the group
+        (type, [exploit[r]], ascending ids, app[r]) -- one uniformly random device for a type in `single_types` (the Philox draw
+        addressed by the env's rng tick, site CG_SITE_GROUP_PICK) -- and a row without groups steps [(noop, [0], [], 0)].
+        `visible` [n, M] overrides the role's visibility mask (build_visibility_mask, IPPO.py:74-96), which the kernel
+        otherwise reads off the flag plane.  Writes n_groups and the groups of rows `rows` of `act`; needs max_groups >=
+        the number of groups a row can have and max_devs >= M (else the row is cut and abi.DECODE_TRUNCATED raised)."""
+        act = self.act if act is None else act
+        dst = self.actions_struct(act)
+        if role not in ("defender", "attacker"):
+            raise ValueError("role must be 'attacker' or 'defender'")
+        n_types = (14 if role == "defender" else self.cfg.max_exploits + 3) if n_types is None else int(n_types)
+        noop = (8 if role == "defender" else 3) if noop is None else int(noop)
+        if types.dim() != 2 or int(types.shape[1]) != self.M or types.device != self.device:
+            raise ValueError("types must be an [n, M] integer tensor on the batch's device")
+        t8 = types if (types.dtype == torch.uint8 and types.is_contiguous()) else types.to(torch.uint8).contiguous()
+        n = int(t8.shape[0])
+        src = abi.DeviceTypes()
+        src.types, src.n, src.n_types, src.noop, src.role = t8.data_ptr(), n, n_types, noop, (1 if role == "defender" else 2)
+        src.single_mask = sum(1 << int(t) for t in single_types if 0 <= int(t) < 32)
+        src.status = self.status.data_ptr()
+        keep = [t8]
+
+        def i32(x, what):
+            x = x if (x.dtype == torch.int32 and x.is_contiguous()) else x.to(torch.int32).contiguous()
+            if int(x.numel()) != n or x.device != self.device:
+                raise ValueError(f"{what} must hold one entry per row on the batch's device")
+            keep.append(x)
+            return x.data_ptr()
+
+        if rows is not None:
+            src.rows = i32(rows, "rows")
+        elif n > self.N:
+            raise ValueError("more rows than envs")
+        if exploit is not None:
+            src.exploit = i32(exploit, "exploit")
+        if app is not None:
+            src.app = i32(app, "app")
+        if visible is not None:
+            v8 = visible if (visible.dtype == torch.uint8 and visible.is_contiguous()) else (visible != 0).to(torch.uint8).contiguous()
+            if tuple(v8.shape) != (n, self.M) or v8.device != self.device:
+                raise ValueError("visible must be [n, M] on the batch's device")
+            keep.append(v8)
+            src.visible = v8.data_ptr()
+        _lib.check(self.lib.cygym_group_actions(self._h, C.byref(src), C.byref(dst), self._stream()), self._h, "cygym_group_actions")
+
     def take_status(self) -> int:
         """Read and clear the batch's status word: the OR of CG_E_TOPO_OVF | CG_E_BUSY_SAT | CG_E_DET_PENDING |
         CG_E_UNPINNED over the envs ticked since the last call (one 4-byte device-to-host copy; synchronises)."""

@@ -183,6 +183,73 @@ __global__ void write_actions_kernel(cygym_action_rows src, cygym_actions dst, i
   }
 }
 
+// cygym_group_actions (IPPO.py:560-572 for a batch): one wave per row.  For every action type in ascending order the
+// devices that sampled it are ranked with ballots (ascending id = list order); a single-device type keeps the r-th of
+// them, r uniform from the addressed Philox draw.
+__global__ void group_actions_kernel(cygym_device_types src, cygym_actions dst, int M, int n_envs, const uint8_t* live,
+                                     const int32_t* ienv, uint64_t seed, int64_t env_id_base) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= src.n) return;
+  const int row = src.rows ? src.rows[wave] : wave;
+  if (row < 0 || row >= n_envs) return;
+  const int G = dst.max_groups, L = dst.max_devs;
+  const uint8_t* ty = src.types + (size_t)wave * M;
+  const uint8_t* vis = src.visible ? src.visible + (size_t)wave * M : nullptr;
+  const uint8_t* fl = live + (size_t)row * 4 * M;
+  const uint32_t want = src.role == 2 ? (CG_F_KNOWN | CG_F_OWNED) : CG_F_OWNED;
+  const int ex = src.exploit ? src.exploit[wave] : 0, app = src.app ? src.app[wave] : 0;
+  int16_t* out = const_cast<int16_t*>(dst.dev_idx) + (size_t)row * L;
+  int32_t* o_at = const_cast<int32_t*>(dst.atype) + (size_t)row * G;
+  int32_t* o_ne = const_cast<int32_t*>(dst.n_exploit) + (size_t)row * G;
+  int32_t* o_ex = const_cast<int32_t*>(dst.exploit) + (size_t)row * G * CG_MAX_EXPLOITS;
+  int32_t* o_app = const_cast<int32_t*>(dst.app) + (size_t)row * G;
+  int32_t* o_cnt = const_cast<int32_t*>(dst.dev_cnt) + (size_t)row * G;
+  const uint32_t tick = (uint32_t)ienv[(size_t)row * CG_I_COUNT + CG_I_RNG_TICK];
+  int g = 0, base = 0;
+  bool cut = false;
+  for (int t = 0; t < src.n_types; ++t) {
+    if (t == src.noop) continue;
+    int total = 0;
+    for (int d0 = 0; d0 < M; d0 += WAVE) {
+      const int d = d0 + lane;
+      const bool on = d < M && ty[d] == t && (vis ? vis[d] != 0 : ((fl[d] & (want | CG_F_NYA)) == want));
+      total += __popcll(__ballot(on));
+    }
+    if (total == 0) continue;
+    if (g >= G) { cut = true; break; }
+    int pick = -1;   // single-device type: index of the chosen device among the type's devices
+    if ((src.single_mask >> t) & 1u) {
+      const cg_u32x4 r = cg_philox4x32_10((uint32_t)(env_id_base + row), tick, CG_SITE_GROUP_PICK, (uint32_t)t, (uint32_t)seed, (uint32_t)(seed >> 32));
+      pick = (int)cg_index(r.v[0], (uint32_t)total);
+    }
+    int seen = 0, cnt = 0;
+    for (int d0 = 0; d0 < M; d0 += WAVE) {
+      const int d = d0 + lane;
+      const bool on = d < M && ty[d] == t && (vis ? vis[d] != 0 : ((fl[d] & (want | CG_F_NYA)) == want));
+      const uint64_t m = __ballot(on);
+      const int rank = seen + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      if (on) {
+        const int pos = pick < 0 ? rank : (rank == pick ? 0 : -1);
+        if (pos >= 0) { if (base + pos < L) out[base + pos] = (int16_t)d; }
+      }
+      seen += __popcll(m);
+    }
+    cnt = pick < 0 ? total : 1;
+    if (base + cnt > L) { cnt = L - base; cut = true; }
+    if (lane == 0) { o_at[g] = t; o_ne[g] = 1; o_ex[(size_t)g * CG_MAX_EXPLOITS] = ex; o_app[g] = app; o_cnt[g] = cnt; }
+    base += cnt;
+    ++g;
+  }
+  if (g == 0) {   // [(noop, [0], [], 0)]
+    if (lane == 0) { o_at[0] = src.noop; o_ne[0] = 1; o_ex[0] = 0; o_app[0] = 0; o_cnt[0] = 0; }
+    g = 1;
+  }
+  if (lane == 0) {
+    const_cast<int32_t*>(dst.n_groups)[row] = g;
+    if (cut && src.status) atomicOr(src.status, CG_DECODE_TRUNCATED);
+  }
+}
+
 // cygym_decode_actions (do_agent.py:970-998 for a batch): one wave per row.  argmax = first maximum (np.argmax).
 __device__ __forceinline__ int wave_argmax(const float* v, int n, int lane) {
   float best = -__builtin_inff();

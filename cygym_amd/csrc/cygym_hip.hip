@@ -148,6 +148,7 @@ int cygym_sizeof(int32_t which) {
     case 6: return (int)sizeof(cygym_action_vectors);
     case 7: return (int)sizeof(cygym_actor_head);
     case 8: return (int)sizeof(cygym_actor_mlp);
+    case 9: return (int)sizeof(cygym_device_types);
     default: return -1;
   }
 }
@@ -619,6 +620,24 @@ int cygym_decode_actions(cygym_handle* h, const cygym_action_vectors* src, const
   const int threads = 256, waves_per_block = threads / WAVE;
   hipLaunchKernelGGL(decode_actions_kernel, dim3((src->n + waves_per_block - 1) / waves_per_block), dim3(threads), 0,
                      (hipStream_t)stream, *src, *dst, h->n_envs, h->b.ienv, h->c.seed, h->c.env_id_base);
+  HIPCHK(h, hipGetLastError());
+  return CYGYM_OK;
+}
+
+int cygym_group_actions(cygym_handle* h, const cygym_device_types* src, const cygym_actions* dst, void* stream) {
+  if (!h || !h->bound) return fail(h, CYGYM_ENOTBOUND, "cygym_group_actions: handle not bound%s", "");
+  if (!src || !dst || !src->types) return fail(h, CYGYM_EINVAL, "cygym_group_actions: null source pointer%s", "");
+  if (!dst->n_groups || !dst->atype || !dst->n_exploit || !dst->exploit || !dst->app || !dst->dev_cnt || !dst->dev_idx || dst->max_groups < 1 ||
+      dst->max_devs < 1)
+    return fail(h, CYGYM_EINVAL, "cygym_group_actions: bad destination%s", "");
+  if (src->n_types < 1 || src->n_types > 32 || (!src->visible && src->role != 1 && src->role != 2))
+    return fail(h, CYGYM_EINVAL, "cygym_group_actions: 1 to 32 action types; role 1 or 2 when no visibility mask is given%s", "");
+  if (src->n < 0 || (!src->rows && src->n > h->n_envs)) return fail(h, CYGYM_EINVAL, "cygym_group_actions: bad row count%s", "");
+  if (src->n == 0) return CYGYM_OK;
+  HIPCHK(h, hipSetDevice(h->device_id));
+  const int threads = 256, waves_per_block = threads / WAVE;
+  hipLaunchKernelGGL(group_actions_kernel, dim3((src->n + waves_per_block - 1) / waves_per_block), dim3(threads), 0, (hipStream_t)stream,
+                     *src, *dst, h->t.M, h->n_envs, (const uint8_t*)h->b.live, h->b.ienv, h->c.seed, h->c.env_id_base);
   HIPCHK(h, hipGetLastError());
   return CYGYM_OK;
 }

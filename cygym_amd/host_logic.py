@@ -101,3 +101,20 @@ def encode_into(act: dict, row: int, mode: str, groups, grouped: bool, M: int):
         act["dev_cnt"][row, g] = len(dv)
         act["dev_idx"][row, used: used + len(dv)] = dv
         used += len(dv)
+
+
+def group_actions_np(types, visible, exploit, app, n_types, noop, single_types, picks=None):
+    """numpy restatement of cygym_group_actions for ONE env (IPPO.py:560-572): the list of groups
+    [(type, [exploit], [device ids], app), ...] `env.step(groups)` receives.  `picks[t]` = index of the device a
+    single-device type keeps among its devices (the reference: random.choice(devs); the library: the addressed Philox draw)."""
+    groups = []
+    for t in range(int(n_types)):
+        if t == noop:
+            continue
+        devs = [int(i) for i in np.nonzero((np.asarray(visible) != 0) & (np.asarray(types) == t))[0]]
+        if not devs:
+            continue
+        if t in set(single_types):
+            devs = [devs[int(picks[t]) if picks is not None else 0]]
+        groups.append((t, [int(exploit)], devs, int(app)))
+    return groups or [(int(noop), [0], [], 0)]

@@ -48,6 +48,7 @@ DET_APL_N = 257
  SITE_EVO_ATT, SITE_EVO_PA, SITE_SHUFFLE, SITE_DET_COIN, SITE_LAZY, SITE_DET_FIT) = range(1, 23)
 SITE_ACTGEN = 64
 SITE_EPS_TYPE = 65
+SITE_GROUP_PICK = 66
 
 POISSON_TABLE = 16
 TRI_TABLE = 8

@@ -191,7 +191,7 @@ typedef struct cygym_handle cygym_handle;
 
 int cygym_version(void);
 /* sizeof of the ABI structs as this library was compiled (which: 0 cygym_topology, 1 cygym_config, 2 cygym_buffers,
- * 3 cygym_actions, 4 cygym_outputs, 5 cygym_action_rows, 6 cygym_action_vectors, 7 cygym_actor_head, 8 cygym_actor_mlp; -1 for anything else): lets a
+ * 3 cygym_actions, 4 cygym_outputs, 5 cygym_action_rows, 6 cygym_action_vectors, 7 cygym_actor_head, 8 cygym_actor_mlp, 9 cygym_device_types; -1 for anything else): lets a
  * binding check its own struct layouts at load time. */
 int cygym_sizeof(int32_t which);
 const char* cygym_last_error(const cygym_handle* h);  /* h may be NULL */
@@ -317,6 +317,34 @@ typedef struct cygym_actor_head {
 } cygym_actor_head;
 int cygym_actor_head_decode(cygym_handle* h, const cygym_actor_head* head, const cygym_action_vectors* layout,
                             const cygym_actions* dst, void* stream);
+
+/* Per-device action types of n envs, DEVICE pointers: what the reference's IPPO / MAPPO / HMARL policies sample per decision
+ * (IPPO.py:526-557: one Categorical per device over the role's action types, one exploit index, one app index). */
+typedef struct cygym_device_types {
+  const int32_t* rows;     /* [n] env ids (rows of the action tensors) to write; NULL = rows 0..n-1             */
+  const uint8_t* types;    /* [n][M] sampled action type of every device, 0 .. n_types - 1                      */
+  const uint8_t* visible;  /* [n][M] non-zero = the device takes part, or NULL: the role's visibility mask computed
+                              from the handle's bound flag plane (build_visibility_mask, IPPO.py:74-96: defender =
+                              attacker_owned and not Not_yet_added; attacker = that and Known_to_attacker)      */
+  const int32_t* exploit;  /* [n] exploit index, or NULL = 0                                                    */
+  const int32_t* app;      /* [n] app index, or NULL = 0                                                        */
+  int32_t n, n_types;
+  int32_t noop;            /* the role's no-op type (DEFENDER_NOOP = 8, ATTACKER_NOOP = 3): never a group        */
+  int32_t role;            /* 1 defender, 2 attacker (only read when visible == NULL)                           */
+  uint32_t single_mask;    /* bit t set: type t acts on ONE device -- a uniformly random one of its devices
+                              (SINGLE_DEVICE_TYPES = {11, 12}, IPPO.py:27, :566-567), drawn with the Philox draw
+                              addressed (env, the env's current rng tick, CG_SITE_GROUP_PICK, t)                 */
+  int32_t reserved;
+  uint32_t* status;        /* optional, ONE word: CG_DECODE_TRUNCATED is OR-ed in when a row needs more groups than
+                              max_groups or more list entries than max_devs (the groups are cut there)          */
+} cygym_device_types;
+
+/* Replaces: the grouping of per-device decisions into env.step(groups) (IPPO.py:560-572, MAPPO.py the same) for a
+ * batch: for every action type t in ascending order except the no-op, the visible devices that sampled t form the group
+ * (t, [exploit], ascending device ids, app) -- one device for a single-device type -- and a row without any group steps
+ * [(noop, [0], [], 0)].  Writes n_groups and the groups' atype / n_exploit (= 1) / exploit[.][0] / app / dev_cnt and the
+ * concatenated device lists of the rows (mode is not touched).  n_types <= 32; needs a bound handle. */
+int cygym_group_actions(cygym_handle* h, const cygym_device_types* src, const cygym_actions* dst, void* stream);
 
 /* The WHOLE actor network of the reference's policies (do_agent.py:357-370: Linear-ReLU stacks ending in a Linear layer,
  * optionally tanh) fused with cygym_decode_actions -- ONE launch per acting role and tick of a closed loop: a workgroup owns

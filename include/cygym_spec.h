@@ -184,9 +184,12 @@ enum {
   CG_SITE_LAZY,              /* CDSimulator.py:328 (no observable effect)             */
   CG_SITE_DET_FIT,           /* CDSimulator.py:694 IsolationForest.fit: seed of the numpy stream it draws from */
   CG_SITE_ACTGEN = 64,       /* synthetic action script of bench.py (not reference)   */
-  CG_SITE_EPS_TYPE = 65      /* do_agent.py:972-973 epsilon-greedy action type of decode_action: word 0 is the coin
+  CG_SITE_EPS_TYPE = 65,     /* do_agent.py:972-973 epsilon-greedy action type of decode_action: word 0 is the coin
                                 (u < ceil(eps * 2^32)), word 1 the uniform type index.  Addressed by the env's own rng
                                 tick, read when the action is decoded (the tick that will execute it)            */
+  CG_SITE_GROUP_PICK = 66    /* IPPO.py:566-567 / MAPPO.py: random.choice(devs) of a single-device action type when
+                                per-device types are grouped (cygym_group_actions): a = action type; addressed by the
+                                env's rng tick like CG_SITE_EPS_TYPE                                              */
 };
 
 /* ---- Philox4x32-10 (Salmon et al., SC'11), counter-based ----
