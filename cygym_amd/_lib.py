@@ -16,7 +16,7 @@ SO = os.environ.get("CYGYM_SO") or os.path.join(HERE, "libcygym_hip.so")   # CYG
 EXPORTS = [
     "cygym_version", "cygym_sizeof", "cygym_last_error", "cygym_create", "cygym_destroy", "cygym_set_config", "cygym_bind", "cygym_derive",
     "cygym_set_snapshot", "cygym_reset", "cygym_randomize", "cygym_step", "cygym_step_range", "cygym_rollout", "cygym_observe",
-    "cygym_gen_actions", "cygym_write_actions", "cygym_decode_actions", "cygym_actor_head_decode", "cygym_actor_mlp_decode", "cygym_group_actions", "cygym_fit_forests",
+    "cygym_gen_actions", "cygym_write_actions", "cygym_decode_actions", "cygym_actor_head_decode", "cygym_actor_mlp_decode", "cygym_group_actions", "cygym_sample_group_actions", "cygym_fit_forests",
     "cygym_timer_start", "cygym_timer_stop",
 ]
 
@@ -60,6 +60,7 @@ def load():
     L.cygym_actor_head_decode.argtypes = [H, C.POINTER(abi.ActorHead), C.POINTER(abi.ActionVectors), C.POINTER(abi.Actions), C.c_void_p]
     L.cygym_actor_mlp_decode.argtypes = [H, C.POINTER(abi.ActorMlp), C.POINTER(abi.ActionVectors), C.POINTER(abi.Actions), C.c_void_p]
     L.cygym_group_actions.argtypes = [H, C.POINTER(abi.DeviceTypes), C.POINTER(abi.Actions), C.c_void_p]
+    L.cygym_sample_group_actions.argtypes = [H, C.POINTER(abi.DeviceLogits), C.POINTER(abi.Actions), C.c_void_p]
     L.cygym_fit_forests.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     L.cygym_gen_actions.argtypes = [H, C.c_int32] + [C.c_void_p] * 8 + [C.c_int32, C.c_void_p]
     L.cygym_timer_start.argtypes = [H, C.c_void_p]
@@ -67,7 +68,7 @@ def load():
     if L.cygym_version() != abi.ABI_VERSION:
         raise CygymError(f"ABI mismatch: library {L.cygym_version()} vs python {abi.ABI_VERSION}")
     L.cygym_sizeof.argtypes = [C.c_int32]
-    for which, st in enumerate((abi.Topology, abi.Config, abi.Buffers, abi.Actions, abi.Outputs, abi.ActionRows, abi.ActionVectors, abi.ActorHead, abi.ActorMlp, abi.DeviceTypes)):
+    for which, st in enumerate((abi.Topology, abi.Config, abi.Buffers, abi.Actions, abi.Outputs, abi.ActionRows, abi.ActionVectors, abi.ActorHead, abi.ActorMlp, abi.DeviceTypes, abi.DeviceLogits)):
         if L.cygym_sizeof(which) != C.sizeof(st):
             raise CygymError(f"ABI struct {st.__name__}: library {L.cygym_sizeof(which)} bytes vs python {C.sizeof(st)}")
     _lib = L

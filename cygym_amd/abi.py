@@ -110,6 +110,13 @@ class DeviceTypes(C.Structure):
                 ("reserved", C.c_int32), ("status", C.c_void_p)]
 
 
+class DeviceLogits(C.Structure):
+    _fields_ = [("rows", C.c_void_p), ("logits", C.c_void_p), ("exp_logits", C.c_void_p), ("app_logits", C.c_void_p),
+                ("types_out", C.c_void_p), ("exp_out", C.c_void_p), ("app_out", C.c_void_p), ("logp_out", C.c_void_p),
+                ("n", C.c_int32), ("n_types", C.c_int32), ("n_exp", C.c_int32), ("n_app", C.c_int32), ("noop", C.c_int32),
+                ("role", C.c_int32), ("single_mask", C.c_uint32), ("greedy", C.c_int32), ("status", C.c_void_p)]
+
+
 DECODE_TRUNCATED = 0x10000
 
 BASELINES = {"Nash": 0, "No Defense": 1, "Preset": 2, "No Attack": 3}

@@ -628,6 +628,52 @@ class BatchedCyberDefenseEnv:
             src.visible = v8.data_ptr()
         _lib.check(self.lib.cygym_group_actions(self._h, C.byref(src), C.byref(dst), self._stream()), self._h, "cygym_group_actions")
 
+    def sample_group_actions(self, rows, logits: torch.Tensor, exp_logits=None, app_logits=None, role: str = "defender", noop: int | None = None,
+                             single_types=(11, 12), greedy: bool = False, act=None):
+        """Sampling AND grouping of a per-device actor's decisions in ONE launch (cygym_sample_group_actions; IPPO.py:524-572 for
+        a batch): `logits` [n, M, K] float32 -> one Categorical sample per VISIBLE device (the role's mask, read off the flag
+        plane), one for the exploit (`exp_logits` [n, E]) and one for the app (`app_logits` [n, A]), the sum of their
+        log-probabilities, and the groups written into rows `rows` of `act` like group_actions.  Samples walk the inverse CDF
+        with addressed Philox draws (env, rng tick, CG_SITE_SAMPLE, device / head); greedy=True takes the arg-max instead.
+        Returns (types [n, M] uint8 -- 0 where invisible --, exploit [n] int32, app [n] int32, logp [n] float32)."""
+        act = self.act if act is None else act
+        dst = self.actions_struct(act)
+        if role not in ("defender", "attacker"):
+            raise ValueError("role must be 'attacker' or 'defender'")
+        ok = lambda t: t.dtype == torch.float32 and t.device == self.device and t.is_contiguous()  # noqa: E731
+        if not ok(logits) or logits.dim() != 3 or int(logits.shape[1]) != self.M or not 1 <= int(logits.shape[2]) <= 32:
+            raise ValueError("logits must be a contiguous [n, M, K <= 32] float32 tensor on the batch's device")
+        n, K = int(logits.shape[0]), int(logits.shape[2])
+        src = abi.DeviceLogits()
+        types = torch.empty((n, self.M), dtype=torch.uint8, device=self.device)
+        exp_o = torch.empty((n,), dtype=torch.int32, device=self.device)
+        app_o = torch.empty((n,), dtype=torch.int32, device=self.device)
+        logp = torch.empty((n,), dtype=torch.float32, device=self.device)
+        src.logits, src.types_out, src.exp_out, src.app_out, src.logp_out = logits.data_ptr(), types.data_ptr(), exp_o.data_ptr(), app_o.data_ptr(), logp.data_ptr()
+        src.n, src.n_types, src.role, src.greedy = n, K, (1 if role == "defender" else 2), int(bool(greedy))
+        src.noop = (8 if role == "defender" else 3) if noop is None else int(noop)
+        src.single_mask = sum(1 << int(t) for t in single_types if 0 <= int(t) < 32)
+        src.status = self.status.data_ptr()
+        keep = [logits]
+        for name, t in (("exp", exp_logits), ("app", app_logits)):
+            if t is None or int(t.shape[-1]) == 0:
+                continue
+            if not ok(t) or t.dim() != 2 or int(t.shape[0]) != n or int(t.shape[1]) > 32:
+                raise ValueError(f"{name}_logits must be a contiguous [n, <= 32] float32 tensor on the batch's device")
+            setattr(src, name + "_logits", t.data_ptr())
+            setattr(src, "n_" + name, int(t.shape[1]))
+            keep.append(t)
+        if rows is not None:
+            r = rows if (rows.dtype == torch.int32 and rows.is_contiguous()) else rows.to(torch.int32).contiguous()
+            if int(r.numel()) != n or r.device != self.device:
+                raise ValueError("rows must hold one env id per row on the batch's device")
+            keep.append(r)
+            src.rows = r.data_ptr()
+        elif n > self.N:
+            raise ValueError("more rows than envs")
+        _lib.check(self.lib.cygym_sample_group_actions(self._h, C.byref(src), C.byref(dst), self._stream()), self._h, "cygym_sample_group_actions")
+        return types, exp_o, app_o, logp
+
     def take_status(self) -> int:
         """Read and clear the batch's status word: the OR of CG_E_TOPO_OVF | CG_E_BUSY_SAT | CG_E_DET_PENDING |
         CG_E_UNPINNED over the envs ticked since the last call (one 4-byte device-to-host copy; synchronises)."""

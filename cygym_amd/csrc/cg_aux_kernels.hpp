@@ -185,30 +185,23 @@ __global__ void write_actions_kernel(cygym_action_rows src, cygym_actions dst, i
 
 // cygym_group_actions (IPPO.py:560-572 for a batch): one wave per row.  For every action type in ascending order the
 // devices that sampled it are ranked with ballots (ascending id = list order); a single-device type keeps the r-th of
-// them, r uniform from the addressed Philox draw.
-__global__ void group_actions_kernel(cygym_device_types src, cygym_actions dst, int M, int n_envs, const uint8_t* live,
-                                     const int32_t* ienv, uint64_t seed, int64_t env_id_base) {
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-  if (wave >= src.n) return;
-  const int row = src.rows ? src.rows[wave] : wave;
-  if (row < 0 || row >= n_envs) return;
+// them, r uniform from the addressed Philox draw.  `ty` = the row's types (global memory or LDS), `vis` an explicit mask or
+// nullptr = the role's visibility read off the flag plane `fl`.
+__device__ __forceinline__ void group_row(const uint8_t* ty, const uint8_t* vis, const uint8_t* fl, const uint32_t want, const int M,
+                                          const int n_types, const int noop, const uint32_t single_mask, const int ex, const int app,
+                                          const cygym_actions& dst, const int row, const uint32_t tick, const uint64_t seed,
+                                          const int64_t env_id_base, uint32_t* status, const int lane) {
   const int G = dst.max_groups, L = dst.max_devs;
-  const uint8_t* ty = src.types + (size_t)wave * M;
-  const uint8_t* vis = src.visible ? src.visible + (size_t)wave * M : nullptr;
-  const uint8_t* fl = live + (size_t)row * 4 * M;
-  const uint32_t want = src.role == 2 ? (CG_F_KNOWN | CG_F_OWNED) : CG_F_OWNED;
-  const int ex = src.exploit ? src.exploit[wave] : 0, app = src.app ? src.app[wave] : 0;
   int16_t* out = const_cast<int16_t*>(dst.dev_idx) + (size_t)row * L;
   int32_t* o_at = const_cast<int32_t*>(dst.atype) + (size_t)row * G;
   int32_t* o_ne = const_cast<int32_t*>(dst.n_exploit) + (size_t)row * G;
   int32_t* o_ex = const_cast<int32_t*>(dst.exploit) + (size_t)row * G * CG_MAX_EXPLOITS;
   int32_t* o_app = const_cast<int32_t*>(dst.app) + (size_t)row * G;
   int32_t* o_cnt = const_cast<int32_t*>(dst.dev_cnt) + (size_t)row * G;
-  const uint32_t tick = (uint32_t)ienv[(size_t)row * CG_I_COUNT + CG_I_RNG_TICK];
   int g = 0, base = 0;
   bool cut = false;
-  for (int t = 0; t < src.n_types; ++t) {
-    if (t == src.noop) continue;
+  for (int t = 0; t < n_types; ++t) {
+    if (t == noop) continue;
     int total = 0;
     for (int d0 = 0; d0 < M; d0 += WAVE) {
       const int d = d0 + lane;
@@ -218,11 +211,11 @@ __global__ void group_actions_kernel(cygym_device_types src, cygym_actions dst, 
     if (total == 0) continue;
     if (g >= G) { cut = true; break; }
     int pick = -1;   // single-device type: index of the chosen device among the type's devices
-    if ((src.single_mask >> t) & 1u) {
+    if ((single_mask >> t) & 1u) {
       const cg_u32x4 r = cg_philox4x32_10((uint32_t)(env_id_base + row), tick, CG_SITE_GROUP_PICK, (uint32_t)t, (uint32_t)seed, (uint32_t)(seed >> 32));
       pick = (int)cg_index(r.v[0], (uint32_t)total);
     }
-    int seen = 0, cnt = 0;
+    int seen = 0;
     for (int d0 = 0; d0 < M; d0 += WAVE) {
       const int d = d0 + lane;
       const bool on = d < M && ty[d] == t && (vis ? vis[d] != 0 : ((fl[d] & (want | CG_F_NYA)) == want));
@@ -230,24 +223,112 @@ __global__ void group_actions_kernel(cygym_device_types src, cygym_actions dst, 
       const int rank = seen + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
       if (on) {
         const int pos = pick < 0 ? rank : (rank == pick ? 0 : -1);
-        if (pos >= 0) { if (base + pos < L) out[base + pos] = (int16_t)d; }
+        if (pos >= 0 && base + pos < L) out[base + pos] = (int16_t)d;
       }
       seen += __popcll(m);
     }
-    cnt = pick < 0 ? total : 1;
+    int cnt = pick < 0 ? total : 1;
     if (base + cnt > L) { cnt = L - base; cut = true; }
     if (lane == 0) { o_at[g] = t; o_ne[g] = 1; o_ex[(size_t)g * CG_MAX_EXPLOITS] = ex; o_app[g] = app; o_cnt[g] = cnt; }
     base += cnt;
     ++g;
   }
   if (g == 0) {   // [(noop, [0], [], 0)]
-    if (lane == 0) { o_at[0] = src.noop; o_ne[0] = 1; o_ex[0] = 0; o_app[0] = 0; o_cnt[0] = 0; }
+    if (lane == 0) { o_at[0] = noop; o_ne[0] = 1; o_ex[0] = 0; o_app[0] = 0; o_cnt[0] = 0; }
     g = 1;
   }
   if (lane == 0) {
     const_cast<int32_t*>(dst.n_groups)[row] = g;
-    if (cut && src.status) atomicOr(src.status, CG_DECODE_TRUNCATED);
+    if (cut && status) atomicOr(status, CG_DECODE_TRUNCATED);
   }
+}
+__global__ void group_actions_kernel(cygym_device_types src, cygym_actions dst, int M, int n_envs, const uint8_t* live,
+                                     const int32_t* ienv, uint64_t seed, int64_t env_id_base) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= src.n) return;
+  const int row = src.rows ? src.rows[wave] : wave;
+  if (row < 0 || row >= n_envs) return;
+  const uint32_t want = src.role == 2 ? (CG_F_KNOWN | CG_F_OWNED) : CG_F_OWNED;
+  const uint32_t tick = (uint32_t)ienv[(size_t)row * CG_I_COUNT + CG_I_RNG_TICK];
+  group_row(src.types + (size_t)wave * M, src.visible ? src.visible + (size_t)wave * M : nullptr, live + (size_t)row * 4 * M, want, M, src.n_types,
+            src.noop, src.single_mask, src.exploit ? src.exploit[wave] : 0, src.app ? src.app[wave] : 0, dst, row, tick, seed, env_id_base,
+            src.status, lane);
+}
+
+// cygym_sample_group_actions (IPPO.py:524-572 for a batch): one wave per row, a lane per device.  Sampling = the inverse CDF
+// of softmax(logits) walked with u = addressed Philox draw / 2^32; the sampled types stay in LDS for the grouping.
+constexpr int SAMPLE_WPB = 4;
+__device__ __forceinline__ int sample_head(const float* l, const int K, const uint32_t u32, const bool greedy, float& logp) {
+  float mx = -__builtin_inff();
+  int am = 0;
+  for (int k = 0; k < K; ++k) { const float x = l[k]; if (x > mx) { mx = x; am = k; } }   // (first maximum)
+  float S = 0.f;
+  for (int k = 0; k < K; ++k) S += __expf(l[k] - mx);
+  int pick = am;
+  if (!greedy) {
+    const float target = (float)u32 * (1.0f / 4294967296.0f) * S;
+    float acc = 0.f;
+    pick = K - 1;
+    for (int k = 0; k < K; ++k) { acc += __expf(l[k] - mx); if (acc > target) { pick = k; break; } }
+  }
+  logp = l[pick] - mx - __logf(S);
+  return pick;
+}
+__global__ __launch_bounds__(SAMPLE_WPB * WAVE) void sample_group_actions_kernel(cygym_device_logits src, cygym_actions dst, int M, int n_envs,
+                                                                                 const uint8_t* live, const int32_t* ienv, uint64_t seed,
+                                                                                 int64_t env_id_base) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * SAMPLE_WPB + wv;
+  if (wave >= src.n) return;
+  const int row = src.rows ? src.rows[wave] : wave;
+  if (row < 0 || row >= n_envs) return;
+  const int Mp = (M + 63) & ~63;
+  uint8_t* ty = smem + (size_t)wv * Mp;
+  const uint8_t* fl = live + (size_t)row * 4 * M;
+  const uint32_t want = src.role == 2 ? (CG_F_KNOWN | CG_F_OWNED) : CG_F_OWNED;
+  const uint32_t tick = (uint32_t)ienv[(size_t)row * CG_I_COUNT + CG_I_RNG_TICK];
+  const uint32_t env_g = (uint32_t)(env_id_base + row), k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  const int K = src.n_types;
+  const bool greedy = src.greedy != 0;
+  float lp = 0.f;
+  for (int d0 = 0; d0 < M; d0 += WAVE) {
+    const int d = d0 + lane;
+    int t = 0;
+    if (d < M) {
+      const bool vis = (fl[d] & (want | CG_F_NYA)) == want;
+      if (vis) {   // never samples an invisible device: label 0, no log-probability (IPPO.py:530-537)
+        const cg_u32x4 r = cg_philox4x32_10(env_g, tick, CG_SITE_SAMPLE, (uint32_t)d & 0xFFFFu, k0, k1);
+        float l1;
+        t = sample_head(src.logits + ((size_t)wave * M + d) * K, K, r.v[0], greedy, l1);
+        lp += l1;
+      }
+      ty[d] = (uint8_t)t;
+      src.types_out[(size_t)wave * M + d] = (uint8_t)t;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) lp += __shfl_xor(lp, off);
+  int ex = 0, app = 0;
+  if (src.exp_logits && src.n_exp > 0) {   // (every lane walks the same few entries)
+    const cg_u32x4 r = cg_philox4x32_10(env_g, tick, CG_SITE_SAMPLE, 1u << 16, k0, k1);
+    float l1;
+    ex = sample_head(src.exp_logits + (size_t)wave * src.n_exp, src.n_exp, r.v[0], greedy, l1);
+    lp += l1;
+  }
+  if (src.app_logits && src.n_app > 0) {
+    const cg_u32x4 r = cg_philox4x32_10(env_g, tick, CG_SITE_SAMPLE, 2u << 16, k0, k1);
+    float l1;
+    app = sample_head(src.app_logits + (size_t)wave * src.n_app, src.n_app, r.v[0], greedy, l1);
+    lp += l1;
+  }
+  if (lane == 0) {
+    if (src.logp_out) src.logp_out[wave] = lp;
+    if (src.exp_out) src.exp_out[wave] = ex;
+    if (src.app_out) src.app_out[wave] = app;
+  }
+  wsync();   // (the wave's own LDS bytes: written above by other lanes)
+  group_row(ty, nullptr, fl, want, M, K, src.noop, src.single_mask, ex, app, dst, row, tick, seed, env_id_base, src.status, lane);
 }
 
 // cygym_decode_actions (do_agent.py:970-998 for a batch): one wave per row.  argmax = first maximum (np.argmax).

@@ -149,6 +149,7 @@ int cygym_sizeof(int32_t which) {
     case 7: return (int)sizeof(cygym_actor_head);
     case 8: return (int)sizeof(cygym_actor_mlp);
     case 9: return (int)sizeof(cygym_device_types);
+    case 10: return (int)sizeof(cygym_device_logits);
     default: return -1;
   }
 }
@@ -637,6 +638,24 @@ int cygym_group_actions(cygym_handle* h, const cygym_device_types* src, const cy
   HIPCHK(h, hipSetDevice(h->device_id));
   const int threads = 256, waves_per_block = threads / WAVE;
   hipLaunchKernelGGL(group_actions_kernel, dim3((src->n + waves_per_block - 1) / waves_per_block), dim3(threads), 0, (hipStream_t)stream,
+                     *src, *dst, h->t.M, h->n_envs, (const uint8_t*)h->b.live, h->b.ienv, h->c.seed, h->c.env_id_base);
+  HIPCHK(h, hipGetLastError());
+  return CYGYM_OK;
+}
+
+int cygym_sample_group_actions(cygym_handle* h, const cygym_device_logits* src, const cygym_actions* dst, void* stream) {
+  if (!h || !h->bound) return fail(h, CYGYM_ENOTBOUND, "cygym_sample_group_actions: handle not bound%s", "");
+  if (!src || !dst || !src->logits || !src->types_out) return fail(h, CYGYM_EINVAL, "cygym_sample_group_actions: null source pointer%s", "");
+  if (!dst->n_groups || !dst->atype || !dst->n_exploit || !dst->exploit || !dst->app || !dst->dev_cnt || !dst->dev_idx || dst->max_groups < 1 ||
+      dst->max_devs < 1)
+    return fail(h, CYGYM_EINVAL, "cygym_sample_group_actions: bad destination%s", "");
+  if (src->n_types < 1 || src->n_types > 32 || src->n_exp < 0 || src->n_exp > 32 || src->n_app < 0 || src->n_app > 32 || (src->role != 1 && src->role != 2))
+    return fail(h, CYGYM_EINVAL, "cygym_sample_group_actions: 1 to 32 action types, at most 32 exploit / app logits, role 1 or 2%s", "");
+  if (src->n < 0 || (!src->rows && src->n > h->n_envs)) return fail(h, CYGYM_EINVAL, "cygym_sample_group_actions: bad row count%s", "");
+  if (src->n == 0) return CYGYM_OK;
+  HIPCHK(h, hipSetDevice(h->device_id));
+  const size_t lds = (size_t)SAMPLE_WPB * ((h->t.M + 63) & ~63);
+  hipLaunchKernelGGL(sample_group_actions_kernel, dim3((src->n + SAMPLE_WPB - 1) / SAMPLE_WPB), dim3(SAMPLE_WPB * WAVE), lds, (hipStream_t)stream,
                      *src, *dst, h->t.M, h->n_envs, (const uint8_t*)h->b.live, h->b.ienv, h->c.seed, h->c.env_id_base);
   HIPCHK(h, hipGetLastError());
   return CYGYM_OK;

@@ -64,6 +64,10 @@ def gae(rewards: torch.Tensor, values: torch.Tensor, dones: torch.Tensor, gamma:
     return adv, adv + values[:-1]
 
 
+def _opt(t):
+    return None if t is None else t.float().contiguous()
+
+
 def _sample(logits: torch.Tensor, greedy: bool, generator):
     """One Categorical per row of `logits` [..., K]: (sample, log-probability of the sample)."""
     logp_all = torch.log_softmax(logits.float(), dim=-1)
@@ -77,7 +81,7 @@ def _sample(logits: torch.Tensor, greedy: bool, generator):
 
 @torch.no_grad()
 def collect(batch, role: str, net, opponent, n_decisions: int, *, greedy: bool = False, generator=None, n_types: int | None = None,
-            randomize_on_reset: bool = True, max_ticks: int | None = None) -> Rollout:
+            randomize_on_reset: bool = True, max_ticks: int | None = None, fused_sampling: bool = True) -> Rollout:
     """Collect `n_decisions` decisions of `role` in every env of `batch` (the while-loop of IPPO.py:503-611).
 
     net(state [N, W], vis [N, M]) -> dict with "per_dev_type_logits" [N, M, K], "value" [N] (or [N, 1]), optional
@@ -86,6 +90,8 @@ def collect(batch, role: str, net, opponent, n_decisions: int, *, greedy: bool =
     opponent: what plays the other role -- a baseline name / fixed sequence (rollout_grid.SequencePolicy semantics), a
         policy(obs, t, M, L) -> action tensors, or an object with write(batch, act, rows, obs) (policies.ActorPolicy).
     The batch must have been created with max_groups >= the role's action types and max_devs >= M, and auto_reset on.
+    fused_sampling (default): the Categoricals are sampled inside the grouping launch (cygym_sample_group_actions: addressed
+    Philox draws, log-probabilities summed in the kernel); False: torch.multinomial with `generator`, then cygym_group_actions.
     """
     from .rollout_grid import SequencePolicy, _baseline_code
     if role not in (HL.DEFENDER, HL.ATTACKER):
@@ -127,21 +133,27 @@ def collect(batch, role: str, net, opponent, n_decisions: int, *, greedy: bool =
             out = net(obs, vis)
             pdt = out["per_dev_type_logits"]
             K = int(pdt.shape[-1]) if n_types is None else int(n_types)
-            types, lp = _sample(pdt, greedy, generator)                       # [N, M]
-            visb = vis > 0.5
-            types = torch.where(visb, types.clamp(0, K - 1), torch.zeros_like(types))   # invisible: in-range dummy label (:531-533)
-            logp = (lp * visb).sum(dim=1)
-            if out.get("exp_logits") is not None and out["exp_logits"].shape[-1] > 0:
-                exp_i, lpe = _sample(out["exp_logits"], greedy, generator)
-                logp = logp + lpe
+            if fused_sampling and K == int(pdt.shape[-1]) <= 32:
+                # sampling, log-probabilities and grouping in ONE launch (addressed Philox draws instead of torch's generator)
+                t8, e32, a32, logp = batch.sample_group_actions(None, pdt.float().contiguous(), _opt(out.get("exp_logits")), _opt(out.get("app_logits")),
+                                                                role, noop=noop, single_types=SINGLE_DEVICE_TYPES, greedy=greedy, act=act)
+                types, exp_i, app_i = t8.to(torch.int64), e32.to(torch.int64), a32.to(torch.int64)
             else:
-                exp_i = torch.zeros(N, dtype=torch.int64, device=dev)
-            if out.get("app_logits") is not None and out["app_logits"].shape[-1] > 0:
-                app_i, lpa = _sample(out["app_logits"], greedy, generator)
-                logp = logp + lpa
-            else:
-                app_i = torch.zeros(N, dtype=torch.int64, device=dev)
-            batch.group_actions(None, types, exp_i, app_i, role, n_types=K, noop=noop, single_types=SINGLE_DEVICE_TYPES, act=act)
+                types, lp = _sample(pdt, greedy, generator)                       # [N, M]
+                visb = vis > 0.5
+                types = torch.where(visb, types.clamp(0, K - 1), torch.zeros_like(types))   # invisible: in-range dummy label (:531-533)
+                logp = (lp * visb).sum(dim=1)
+                if out.get("exp_logits") is not None and out["exp_logits"].shape[-1] > 0:
+                    exp_i, lpe = _sample(out["exp_logits"], greedy, generator)
+                    logp = logp + lpe
+                else:
+                    exp_i = torch.zeros(N, dtype=torch.int64, device=dev)
+                if out.get("app_logits") is not None and out["app_logits"].shape[-1] > 0:
+                    app_i, lpa = _sample(out["app_logits"], greedy, generator)
+                    logp = logp + lpa
+                else:
+                    app_i = torch.zeros(N, dtype=torch.int64, device=dev)
+                batch.group_actions(None, types, exp_i, app_i, role, n_types=K, noop=noop, single_types=SINGLE_DEVICE_TYPES, act=act)
             state_rec = obs.clone()
         else:
             act["n_groups"].zero_()

@@ -49,6 +49,7 @@ DET_APL_N = 257
 SITE_ACTGEN = 64
 SITE_EPS_TYPE = 65
 SITE_GROUP_PICK = 66
+SITE_SAMPLE = 67
 
 POISSON_TABLE = 16
 TRI_TABLE = 8

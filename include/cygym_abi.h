@@ -191,7 +191,7 @@ typedef struct cygym_handle cygym_handle;
 
 int cygym_version(void);
 /* sizeof of the ABI structs as this library was compiled (which: 0 cygym_topology, 1 cygym_config, 2 cygym_buffers,
- * 3 cygym_actions, 4 cygym_outputs, 5 cygym_action_rows, 6 cygym_action_vectors, 7 cygym_actor_head, 8 cygym_actor_mlp, 9 cygym_device_types; -1 for anything else): lets a
+ * 3 cygym_actions, 4 cygym_outputs, 5 cygym_action_rows, 6 cygym_action_vectors, 7 cygym_actor_head, 8 cygym_actor_mlp, 9 cygym_device_types, 10 cygym_device_logits; -1 for anything else): lets a
  * binding check its own struct layouts at load time. */
 int cygym_sizeof(int32_t which);
 const char* cygym_last_error(const cygym_handle* h);  /* h may be NULL */
@@ -345,6 +345,31 @@ typedef struct cygym_device_types {
  * [(noop, [0], [], 0)].  Writes n_groups and the groups' atype / n_exploit (= 1) / exploit[.][0] / app / dev_cnt and the
  * concatenated device lists of the rows (mode is not touched).  n_types <= 32; needs a bound handle. */
 int cygym_group_actions(cygym_handle* h, const cygym_device_types* src, const cygym_actions* dst, void* stream);
+
+/* Per-device action-type LOGITS of n envs, DEVICE pointers: the outputs of the reference's per-device actor-critic networks
+ * (IPPO.py:517-519: out["per_dev_type_logits"] [1, D, K], out["exp_logits"], out["app_logits"]) for a batch. */
+typedef struct cygym_device_logits {
+  const int32_t* rows;       /* [n] env ids (rows of the action tensors) to write; NULL = rows 0..n-1           */
+  const float* logits;       /* [n][M][n_types]                                                                 */
+  const float* exp_logits;   /* [n][n_exp] or NULL (exploit index 0)                                            */
+  const float* app_logits;   /* [n][n_app] or NULL (app index 0)                                                */
+  uint8_t* types_out;        /* [n][M] the sampled type of every device, 0 where invisible (Step.per_dev_types) */
+  int32_t* exp_out;          /* [n] or NULL                                                                     */
+  int32_t* app_out;          /* [n] or NULL                                                                     */
+  float*   logp_out;         /* [n] sum of the log-probabilities of the samples: visible devices + exploit + app */
+  int32_t n, n_types, n_exp, n_app;   /* n_types, n_exp, n_app <= 32                                             */
+  int32_t noop, role;        /* as in cygym_device_types; the visibility mask is the role's (flag plane)         */
+  uint32_t single_mask;
+  int32_t greedy;            /* non-zero: arg-max (first maximum) instead of a sample                           */
+  uint32_t* status;          /* optional, ONE word: CG_DECODE_TRUNCATED as in cygym_device_types                 */
+} cygym_device_logits;
+
+/* Replaces: the sampling of one Categorical per visible device, of the exploit and of the app, their summed log-probability
+ * (IPPO.py:524-557) AND the grouping into env.step(groups) (:560-572) for a batch, in ONE launch: sample k of a head with
+ * logits l is the first k with  sum_{j <= k} exp(l_j - max l) > u * sum_j exp(l_j - max l),  u from the Philox draw addressed
+ * (env, the env's current rng tick, CG_SITE_SAMPLE, device / head); log-probability l_k - max l - log(sum).  Then exactly
+ * cygym_group_actions on the sampled types.  Needs a bound handle. */
+int cygym_sample_group_actions(cygym_handle* h, const cygym_device_logits* src, const cygym_actions* dst, void* stream);
 
 /* The WHOLE actor network of the reference's policies (do_agent.py:357-370: Linear-ReLU stacks ending in a Linear layer,
  * optionally tanh) fused with cygym_decode_actions -- ONE launch per acting role and tick of a closed loop: a workgroup owns

@@ -187,9 +187,12 @@ enum {
   CG_SITE_EPS_TYPE = 65,     /* do_agent.py:972-973 epsilon-greedy action type of decode_action: word 0 is the coin
                                 (u < ceil(eps * 2^32)), word 1 the uniform type index.  Addressed by the env's own rng
                                 tick, read when the action is decoded (the tick that will execute it)            */
-  CG_SITE_GROUP_PICK = 66    /* IPPO.py:566-567 / MAPPO.py: random.choice(devs) of a single-device action type when
+  CG_SITE_GROUP_PICK = 66,   /* IPPO.py:566-567 / MAPPO.py: random.choice(devs) of a single-device action type when
                                 per-device types are grouped (cygym_group_actions): a = action type; addressed by the
                                 env's rng tick like CG_SITE_EPS_TYPE                                              */
+  CG_SITE_SAMPLE = 67        /* IPPO.py:524-555 Categorical(logits).sample() of cygym_sample_group_actions: a = device id,
+                                b = 0 (per-device type) / a = 0, b = 1 (exploit) / b = 2 (app); u = word 0 / 2^32 walks
+                                the inverse CDF of softmax(logits); same addressing                               */
 };
 
 /* ---- Philox4x32-10 (Salmon et al., SC'11), counter-based ----

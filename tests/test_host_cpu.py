@@ -63,7 +63,7 @@ def test_library_loads_and_exports_every_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/cygym_abi.h but not exported"
     assert lib.cygym_version() == abi.ABI_VERSION
-    for which, st in enumerate((abi.Topology, abi.Config, abi.Buffers, abi.Actions, abi.Outputs, abi.ActionRows, abi.ActionVectors, abi.ActorHead, abi.ActorMlp, abi.DeviceTypes)):
+    for which, st in enumerate((abi.Topology, abi.Config, abi.Buffers, abi.Actions, abi.Outputs, abi.ActionRows, abi.ActionVectors, abi.ActorHead, abi.ActorMlp, abi.DeviceTypes, abi.DeviceLogits)):
         assert lib.cygym_sizeof(which) == C.sizeof(st), st.__name__       # the ctypes mirrors match the compiled structs
     assert lib.cygym_sizeof(99) == -1
     # bad arguments come back as error codes with a message, never a crash

@@ -101,6 +101,87 @@ def test_group_actions_kernel_equals_the_numpy_grouping():
         env.close()
 
 
+@pytest.mark.gpu
+def test_sample_group_actions_kernel_equals_the_numpy_sampler():
+    """cygym_sample_group_actions: per-device Categorical samples by the inverse CDF of softmax(logits) walked with the
+    addressed Philox draw, their summed log-probability over the visible devices (+ exploit + app), then the grouping --
+    against a float64 numpy restatement (rows whose every draw is clear of a CDF boundary compare exactly; the
+    log-probabilities to 1e-4), plus the sample frequencies against softmax, and greedy = arg-max."""
+    from cygym_amd.batched_env import BatchedCyberDefenseEnv
+    from cygym_amd.topology import make_topology
+    for M, N, role, K, noop in ((64, 48, "defender", 14, 8), (100, 20, "attacker", 5, 3)):
+        topo, init, ck = make_topology(M, 4 if M == 64 else 1, seed=4, n_active=M - 4)
+        cfg = abi.EnvConfig(seed=123456789012, env_id_base=40, **ck)
+        env = BatchedCyberDefenseEnv(topo, cfg, N, init, device="cuda:0", max_groups=14, max_devs=M)
+        env.randomize()
+        st = env.state_numpy()
+        vis = _np_visibility(st["flags"], role)
+        ticks = st["ienv"][:, S.I_RNG_TICK]
+        g = torch.Generator().manual_seed(M)
+        E, A = cfg.max_exploits, 4
+        logits = torch.randn((N, M, K), generator=g) * 1.5
+        el, al = torch.randn((N, E), generator=g), torch.randn((N, A), generator=g)
+        types, ex, ap, logp = env.sample_group_actions(None, logits.to("cuda:0"), el.to("cuda:0"), al.to("cuda:0"), role, noop=noop)
+        types, ex, ap, logp = types.cpu().numpy(), ex.cpu().numpy(), ap.cpu().numpy(), logp.cpu().numpy()
+        got = {k: v.cpu().numpy() for k, v in env.act.items()}
+
+        def head(l, u32):
+            """(sample, log-probability, clear of every CDF boundary?) in float64"""
+            l = l.astype(np.float64)
+            p = np.exp(l - l.max())
+            cdf = np.cumsum(p)
+            target = (u32 / 4294967296.0) * cdf[-1]
+            k = int(np.searchsorted(cdf, target, side="right"))
+            k = min(k, len(l) - 1)
+            return k, l[k] - l.max() - np.log(cdf[-1]), bool(np.abs(cdf - target).min() > 1e-4 * cdf[-1])
+
+        n_checked = 0
+        for e in range(N):
+            want_t = np.zeros(M, np.int64)
+            lp, clear = 0.0, True
+            env_g = cfg.env_id_base + e
+            for d in np.nonzero(vis[e])[0]:
+                k, l1, c = head(logits[e, d].numpy(), R.draw(cfg.seed, env_g, int(ticks[e]), S.SITE_SAMPLE, int(d), 0))
+                want_t[d] = k; lp += l1; clear &= c
+            ke, l1, c = head(el[e].numpy(), R.draw(cfg.seed, env_g, int(ticks[e]), S.SITE_SAMPLE, 0, 1)); lp += l1; clear &= c
+            ka, l1, c = head(al[e].numpy(), R.draw(cfg.seed, env_g, int(ticks[e]), S.SITE_SAMPLE, 0, 2)); lp += l1; clear &= c
+            assert (types[e][~vis[e]] == 0).all()
+            if not clear:
+                continue
+            n_checked += 1
+            np.testing.assert_array_equal(types[e], want_t, err_msg=f"M={M} env {e}")
+            assert ex[e] == ke and ap[e] == ka
+            assert abs(logp[e] - lp) < 1e-4 * max(1.0, abs(lp)), (e, logp[e], lp)
+            counts = {t: int((vis[e] & (want_t == t)).sum()) for t in (11, 12)}
+            want = HL.group_actions_np(want_t, vis[e], ke, ka, K, noop, (11, 12), _picks(cfg, e, int(ticks[e]), counts, (11, 12)))
+            assert got["n_groups"][e] == len(want)
+            used = 0
+            for gi, (at, exs, devs, a_) in enumerate(want):
+                assert got["atype"][e, gi] == at and got["exploit"][e, gi, 0] == exs[0] and got["app"][e, gi] == a_ and got["dev_cnt"][e, gi] == len(devs)
+                assert list(got["dev_idx"][e, used: used + len(devs)]) == devs
+                used += len(devs)
+        assert n_checked > N // 2
+        # greedy = arg-max (first maximum), exactly
+        tg, eg, ag, _ = env.sample_group_actions(None, logits.to("cuda:0"), el.to("cuda:0"), al.to("cuda:0"), role, noop=noop, greedy=True)
+        np.testing.assert_array_equal(tg.cpu().numpy(), np.where(vis, logits.argmax(dim=-1).numpy(), 0))
+        np.testing.assert_array_equal(eg.cpu().numpy(), el.argmax(dim=-1).numpy())
+        np.testing.assert_array_equal(ag.cpu().numpy(), al.argmax(dim=-1).numpy())
+        env.close()
+    # frequencies: the same logits in every row and device, rng ticks moved on per env by stepping -> samples ~ softmax
+    topo, init, ck = make_topology(64, 4, seed=4, n_active=60)
+    cfg = abi.EnvConfig(seed=5, **ck)
+    env = BatchedCyberDefenseEnv(topo, cfg, 2048, init, device="cuda:0", max_groups=14, max_devs=64)
+    base = torch.tensor([0.0, 1.0, -1.0, 2.0, 0.5])
+    lg = base[None, None, :].repeat(2048, 64, 1).contiguous().to("cuda:0")
+    t, _, _, _ = env.sample_group_actions(None, lg, None, None, "attacker", noop=3)
+    vis = env.visibility_mask("attacker").cpu().numpy() > 0.5
+    tt = t.cpu().numpy()[vis]
+    freq = np.bincount(tt, minlength=5) / tt.size
+    p = torch.softmax(base, 0).numpy()
+    assert tt.size > 5000 and np.abs(freq - p).max() < 4 * np.sqrt(p.max() / tt.size) + 2e-3, (freq, p)
+    env.close()
+
+
 class IntPerDeviceNet:
     """Per-device actor-critic with integer weights (exact in float32 everywhere): logits [N, M, K] from the device's own
     view row, unique arg-maxima; exploit / app logits and a value from sums of the view."""
