@@ -16,7 +16,7 @@ SO = os.environ.get("CYGYM_SO") or os.path.join(HERE, "libcygym_hip.so")   # CYG
 EXPORTS = [
     "cygym_version", "cygym_sizeof", "cygym_last_error", "cygym_create", "cygym_destroy", "cygym_set_config", "cygym_bind", "cygym_derive",
     "cygym_set_snapshot", "cygym_reset", "cygym_randomize", "cygym_step", "cygym_step_range", "cygym_rollout", "cygym_observe",
-    "cygym_gen_actions", "cygym_write_actions", "cygym_decode_actions", "cygym_actor_head_decode", "cygym_actor_mlp_decode", "cygym_group_actions", "cygym_sample_group_actions", "cygym_fit_forests",
+    "cygym_gen_actions", "cygym_write_actions", "cygym_decode_actions", "cygym_actor_head_decode", "cygym_actor_mlp_decode", "cygym_step_actor", "cygym_group_actions", "cygym_sample_group_actions", "cygym_fit_forests",
     "cygym_timer_start", "cygym_timer_stop",
 ]
 
@@ -59,6 +59,8 @@ def load():
     L.cygym_decode_actions.argtypes = [H, C.POINTER(abi.ActionVectors), C.POINTER(abi.Actions), C.c_void_p]
     L.cygym_actor_head_decode.argtypes = [H, C.POINTER(abi.ActorHead), C.POINTER(abi.ActionVectors), C.POINTER(abi.Actions), C.c_void_p]
     L.cygym_actor_mlp_decode.argtypes = [H, C.POINTER(abi.ActorMlp), C.POINTER(abi.ActionVectors), C.POINTER(abi.Actions), C.c_void_p]
+    L.cygym_step_actor.argtypes = [H, C.POINTER(abi.Actions), C.POINTER(abi.Outputs), C.POINTER(abi.ActorMlp), C.POINTER(abi.ActionVectors),
+                                   C.POINTER(abi.Actions), C.c_void_p]
     L.cygym_group_actions.argtypes = [H, C.POINTER(abi.DeviceTypes), C.POINTER(abi.Actions), C.c_void_p]
     L.cygym_sample_group_actions.argtypes = [H, C.POINTER(abi.DeviceLogits), C.POINTER(abi.Actions), C.c_void_p]
     L.cygym_fit_forests.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]

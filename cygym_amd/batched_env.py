@@ -498,7 +498,7 @@ class BatchedCyberDefenseEnv:
 
     def actor_mlp_decode(self, rows, obs: torch.Tensor, hidden_layers, head, n_types: int, n_exploits: int | None = None,
                          n_apps: int = 0, type_map=None, act=None, epsilon: float = 0.0, tanh: bool = False, n_groups: int = 1,
-                         obs_by_env: bool = False, obs_role: str | None = None):
+                         obs_by_env: bool = False, obs_role: str | None = None, rows_per_group: int | None = None, step: dict | None = None):
         """The WHOLE actor (Linear-ReLU stack + last Linear layer, do_agent.py:357-370) fused with decode_actions
         (cygym_actor_mlp_decode): ONE launch per acting role -- hidden activations and action vectors never reach HBM.
           obs            [n, K] float32 (unit inner stride); with obs_by_env the batch's [N, K] role view, read at rows `rows`
@@ -509,7 +509,11 @@ class BatchedCyberDefenseEnv:
         after actor), row r belongs to actor r // (n / S), n / S a multiple of 16.
         obs_role = "defender" / "attacker": `obs` is not read (pass None) -- the kernel builds the role's view of env rows[r]
         (or r) on chip from the batch's CURRENT state (flag plane + static columns: 256 bytes per env instead of a 6 KB view;
-        _get_defender_state / _get_attacker_state, CyberDefenseEnv.py:194-257), so the tick need not write role views. M even."""
+        _get_defender_state / _get_attacker_state, CyberDefenseEnv.py:194-257), so the tick need not write role views. M even.
+        rows_per_group: with n_groups = S, row r belongs to actor (r // rows_per_group) % S (default n // S: actor after actor);
+        the grid layouts of rollout_grid in env order are (nA * n_mc, nD) for the defender and (n_mc, nA) for the attacker.
+        step = {"act": tensors of the tick to run FIRST, "view", "full_obs", "returns" as in step()}: cygym_step_actor -- the
+        tick and this actor (on the state the tick leaves behind) as ONE launch; needs can_step_actor(...)."""
         act = self.act if act is None else act
         dst = self.actions_struct(act)
         n_exploits = self.cfg.max_exploits if n_exploits is None else int(n_exploits)
@@ -550,9 +554,10 @@ class BatchedCyberDefenseEnv:
             raise ValueError(f"head: bias must hold {S_ * n_out} float32 values")
         ml.w_head, ml.b_head = wh.data_ptr(), (bh.data_ptr() if bh is not None else None)
         n = int(rows.shape[0]) if (obs_by_env and rows is not None) else (self.N if obs_role is not None else int(obs.shape[0]))
-        if S_ > 1 and (n % S_ or (n // S_) % 16):
+        rpg = (n // S_ if rows_per_group is None else int(rows_per_group)) if S_ > 1 else 0
+        if S_ > 1 and (rpg < 16 or rpg % 16 or (rows_per_group is None and n % S_)):
             raise ValueError("a population launch needs the same number of rows per actor, a multiple of 16")
-        ml.n_groups, ml.rows_per_group = (S_, n // S_) if S_ > 1 else (1, 0)
+        ml.n_groups, ml.rows_per_group = (S_, rpg) if S_ > 1 else (1, 0)
         src = abi.ActionVectors()
         src.n_types, src.n_devices, src.n_exploits, src.n_apps, src.n = int(n_types), self.M, n_exploits, int(n_apps), n
         src.status = self.status.data_ptr()
@@ -576,8 +581,22 @@ class BatchedCyberDefenseEnv:
                 raise ValueError("type_map must hold n_types int32 entries on the batch's device")
             keep.append(tm)
             src.type_map = tm.data_ptr()
+        if step is not None:
+            a = self.actions_struct(step.get("act"))
+            view, full_obs, returns = step.get("view"), bool(step.get("full_obs", False)), bool(step.get("returns", False))
+            o = self._out if (view is None and full_obs and not returns) else self._outputs(view, full_obs, returns)
+            _lib.check(self.lib.cygym_step_actor(self._h, C.byref(a), C.byref(o), C.byref(ml), C.byref(src), C.byref(dst), self._stream()),
+                       self._h, "cygym_step_actor")
+            return
         _lib.check(self.lib.cygym_actor_mlp_decode(self._h, C.byref(ml), C.byref(src), C.byref(dst), self._stream()),
                    self._h, "cygym_actor_mlp_decode")
+
+    def can_step_actor(self, n_out: int) -> bool:
+        """May a tick and the next actor run as ONE launch (cygym_step_actor)?  Where both kernels share their launch shape: 256
+        devices, a fixed topology without detector buffers, a multiple of 16 envs and at most 16 envs per CU, 257..384 outputs."""
+        cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+        return (self.M == 256 and not getattr(self, "detector", False) and not self.slow_scan and int(self.topo.max_extra) == 0
+                and self.N % 16 == 0 and self.N <= 16 * cus and 257 <= int(n_out) <= 384)
 
     def group_actions(self, rows, types: torch.Tensor, exploit=None, app=None, role: str = "defender", n_types: int | None = None,
                       noop: int | None = None, single_types=(11, 12), visible: torch.Tensor | None = None, act=None):

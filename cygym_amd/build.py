@@ -18,7 +18,7 @@ def needs_build() -> bool:
     t = os.path.getmtime(SO)
     import glob
     deps = [SRC, os.path.join(INC, "cygym_abi.h"), os.path.join(INC, "cygym_spec.h")]
-    deps += glob.glob(os.path.join(os.path.dirname(SRC), "*.hpp")) + glob.glob(os.path.join(os.path.dirname(SRC), "*.hip"))
+    deps += [f for pat in ("*.hpp", "*.hip", "*.inc") for f in glob.glob(os.path.join(os.path.dirname(SRC), pat))]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -45,6 +45,7 @@ def _parse_resources(text: str) -> dict:
 
 
 INST = os.path.join(HERE, "csrc", "cg_inst.hip")
+INST_ACTOR = os.path.join(HERE, "csrc", "cg_inst_actor.hip")
 N_GROUPS = 8   # CG_INST_GROUPS of csrc/cg_device.hpp
 GROUP_MT = {0: 256, 1: 256, 2: 64, 3: 64, 4: 0, 5: 0, 6: 0, 7: 0}   # device-count class each instantiation group holds
 
@@ -66,6 +67,8 @@ def build_to(so: str, resources: str | None = None, flags: list[str] | None = No
     with tempfile.TemporaryDirectory(prefix="cygym_build_") as tmp:
         units = [("main", base + ["-c", SRC, "-o", os.path.join(tmp, "main.o")])]
         units += [(f"inst{g}", base + [f"-DCG_INST_GROUP={g}", "-c", INST, "-o", os.path.join(tmp, f"inst{g}.o")]) for g in groups]
+        if dev_mt is None or dev_mt == 256:   # the tick + actor kernels (256 devices only)
+            units.append(("inst_actor", base + ["-c", INST_ACTOR, "-o", os.path.join(tmp, "inst_actor.o")]))
 
         def run(unit):
             name, cmd = unit

@@ -135,9 +135,12 @@ __device__ __forceinline__ void mlp_finish_hidden(const float* part, const float
   }
 }
 
-template <int HEAD_OPL, int VW>
-__global__ __launch_bounds__(MLP_THREADS) void actor_mlp_kernel(cygym_actor_mlp ml, cygym_action_vectors src, cygym_actions dst, int n_envs,
-                                                                const int32_t* ienv, uint64_t seed, int64_t env_id_base, unsigned long long* st, MlpView vw) {
+// FROM_LDS (tick_actor_kernel, cg_tick_actor.hpp): the flag planes of the 16 envs are still in LDS where the tick left them --
+// row r's at lds_flags + r * lds_pitch -- and source row == env id; they are read before the observation tile overwrites them.
+template <int HEAD_OPL, int VW, bool FROM_LDS>
+__device__ __forceinline__ void actor_mlp_body(cygym_actor_mlp ml, const cygym_action_vectors& src, const cygym_actions& dst, const int n_envs,
+                                               const int32_t* ienv, const uint64_t seed, const int64_t env_id_base, unsigned long long* st,
+                                               const MlpView& vw, const uint8_t* lds_flags, const int lds_pitch) {
 #ifdef CG_STAMPS
 #define MSTAMP(k) do { if (st && threadIdx.x == 0) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); st[(size_t)blockIdx.x * 16 + (k)] = _t; } } while (0)
 #else
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(MLP_THREADS) void actor_mlp_kernel(cygym_actor_mlp 
   const float* w_head = ml.w_head;
   const float* b_head = ml.b_head;
   {
-    const size_t grp = ml.n_groups > 1 ? (size_t)(row0 / ml.rows_per_group) : 0;   // a population of actors: this workgroup's 16 rows belong to ONE of them
+    const size_t grp = ml.n_groups > 1 ? (size_t)((row0 / ml.rows_per_group) % ml.n_groups) : 0;   // a population of actors: this workgroup's 16 rows belong to ONE of them
     int kin = G0;
 #pragma unroll
     for (int l = 0; l < CG_MLP_MAX_HIDDEN; ++l) {
@@ -298,11 +301,13 @@ __global__ __launch_bounds__(MLP_THREADS) void actor_mlp_kernel(cygym_actor_mlp 
             okp[hh] = env >= 0 && 2 * p < M;
             const int pc = 2 * p < M ? p : 0;
             const size_t ec = env >= 0 ? (size_t)env : 0;
-            f2[hh] = reinterpret_cast<const uint16_t*>(vw.live + ec * 4 * M)[pc];
+            if constexpr (FROM_LDS) f2[hh] = reinterpret_cast<const uint16_t*>(lds_flags + (size_t)trow * lds_pitch)[pc];
+            else f2[hh] = reinterpret_cast<const uint16_t*>(vw.live + ec * 4 * M)[pc];
             o[hh] = reinterpret_cast<const float2*>(vw.osv)[pc];
             v[hh] = reinterpret_cast<const float2*>(vw.ver)[pc];
             an[hh] = vw.ano_dyn ? reinterpret_cast<const float2*>(vw.ano_dyn + ec * M)[pc] : reinterpret_cast<const float2*>(vw.ano)[pc];
           }
+          if constexpr (FROM_LDS) __syncthreads();   // (every flag byte is in a register before the tile overwrites the planes)
 #pragma unroll
           for (int hh = 0; hh < 2; ++hh) {
             const int i = tid + MLP_THREADS * hh, trow = i >> 7, pl = i & 127;
@@ -331,10 +336,12 @@ __global__ __launch_bounds__(MLP_THREADS) void actor_mlp_kernel(cygym_actor_mlp 
             if (env >= n_envs) env = -1;
             st_[hh] = env < 0 ? 0 : d < M ? 1 : 2;
             const int dc = d < M ? d : 0;
-            fl[hh] = vw.live[(env >= 0 ? (size_t)env : 0) * 4 * M + dc];
+            if constexpr (FROM_LDS) fl[hh] = (lds_flags + (size_t)trow * lds_pitch)[dc];
+            else fl[hh] = vw.live[(env >= 0 ? (size_t)env : 0) * 4 * M + dc];
             ov[hh] = vw.osv[dc];
             vv[hh] = vw.ver[dc];
           }
+          if constexpr (FROM_LDS) __syncthreads();
 #pragma unroll
           for (int hh = 0; hh < 6; ++hh) {
             const int i = tid + MLP_THREADS * hh, trow = i / (MLP_KT / 4), dl = i - trow * (MLP_KT / 4), d = d0 + dl;
@@ -439,4 +446,11 @@ __global__ __launch_bounds__(MLP_THREADS) void actor_mlp_kernel(cygym_actor_mlp 
   head_decode_row<HEAD_OPL>(outs + wave * n_out_p, bias_r, ml.tanh_out, row, tick, tmap, src, dst, lane, seed, env_id_base);
   MSTAMP(11);
 #undef MSTAMP
+}
+
+template <int HEAD_OPL, int VW>
+__global__ __launch_bounds__(MLP_THREADS) void actor_mlp_kernel(cygym_actor_mlp ml, cygym_action_vectors src, cygym_actions dst, int n_envs,
+                                                                const int32_t* ienv, uint64_t seed, int64_t env_id_base, unsigned long long* st,
+                                                                MlpView vw) {
+  actor_mlp_body<HEAD_OPL, VW, false>(ml, src, dst, n_envs, ienv, seed, env_id_base, st, vw, nullptr, 0);
 }

@@ -143,6 +143,8 @@ __global__ void observe_kernel(KParams P, int role, float* out) {
   }
 }
 
+#include "cg_decode.hpp"      // decode of one row by one wave + the whole-actor kernel (templates: also used by cg_inst_actor.hip)
+
 // cygym_write_actions: one wave per source row.  A device mask is compacted to the ascending id list with ballots
 // (rank of a chosen device = chosen devices below it), the first max_devs of them; entries past the count are zeroed.
 __global__ void write_actions_kernel(cygym_action_rows src, cygym_actions dst, int M, int n_envs) {
@@ -390,23 +392,6 @@ __global__ void decode_actions_kernel(cygym_action_vectors src, cygym_actions ds
 // other rows'); lane j accumulates outputs j, j + 64, ... (HEAD_OPL per lane) with the hidden activation of step k
 // broadcast from the lane that holds it (v_readlane: an SGPR operand, no LDS traffic).  The action vector of a row lives
 // in registers only; its arg-maxima are wave reductions on the DPP path over (order-preserving value bits, ~index) pairs.
-constexpr int HEAD_WAVES = 16, HEAD_OPL_MAX = 8, HEAD_KC = 64;
-// max over the wave of a (hi, lo) pair compared lexicographically; every lane active.  Result valid in lane 63.
-__device__ __forceinline__ void dpp_pair_max(uint32_t& hi, uint32_t& lo) {
-#define CG_PMAX(ctrl, rmask)                                                                          \
-  {                                                                                                   \
-    const uint32_t oh = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, (ctrl), (rmask), 0xf, false); \
-    const uint32_t ol = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, (ctrl), (rmask), 0xf, false); \
-    const bool take = oh > hi || (oh == hi && ol > lo);                                               \
-    hi = take ? oh : hi; lo = take ? ol : lo;                                                         \
-  }
-  CG_PMAX(0x111, 0xf) CG_PMAX(0x112, 0xf) CG_PMAX(0x114, 0xf) CG_PMAX(0x118, 0xf) CG_PMAX(0x142, 0xa) CG_PMAX(0x143, 0xc)
-#undef CG_PMAX
-}
-__device__ __forceinline__ uint32_t float_order_bits(float x) {   // a < b  <=>  bits(a) < bits(b) (finite values)
-  const uint32_t u = __float_as_uint(x);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
 template <int HEAD_OPL>
 __global__ __launch_bounds__(HEAD_WAVES * WAVE) void actor_head_kernel(cygym_actor_head hd, cygym_action_vectors src, cygym_actions dst,
                                                                         int n_envs, const int32_t* ienv, uint64_t seed, int64_t env_id_base) {
@@ -506,72 +491,11 @@ __global__ __launch_bounds__(HEAD_WAVES * WAVE) void actor_head_kernel(cygym_act
   }
 }
 
-// Decode of ONE row by one wave (do_agent.py:970-998), shared by the matrix-core kernels: the row's action vector comes out
-// of LDS (`outs_row`, n_out_p floats) plus the bias held in registers; everything the decode needs from global memory (row id,
-// rng tick, type-map entry per lane) was requested by the caller ahead of the product.
-template <int HEAD_OPL>
-__device__ __forceinline__ void head_decode_row(const float* outs_row, const float (&bias_r)[HEAD_OPL], const int tanh_out, const int row,
-                                                const uint32_t tick, const int tmap, const cygym_action_vectors& src,
-                                                const cygym_actions& dst, const int lane, const uint64_t seed, const int64_t env_id_base) {
-  const int G = dst.max_groups, L = dst.max_devs, M = src.n_devices, nt = src.n_types;
-  const int n_out = nt + M + src.n_exploits + src.n_apps;
-  float v[HEAD_OPL];
-#pragma unroll
-  for (int i = 0; i < HEAD_OPL; ++i) {
-    const float x = outs_row[lane + i * WAVE] + bias_r[i];
-    v[i] = tanh_out ? tanhf(x) : x;
-  }
-  auto range_argmax = [&](int lo, int hi) -> int {
-    uint32_t bh = 0u, bl = 0u;
-#pragma unroll
-    for (int i = 0; i < HEAD_OPL; ++i) {
-      if ((i + 1) * WAVE <= lo || i * WAVE >= hi) continue;   // (scalar branch: a register none of whose lanes is in range)
-      const int j = lane + i * WAVE;
-      const uint32_t ob = float_order_bits(v[i]);
-      if (j >= lo && j < hi && ob > bh) { bh = ob; bl = ~(uint32_t)(j - lo); }
-    }
-    dpp_pair_max(bh, bl);
-    const uint32_t rl = (uint32_t)__builtin_amdgcn_readlane((int)bl, 63), rh = (uint32_t)__builtin_amdgcn_readlane((int)bh, 63);
-    return rh == 0u ? 0 : (int)~rl;
-  };
-  int at = nt > 0 ? range_argmax(0, nt) : 0;
-  if (src.epsilon_thr && nt > 0) {   // epsilon-greedy (do_agent.py:972-973)
-    const cg_u32x4 rr = cg_philox4x32_10((uint32_t)(env_id_base + row), tick, CG_SITE_EPS_TYPE, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
-    if ((uint64_t)rr.v[0] < src.epsilon_thr) at = (int)cg_index(rr.v[1], (uint32_t)nt);
-  }
-  if (nt > 0) at = nt <= WAVE ? __shfl(tmap, at) : (src.type_map ? src.type_map[at] : at);
-  int16_t* out = const_cast<int16_t*>(dst.dev_idx) + (size_t)row * L;
-  int base = 0;
-#pragma unroll
-  for (int i = 0; i < HEAD_OPL; ++i) {
-    if ((i + 1) * WAVE <= nt || i * WAVE >= nt + M) continue;   // (scalar branch: no device value in this register)
-    const int d = lane + i * WAVE - nt;
-    const bool on = d >= 0 && d < M && v[i] > 0.f;
-    const uint64_t m = __ballot(on);
-    const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-    if (on && pos < L) out[pos] = (int16_t)d;
-    base += __popcll(m);
-  }
-  const int cnt = base < L ? base : L;
-  for (int q = cnt + lane; q < L; q += WAVE) out[q] = 0;
-  const int ex = src.n_exploits > 0 ? range_argmax(nt + M, nt + M + src.n_exploits) : 0;
-  const int app = src.n_apps > 0 ? range_argmax(nt + M + src.n_exploits, n_out) : 0;
-  if (lane == 0) {
-    const_cast<int32_t*>(dst.atype)[(size_t)row * G] = at;
-    const_cast<int32_t*>(dst.exploit)[(size_t)row * G * CG_MAX_EXPLOITS] = ex;
-    const_cast<int32_t*>(dst.n_exploit)[(size_t)row * G] = 1;
-    const_cast<int32_t*>(dst.app)[(size_t)row * G] = app;
-    const_cast<int32_t*>(dst.dev_cnt)[(size_t)row * G] = cnt;
-    if (base > L && src.status) atomicOr(src.status, CG_DECODE_TRUNCATED);
-  }
-}
-
 // The same on the matrix cores (H % 4 == 0): a workgroup of 16 waves owns 16 rows; the [16 x H] x [H x n_out_p] product
 // is cut into 16 x 16 output tiles (v_mfma_f32_16x16x4_f32, fp32 in, fp32 accumulate), tile t on wave t % 16; the A
 // fragments (hidden activations) and B fragments (weights, k-major: 64-byte runs per k) come straight from global
 // memory / L2 -- every weight is used once per workgroup, so there is nothing to stage; the 16 x n_out_p outputs pass
 // through LDS once to get each row into one wave, which decodes it as above.
-typedef float cg_floatx4 __attribute__((ext_vector_type(4)));
 template <int HEAD_OPL>
 __global__ __launch_bounds__(16 * WAVE) void actor_head_mfma_kernel(cygym_actor_head hd, cygym_action_vectors src, cygym_actions dst,
                                                                     int n_envs, const int32_t* ienv, uint64_t seed, int64_t env_id_base) {
@@ -626,8 +550,6 @@ __global__ __launch_bounds__(16 * WAVE) void actor_head_mfma_kernel(cygym_actor_
   if (row < 0) return;
   head_decode_row<HEAD_OPL>(outs + wave * n_out_p, bias_r, hd.tanh_out, row, tick, tmap, src, dst, lane, seed, env_id_base);
 }
-
-#include "cg_actor_mlp.hpp"
 
 // Synthetic action script of bench.py: alternating defender / attacker turns.
 // Mirrored in numpy by cygym_amd/actions.py (tests check equality).

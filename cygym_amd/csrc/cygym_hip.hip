@@ -44,6 +44,13 @@ CG_STEP_KERNELS(CG_DECL)
 #undef CG_DECL
 }  // namespace cygym_k
 
+// the tick + actor kernels live in their own unit (cg_inst_actor.hip): declared, not instantiated, here
+namespace cygym_k {
+#include "cg_tick_actor.hpp"
+extern template __global__ void tick_actor_kernel<5>(const KParams, cygym_actor_mlp, cygym_action_vectors, cygym_actions, MlpView);
+extern template __global__ void tick_actor_kernel<6>(const KParams, cygym_actor_mlp, cygym_action_vectors, cygym_actions, MlpView);
+}  // namespace cygym_k
+
 // =====================================================================
 // C ABI
 // =====================================================================
@@ -562,6 +569,69 @@ int cygym_rollout(cygym_handle* h, int32_t n_ticks, const cygym_actions* a, cons
   return launch_ticks(h, n_ticks, 0, h ? h->n_envs : 0, a, o, stream);
 }
 
+int cygym_step_actor(cygym_handle* h, const cygym_actions* a, const cygym_outputs* o, const cygym_actor_mlp* mlp,
+                     const cygym_action_vectors* layout, const cygym_actions* next, void* stream) {
+  if (!h || !h->bound) return fail(h, CYGYM_ENOTBOUND, "cygym_step_actor: handle not bound%s", "");
+  if (!a || !o || !mlp || !layout || !next) return fail(h, CYGYM_EINVAL, "cygym_step_actor: null argument%s", "");
+  if (!a->mode || !a->n_groups || !a->atype || !a->n_exploit || !a->exploit || !a->app || !a->dev_cnt || !a->dev_idx || !o->raw || !o->shaped || !o->done ||
+      a->max_groups < 1 || a->max_devs < 1 || a->max_devs > 32767)
+    return fail(h, CYGYM_EINVAL, "cygym_step_actor: bad action / output tensors%s", "");
+  if (a->max_devs > h->max_devs) {   // the device list lives in LDS: re-plan the launch for a longer list (as cygym_step does)
+    if (choose_launch(h, a->max_devs) != 0) return fail(h, CYGYM_EUNSUPPORTED, "device list does not fit in LDS%s", "");
+    HIPCHK(h, set_lds_attr(h));
+  }
+  // the shape both halves share: the lean WIDE per-tick kernel (256 devices, one 16-wave workgroup per CU = 16 envs) over the whole batch
+  if (h->t.M != 256 || !h->wide || h->wpb != 16 || full_feature(h) || (h->n_envs & 15))
+    return fail(h, CYGYM_EUNSUPPORTED, "cygym_step_actor: 256 devices, a fixed topology without detector buffers, a multiple of 16 envs and at most 16 envs per CU%s", "");
+  if (!next->atype || !next->n_exploit || !next->exploit || !next->app || !next->dev_cnt || !next->dev_idx || next->max_groups < 1 || next->max_devs < 1)
+    return fail(h, CYGYM_EINVAL, "cygym_step_actor: bad destination%s", "");
+  if (h->c.auto_reset && !h->has_snap) return fail(h, CYGYM_EINVAL, "auto_reset needs cygym_set_snapshot first%s", "");
+  if (mlp->obs_role < 1 || mlp->obs_role > 2 || !mlp->w_head || mlp->n_hidden < 1 || mlp->n_hidden > CG_MLP_MAX_HIDDEN ||
+      mlp->K != (mlp->obs_role == 1 ? 6 * h->t.M : 4 * h->t.M + h->c.max_exploits))
+    return fail(h, CYGYM_EINVAL, "cygym_step_actor: the actor reads the role view built on chip (obs_role 1 / 2, K = 6 M / 4 M + MaxExploits)%s", "");
+  for (int l = 0; l < mlp->n_hidden; ++l)
+    if (!mlp->w[l] || mlp->width[l] < 16 || mlp->width[l] > 256 || (mlp->width[l] & 15))
+      return fail(h, CYGYM_EUNSUPPORTED, "cygym_step_actor: hidden widths must be multiples of 16 up to 256%s", "");
+  if (layout->rows || layout->n != h->n_envs || layout->n_devices != h->t.M || layout->n_types < 0 || layout->n_exploits < 0 || layout->n_apps < 0)
+    return fail(h, CYGYM_EINVAL, "cygym_step_actor: the actor acts for every env, in env order (rows == NULL, n == n_envs)%s", "");
+  if (mlp->n_groups > 1 && (mlp->rows_per_group < 16 || (mlp->rows_per_group & 15)))
+    return fail(h, CYGYM_EINVAL, "cygym_step_actor: rows_per_group must be a multiple of 16%s", "");
+  const long long n_out = (long long)layout->n_types + layout->n_devices + layout->n_exploits + layout->n_apps;
+  const int opl = (int)((n_out + 63) / 64);
+  if (opl != 5 && opl != 6) return fail(h, CYGYM_EUNSUPPORTED, "cygym_step_actor: action vectors of 257 to 384 entries%s", "");
+  HIPCHK(h, hipSetDevice(h->device_id));
+  KParams P = make_params(h);
+  P.a = *a; P.o = *o;
+  P.n_ticks = 1;
+  P.snap = h->snap;
+  P.env_begin = 0; P.env_end = h->n_envs;
+  const MlpPlan pl = mlp_plan(mlp->K, mlp->n_hidden, mlp->width, opl * 64);
+  size_t lds = (size_t)pl.total * sizeof(float);
+  const size_t lds_tick = (size_t)h->shared_lds + (size_t)h->wave_lds * 16;
+  if (lds_tick > lds) lds = lds_tick;
+  if (lds > 160 * 1024) return fail(h, CYGYM_EUNSUPPORTED, "cygym_step_actor: the layer shapes do not fit in LDS%s", "");
+#if CG_HAS_MT(256)
+  const void* k = opl == 5 ? (const void*)tick_actor_kernel<5> : (const void*)tick_actor_kernel<6>;
+#else
+  const void* k = nullptr;   // development subset build without the 256-device kernels
+  if (!k) return fail(h, CYGYM_EUNSUPPORTED, "cygym_step_actor: not in this build%s", "");
+#endif
+  {
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> raised;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!raised.count({k, h->device_id})) {
+      HIPCHK(h, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      raised.insert({k, h->device_id});
+    }
+  }
+  MlpView view = {h->b.live, h->t.os_val, h->t.version, h->t.anomaly, h->b.anomaly, h->t.M, h->t.X, h->c.max_exploits, mlp->obs_role};
+  void* args[] = {(void*)&P, (void*)mlp, (void*)layout, (void*)next, &view};
+  HIPCHK(h, hipLaunchKernel(k, dim3(h->n_envs / 16), dim3(16 * WAVE), args, lds, (hipStream_t)stream));
+  HIPCHK(h, hipGetLastError());
+  return CYGYM_OK;
+}
+
 int cygym_observe(cygym_handle* h, int32_t role, float* out, void* stream) {
   if (!h || !h->bound) return fail(h, CYGYM_ENOTBOUND, "cygym_observe: handle not bound%s", "");
   if (!out || role < 0 || role > 2) return fail(h, CYGYM_EINVAL, "cygym_observe: bad argument%s", "");
@@ -744,8 +814,8 @@ int cygym_actor_mlp_decode(cygym_handle* h, const cygym_actor_mlp* mlp, const cy
   if (n_out > (long long)HEAD_OPL_MAX * WAVE) return fail(h, CYGYM_EUNSUPPORTED, "cygym_actor_mlp_decode: more than 512 outputs%s", "");
   if (src->n < 0 || (!src->rows && src->n > h->n_envs)) return fail(h, CYGYM_EINVAL, "cygym_actor_mlp_decode: bad row count%s", "");
   if (src->epsilon_thr && !h->bound) return fail(h, CYGYM_ENOTBOUND, "cygym_actor_mlp_decode: epsilon > 0 needs a bound handle%s", "");
-  if (mlp->n_groups > 1 && (mlp->rows_per_group < 16 || (mlp->rows_per_group & 15) || (long long)mlp->n_groups * mlp->rows_per_group < src->n))
-    return fail(h, CYGYM_EINVAL, "cygym_actor_mlp_decode: rows_per_group must be a multiple of 16 and the groups must cover the rows%s", "");
+  if (mlp->n_groups > 1 && (mlp->rows_per_group < 16 || (mlp->rows_per_group & 15)))   // (row r: actor (r / rows_per_group) % n_groups)
+    return fail(h, CYGYM_EINVAL, "cygym_actor_mlp_decode: rows_per_group must be a multiple of 16%s", "");
   if (src->n == 0) return CYGYM_OK;
   HIPCHK(h, hipSetDevice(h->device_id));
   const int n_out_p = ((int)n_out + 63) & ~63;

@@ -80,15 +80,19 @@ class ActorPolicy:
         return self.fused_mlp(batch) and self.from_state and batch.M % 2 == 0
 
     @torch.no_grad()
-    def write_by_env(self, batch, act, rows, obs_all, role=None):
+    def write_by_env(self, batch, act, rows, obs_all, role=None, step=None):
         """The whole actor + decode + scatter in ONE launch (cygym_actor_mlp_decode), for the envs `rows`: the observation is
         built on chip from the batch's state when `role` is given and reads_state(batch), else read in place from the batch's
-        role view `obs_all` [N, K]; only when fused_mlp(batch)."""
+        role view `obs_all` [N, K]; only when fused_mlp(batch).  step = {...}: a tick runs first, in the same launch
+        (BatchedCyberDefenseEnv.actor_mlp_decode)."""
         hidden, head = self._packed(batch, batch.M)
         from_state = role is not None and self.reads_state(batch)
         batch.actor_mlp_decode(rows, None if from_state else obs_all, hidden, head, self.n_types, self.n_exploits, self.n_apps,
                                self._map(batch.device), act, epsilon=self.epsilon, tanh=self._split_mlp(batch.M)[2], obs_by_env=True,
-                               obs_role=role if from_state else None)
+                               obs_role=role if from_state else None, step=step)
+
+    def n_out(self, M):
+        return self.n_types + M + self.n_exploits + self.n_apps
 
     @torch.no_grad()
     def write(self, batch, act, rows, obs):
@@ -195,15 +199,20 @@ class ActorPolicyGroup:
         return all(p.reads_state(batch) for p in self.policies)
 
     @torch.no_grad()
-    def write_by_env(self, batch, act, rows, obs_all, role=None):
+    def write_by_env(self, batch, act, rows, obs_all, role=None, step=None, rows_per_group=None):
         """All the actors of the population, whole networks + decode + scatter, in ONE launch (observations as in
-        ActorPolicy.write_by_env)."""
+        ActorPolicy.write_by_env).  rows_per_group: rows in ENV order (rows = None), env e playing actor (e // rows_per_group) %
+        len(policies) -- the grid layouts of rollout_grid; default: rows ordered actor after actor."""
         hidden, head = self._packed_all(batch)
         p0 = self.policies[0]
         from_state = role is not None and self.reads_state(batch)
         batch.actor_mlp_decode(rows, None if from_state else obs_all, hidden, head, self.n_types, self.n_exploits, self.n_apps,
                                p0._map(batch.device), act, epsilon=self.epsilon, tanh=p0._split_mlp(batch.M)[2],
-                               n_groups=len(self.policies), obs_by_env=True, obs_role=role if from_state else None)
+                               n_groups=len(self.policies), obs_by_env=True, obs_role=role if from_state else None, step=step,
+                               rows_per_group=rows_per_group)
+
+    def n_out(self, M):
+        return self.policies[0].n_out(M)
 
     @torch.no_grad()
     def write(self, batch, act, rows, obs):

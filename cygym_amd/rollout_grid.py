@@ -33,6 +33,7 @@ import torch
 
 from . import abi
 from . import host_logic as HL
+from ._lib import CygymError as _CygymError
 from . import sharding
 from . import spec as S
 
@@ -204,25 +205,29 @@ def _write_rows(batch, act, r, a, L):
     act["dev_idx"].index_copy_(0, r, a["dev_idx"].to(torch.int16))
 
 
-def _group_actors(batch, items, M):
+def _group_actors(batch, items, M, env_order_rpg=None):
     """Strategies of one role and sub-batch that are actor networks of ONE architecture with equally many rows (a multiple
-    of 16) each are evaluated as a population: batched GEMMs + one head launch (policies.ActorPolicyGroup)."""
+    of 16) each are evaluated as a population: one launch for all of them (policies.ActorPolicyGroup).  env_order_rpg: the
+    sub-batch is the whole grid in env order and env e plays strategy (e // env_order_rpg) % len(items) -- the population then
+    needs no row ids at all (rows_per_group of cygym_actor_mlp)."""
     from .policies import ActorPolicyGroup
     if len(items) < 2 or not hasattr(batch, "actor_head_decode"):
         return items
-    keys = [ActorPolicyGroup.key(p, M) for p, _, _, _ in items]
+    keys = [ActorPolicyGroup.key(p, M) for p, _, _, _, _ in items]
     n0 = int(items[0][1].numel())
     if keys[0] is None or any(k != keys[0] for k in keys) or n0 % 16 or any(int(it[1].numel()) != n0 for it in items):
         return items
     r64 = torch.cat([it[1] for it in items])
     ids = r64.cpu().numpy()
     sl = slice(int(ids[0]), int(ids[-1]) + 1) if (np.diff(ids) == 1).all() else None      # (the defender's strategies: one ascending range)
-    return [(ActorPolicyGroup([it[0] for it in items]), r64, r64.to(torch.int32), sl)]
+    grp = ActorPolicyGroup([it[0] for it in items])
+    rpg = env_order_rpg if (env_order_rpg and env_order_rpg % 16 == 0 and grp.fused_mlp(batch)) else None
+    return [(grp, r64, r64.to(torch.int32), sl, rpg)]
 
 
 def simulate_grid(batch, def_policies, att_policies, n_mc: int, T: int, randomize: bool = True,
                   group=None, n_total: int | None = None, cell_offset: int = 0, timers: dict | None = None,
-                  graph: bool = False, streams: int = 1):
+                  graph: bool = False, streams: int = 1, merge_launches: bool = True):
     """The |D| x |A| x n_mc grid of `simulate_game` (do_agent.py:1875-2089 / worker :129-287) with CLOSED-LOOP
     strategies, as one batch: cell (i, j, mc) is env slot i*|A|*n_mc + j*n_mc + mc.
 
@@ -247,6 +252,10 @@ def simulate_grid(batch, def_policies, att_policies, n_mc: int, T: int, randomiz
     env is done -- the batched counterpart of the reference's process-per-rollout fan-out (do_agent.py:1928-1942).
     graph=True: when every policy is tick_free and none can train, ticks 6, 7 are captured in a HIP graph (all
     streams) and replayed for the rest of the horizon (no host work per tick); otherwise the flag is ignored.
+
+    merge_launches (default): where the next role's whole plan is one actor launch over every env in env order and the batch has
+    the shape for it (BatchedCyberDefenseEnv.can_step_actor: 256 devices, fixed topology, at most 16 envs per CU), a tick and
+    the NEXT role's actor run as ONE launch (cygym_step_actor) -- a turn of the loop per launch.
 
     Detector.train (defender action 10): when some defender policy can emit it the batch must have been created
     with detector=True; after every defender tick the 4-byte status word says whether any env asked, and the
@@ -286,8 +295,10 @@ def simulate_grid(batch, def_policies, att_policies, n_mc: int, T: int, randomiz
                     continue
                 sl = slice(int(ids[0]), int(ids[-1]) + 1) if ids[-1] - ids[0] + 1 == ids.size else None
                 t64 = torch.from_numpy(ids).to(dev)
-                items.append((p, t64, t64.to(torch.int32), sl))
-            plan[r].append(_group_actors(batch, items, M) if fused else items)
+                items.append((p, t64, t64.to(torch.int32), sl, None))
+            # the whole grid in env order: env e plays defender strategy e // (nA n_mc) and attacker strategy (e // n_mc) % nA
+            rpg = (nA * n_mc if r == HL.DEFENDER else n_mc) if (S_sub == 1 and cell_offset == 0 and N == cells) else None
+            plan[r].append(_group_actors(batch, items, M, rpg) if fused else items)
     bl = baseline_schedule(def_policies, att_policies, cell_np, n_mc, min(T, 4), _cfg_baseline_code(batch))
     # (ticks >= 2 repeat with period 2: rows 2 / 3 of the schedule; shorter runs only have the first rows)
     mode_words = [torch.from_numpy(((bl[t] + 1) << S.MODE_BASELINE_SHIFT) | (t % 2)).to(device=dev, dtype=torch.int32)
@@ -303,8 +314,20 @@ def simulate_grid(batch, def_policies, att_policies, n_mc: int, T: int, randomiz
     batch.act["n_exploit"].zero_()
     # a role whose strategies all build their observation on chip from the state (policies.ActorPolicy.reads_state) needs no
     # role-view tensor: the tick then does not write one
-    needs_view = {r: not fused or any(not (hasattr(p, "reads_state") and p.reads_state(batch)) for items in plan[r] for p, _, _, _ in items)
+    needs_view = {r: not fused or any(not (hasattr(p, "reads_state") and p.reads_state(batch)) for items in plan[r] for p, _, _, _, _ in items)
                   for r in ROLES}
+
+    def _one_launch(r):
+        """The role's whole plan as ONE actor launch over every env in env order (so that a tick can carry it: cygym_step_actor)?"""
+        if not fused or S_sub != 1 or trains or split or len(plan[r][0]) != 1:
+            return False
+        p, _, _, sl, rpg = plan[r][0][0]
+        in_order = rpg is not None or (sl is not None and sl.start == 0 and sl.stop == N)
+        return bool(in_order and hasattr(p, "reads_state") and p.reads_state(batch) and hasattr(batch, "can_step_actor")
+                    and batch.can_step_actor(p.n_out(M)) and merge_launches)
+
+    carried = {r: _one_launch(r) for r in ROLES}      # the role's actor runs inside the PREVIOUS tick's launch
+    pending = {r: False for r in ROLES}               # ... and has already written the role's next actions
     if fused:
         batch.reset_returns()
         if needs_view[HL.DEFENDER]:
@@ -334,10 +357,13 @@ def simulate_grid(batch, def_policies, att_policies, n_mc: int, T: int, randomiz
         mark()
         if t < 4 and t < len(mode_words):
             act["mode"][lo:hi].copy_(mode_words[t][lo:hi])
-        for p, r64, r32, sl in plan[role][j]:
+        for p, r64, r32, sl, rpg in ([] if pending[role] else plan[role][j]):
             if fused and hasattr(p, "write_by_env") and p.fused_mlp(batch):
                 whole = sl is not None and sl.start == 0 and sl.stop == N      # (every env, in order: no row-id indirection)
-                p.write_by_env(batch, act, None if whole else r32, obs, role)      # whole actor + decode + scatter: one launch, no gather
+                if rpg is not None:
+                    p.write_by_env(batch, act, None, obs, role, rows_per_group=rpg)      # a population in env order
+                else:
+                    p.write_by_env(batch, act, None if whole else r32, obs, role)      # whole actor + decode + scatter: one launch, no gather
                 continue
             o = obs[sl] if sl is not None else obs.index_select(0, r64)
             if fused and hasattr(p, "write"):
@@ -349,7 +375,20 @@ def simulate_grid(batch, def_policies, att_policies, n_mc: int, T: int, randomiz
                 else:
                     _write_rows(batch, batch.act, r64, a, L)
         mark()
-        if fused:
+        pending[role] = False
+        if fused and carried[nxt] and t + 1 < T:
+            # this tick AND the next role's actor as one launch: the actor writes the next tick's actions into acts[nxt]
+            p, _, _, _, rpg = plan[nxt][0][0]
+            kw = {"rows_per_group": rpg} if rpg is not None else {}
+            try:
+                p.write_by_env(batch, acts[nxt], None, None, nxt, step={"act": act, "view": None, "full_obs": False, "returns": True}, **kw)
+                pending[nxt] = True
+            except _CygymError as exc:      # (the handle's launch plan does not have the shared shape after all: two launches)
+                if "cygym_step_actor" not in str(exc):
+                    raise
+                carried[HL.DEFENDER] = carried[HL.ATTACKER] = False
+                batch.step_range(lo, hi - lo, act, view=nxt if needs_view[nxt] else None, full_obs=False, returns=True)
+        elif fused:
             batch.step_range(lo, hi - lo, act, view=nxt if needs_view[nxt] else None, full_obs=False, returns=True)
         else:
             batch.act["mode"].copy_(act["mode"])

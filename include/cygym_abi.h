@@ -401,11 +401,23 @@ typedef struct cygym_actor_mlp {
                               6 M resp. 4 M + MaxExploits, M even.                                                        */
   int32_t reserved;
   /* A population of same-shaped actors in one launch, as in cygym_actor_head: source row r belongs to actor
-   * r / rows_per_group; every packed matrix / bias of actor a follows that of actor a - 1 contiguously. */
+   * (r / rows_per_group) % n_groups; every packed matrix / bias of actor a follows that of actor a - 1 contiguously. */
   int32_t n_groups, rows_per_group;
 } cygym_actor_mlp;
 int cygym_actor_mlp_decode(cygym_handle* h, const cygym_actor_mlp* mlp, const cygym_action_vectors* layout,
                            const cygym_actions* dst, void* stream);
+
+/* cygym_step and the NEXT acting role's cygym_actor_mlp_decode as ONE launch -- a whole turn of a closed loop
+ * (do_agent.py:206-272: act on the observation, step) per launch instead of two.  Tick the whole batch with the actions `a`
+ * (outputs `o`, as cygym_step), then, in the same workgroups, build the role view mlp->obs_role of the state the tick left
+ * behind, run the actor on it and write every env's next action into `next` (which may alias `a`: a workgroup reads its
+ * envs' actions before it writes them).  `layout`: rows == NULL, n == n_envs; with n_groups > 1 env e belongs to actor
+ * (e / rows_per_group) % n_groups (the grid layouts of cygym_amd/rollout_grid: defender strategies vary slowest, attacker
+ * strategies next, Monte-Carlo repeats fastest).  Only where both kernels share their launch shape: 256 devices, a fixed
+ * topology (no extra-edge list, no detector buffers), a multiple of 16 envs and at most 16 envs per CU, action vectors of
+ * 257..384 entries -- CYGYM_EUNSUPPORTED otherwise (use the two calls). */
+int cygym_step_actor(cygym_handle* h, const cygym_actions* a, const cygym_outputs* o, const cygym_actor_mlp* mlp,
+                     const cygym_action_vectors* layout, const cygym_actions* next, void* stream);
 
 /* Replaces: Detector.train(logs) for a batch (CDSimulator.py:688-695: IsolationForest(n_estimators=2, max_samples=256).fit
  * on the [from_device, to_device] pairs of the last <= 2000 log entries, volt_typhoon_env.py:955-961) -- HOST memory in,

@@ -510,6 +510,46 @@ def test_actor_population_is_one_batched_forward_and_one_head_launch():
     batch.close()
 
 
+def test_tick_and_next_actor_as_one_launch_equals_two_launches():
+    """cygym_step_actor (merge_launches: a tick and the next role's whole-actor launch as ONE kernel, the actor reading the flag
+    planes the tick left in LDS) against the two-launch loop on the same strategies -- float weights, epsilon-greedy action
+    types (the addressed Philox draw reads the rng tick the tick has just written back), a 2 x 2 population grid in env order
+    and a 1 x 1 grid, eager and graph replay: identical payoffs and final state, and the merged entry point really ran."""
+    from cygym_amd.batched_env import BatchedCyberDefenseEnv
+    from cygym_amd.policies import ActorPolicy, mlp_actor
+    from cygym_amd.rollout_grid import simulate_grid
+    from cygym_amd.topology import make_topology
+    M = 256
+    topo, init, ck = make_topology(M, 1, seed=11, max_extra=0)
+    cfg = abi.EnvConfig(seed=11, lambda_events=0.0, **ck)
+    X = cfg.max_exploits
+    dt, at = [1, 4, 5, 6, 7, 8, 9, 11, 12, 13, 2], [1, 2, 3]
+    for (nD, nA, n_mc), graph in (((2, 2, 16), True), ((1, 1, 48), False), ((3, 2, 32), False)):
+        N = nD * nA * n_mc
+
+        def make():
+            Dp = [ActorPolicy(mlp_actor(6 * M, len(dt) + M + X + 4, (32,), seed=100 + i, device="cuda:0"), len(dt), X, 4, type_map=dt, epsilon=0.3) for i in range(nD)]
+            Ap = [ActorPolicy(mlp_actor(4 * M + X, len(at) + M + X, (32,), seed=200 + j, device="cuda:0"), len(at), X, 0, type_map=at, epsilon=0.3) for j in range(nA)]
+            return Dp, Ap
+        res = {}
+        for merge in (False, True):
+            batch = BatchedCyberDefenseEnv(topo, cfg, N, init, device="cuda:0", max_groups=1, max_devs=M)
+            calls = []
+            orig = batch.actor_mlp_decode
+            batch.actor_mlp_decode = lambda *a, **k: (calls.append(k.get("step") is not None), orig(*a, **k))[1]
+            U = simulate_grid(batch, *make(), n_mc, 31, randomize=False, graph=graph, merge_launches=merge)
+            res[merge] = (U, batch.state_numpy(), batch.ret.cpu().numpy().copy())
+            assert any(calls) == merge, (merge, calls[:8])
+            if merge:
+                assert sum(calls) >= (8 if graph else 29)          # every tick but the first actor and the last tick (graph: the eager part)
+            batch.close()
+        (Ua, sa, ra), (Ub, sb, rb) = res[False], res[True]
+        np.testing.assert_array_equal(Ua[0], Ub[0]); np.testing.assert_array_equal(Ua[1], Ub[1])
+        np.testing.assert_array_equal(ra, rb)
+        assert not gio.compare_state(sb, sa, f"merged grid {nD}x{nA}x{n_mc}")
+        assert np.abs(ra).sum() > 0
+
+
 def test_view_step_cost_does_not_grow_with_the_batch():
     """CyberDefenseEnvView.step launches only its own env (cygym_step_range) and writes only its own action row:
     the other envs of the batch neither tick nor have their action rows touched."""

@@ -20,6 +20,7 @@ ap.add_argument("--no-randomize", action="store_true"); ap.add_argument("--maxde
 ap.add_argument("--eps", type=float, default=1.0); ap.add_argument("--streams", type=int, default=1)
 ap.add_argument("--no-mlp", action="store_true", help="actor body in torch, only the last layer in the decode launch")
 ap.add_argument("--no-state", action="store_true", help="fused actor reads the role-view tensor instead of building the view from the state")
+ap.add_argument("--no-merge", action="store_true", help="tick and next actor as two launches")
 ap.add_argument("--loop-only", action="store_true", help="stop after the timed loops (profiling: no split, no script-stepping section)")
 a = ap.parse_args()
 nD, nA = (int(x) for x in a.grid.split("x"))
@@ -36,11 +37,11 @@ Ap = [ActorPolicy(mlp_actor(4 * M + X, len(at) + M + X, (a.hidden,), seed=200 + 
 for p, role in [(p, 1) for p in Dp] + [(p, 2) for p in Ap]:
     calibrate_device_head(p, batch.observe(role), M, a.frac)
     p.fuse_mlp, p.from_state = not a.no_mlp, not a.no_state
-simulate_grid(batch, Dp, Ap, n_mc, 16, graph=not a.eager, streams=a.streams)
+simulate_grid(batch, Dp, Ap, n_mc, 16, graph=not a.eager, streams=a.streams, merge_launches=not a.no_merge)
 for rep in range(3):
     tm = {}
-    simulate_grid(batch, Dp, Ap, n_mc, a.ticks, graph=not a.eager, timers=tm, streams=a.streams, randomize=not a.no_randomize)
-    print(f"grid {a.grid} hidden {a.hidden} mlp={not a.no_mlp} state={not a.no_state} graph={tm['graph']} streams={tm['streams']}: {tm['loop_s'] / a.ticks * 1e6:.1f} us/tick, {N * a.ticks / tm['loop_s']:.3e} env-steps/s, "
+    simulate_grid(batch, Dp, Ap, n_mc, a.ticks, graph=not a.eager, timers=tm, streams=a.streams, randomize=not a.no_randomize, merge_launches=not a.no_merge)
+    print(f"grid {a.grid} hidden {a.hidden} mlp={not a.no_mlp} state={not a.no_state} merge={not a.no_merge} graph={tm['graph']} streams={tm['streams']}: {tm['loop_s'] / a.ticks * 1e6:.1f} us/tick, {N * a.ticks / tm['loop_s']:.3e} env-steps/s, "
           f"mean list {float(batch.act['dev_cnt'].float().mean()):.1f}")
 if a.loop_only:
     sys.exit(0)

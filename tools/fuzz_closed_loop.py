@@ -62,7 +62,7 @@ def main():
     t0 = time.time()
     for case in range(a.seed0, a.seed0 + a.cases):
         rs = np.random.RandomState(case)
-        M = int(rs.choice([16, 24, 37, 64, 100, 130, 256]))
+        M = int(rs.choice([16, 24, 37, 64, 100, 130, 256, 256]))
         blocks = 4 if M == 64 else 1
         topo, init, ck = make_topology(M, blocks, seed=case, n_active=max(8, M - int(rs.randint(0, M // 4 + 1))), max_extra=int(rs.choice([0, 16])))
         cfg = abi.EnvConfig(seed=case, lambda_events=float(rs.choice([0.0, 0.7])), **ck)
@@ -78,6 +78,7 @@ def main():
         n_apps = int(rs.choice([0, 4]))
         randomize = bool(rs.rand() < 0.5)
         fuse_mlp, from_state, graph = bool(rs.rand() < 0.8), bool(rs.rand() < 0.8), bool(rs.rand() < 0.6)
+        merge = bool(rs.rand() < 0.8)             # (tick + next actor as one launch where the shapes allow: 256 devices)
 
         def make(dev):
             def w(i):
@@ -92,14 +93,14 @@ def main():
         og = OracleGrid(topo, cfg, N, init, 1, M)
         E_def, E_att = simulate_grid(og, *make("cpu"), n_mc, T, randomize=randomize)
         batch = BatchedCyberDefenseEnv(topo, cfg, N, init, device="cuda:0", max_groups=1, max_devs=M)
-        U_def, U_att = simulate_grid(batch, *make("cuda:0"), n_mc, T, randomize=randomize, graph=graph)
+        U_def, U_att = simulate_grid(batch, *make("cuda:0"), n_mc, T, randomize=randomize, graph=graph, merge_launches=merge)
         got = batch.state_numpy()
         got["ienv"] = got["ienv"].copy()
         got["ienv"][:, S.I_FLAGS] &= ~0x80
         bad = gio.compare_state(got, og.ob.state, f"case {case}")
         ok = not bad and np.allclose(U_def, E_def, rtol=0, atol=1e-9) and np.allclose(U_att, E_att, rtol=0, atol=1e-9)
         print(f"case {case}: {'ok' if ok else 'MISMATCH'}  M={M} grid {nD}x{nA}x{n_mc} T={T} widths={widths} same_arch={same_arch} n_apps={n_apps} "
-              f"randomize={randomize} lam={cfg.lambda_events} fuse_mlp={fuse_mlp} from_state={from_state} graph={graph} [{time.time() - t0:.0f}s]", flush=True)
+              f"randomize={randomize} lam={cfg.lambda_events} fuse_mlp={fuse_mlp} from_state={from_state} graph={graph} merge={merge} [{time.time() - t0:.0f}s]", flush=True)
         if not ok:
             print("\n".join(bad[:8]))
             print("U_def", U_def, "\nE_def", E_def)
