@@ -401,7 +401,8 @@ def closed_loop_block(D: Dist, per_tick_value, seed, n_per_gpu, M=256, blocks=1,
     observation built on chip from the envs' flag planes, + decode_action + the scatter into the action tensors = the
     reference's actor forward and do_agent.decode_action for the batch; a population of same-shaped actors shares the launch)
     and one cygym_step launch that also adds the episode returns -- the shape of do_agent.py:206-272 / :2035-2073 with the
-    actors evaluated for all cells at once.  Grid = |D| x |A| x n_mc cells = one env each.  `torch_body` times the same loop
+    actors evaluated for all cells at once.  `one_launch` times the same loop with the tick and the NEXT role's actor as one
+    kernel (cygym_step_actor: simulate_grid's default in the eager loop).  Grid = |D| x |A| x n_mc cells = one env each.  `torch_body` times the same loop
     with the actor's first layer as a torch GEMM on the role view the tick writes and only the last layer in the decode
     launch (cygym_actor_head_decode): what the fused actor launch replaces.
 
@@ -436,8 +437,9 @@ def closed_loop_block(D: Dist, per_tick_value, seed, n_per_gpu, M=256, blocks=1,
         return Dp, Ap
 
     out = {"what": "simulate_grid, closed loop: cygym_actor_mlp_decode (whole actor on the matrix cores, role view built on chip from the "
-                   "flag planes, + decode + scatter) -> cygym_step (+ episode returns) per tick: 2 launches; all tensors on the device; "
-                   "no ownership reshuffle",
+                   "flag planes, + decode + scatter) -> cygym_step (+ episode returns) per tick: 2 launches, replayed from a HIP graph; "
+                   "`one_launch` times the same loop with the tick and the next role's actor as ONE kernel (cygym_step_actor); all tensors "
+                   "on the device; no ownership reshuffle",
            "envs": n_per_gpu, "devices": M,
            "policy": f"per role: Linear(obs, {hidden})-ReLU-Linear({hidden}, action vector) fp32, random weights, epsilon-greedy types "
                      f"(epsilon = 1), device head calibrated to ~M/16 devices; obs = 6M (defender) / 4M + {X} (attacker) floats",
@@ -472,8 +474,21 @@ def closed_loop_block(D: Dist, per_tick_value, seed, n_per_gpu, M=256, blocks=1,
         rec["eager"]["split_us_per_tick"] = {k: tm[k] / 60 * 1e6 for k in ("observe", "policy+scatter", "step")}
         rec["mean_device_list"] = float(batch.act["dev_cnt"].float().mean())
         rec["launches_per_tick"] = ("1 cygym_actor_mlp_decode, 1 cygym_step" if nD * nA == 1 else
-                                    "the acting role's actors as ONE population (same architecture): 1 cygym_actor_mlp_decode with n_groups, "
+                                    "the acting role's actors as ONE population in env order (n_groups): 1 cygym_actor_mlp_decode, "
                                     "1 cygym_step -- independent of the number of strategies")
+        one = {}
+        for T in (106, 306):      # the same loop with the tick and the next role's actor as ONE launch
+            best = None
+            for _ in range(3):
+                tm = {}
+                D.barrier()
+                simulate_grid(batch, Dp, Ap, n_mc, T, randomize=False, graph=True, timers=tm, merge_launches=True)
+                t = D.max_over_ranks([tm["loop_s"]])[0]
+                best = t if best is None else min(best, t)
+            one[T] = best
+        st1 = (one[306] - one[106]) / 200
+        rec["one_launch"] = {"what": "cygym_step_actor per tick (tick + next role's actor in one kernel), replayed from a HIP graph",
+                             "steady_state": {"value": N * D.world / st1, "ms_per_tick": st1 * 1e3}}
         if nD * nA == 1:      # the loop this replaces: first layer as a torch GEMM on the role view, last layer in the decode launch
             for p in Dp + Ap:
                 p.fuse_mlp = False

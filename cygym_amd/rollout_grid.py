@@ -227,7 +227,7 @@ def _group_actors(batch, items, M, env_order_rpg=None):
 
 def simulate_grid(batch, def_policies, att_policies, n_mc: int, T: int, randomize: bool = True,
                   group=None, n_total: int | None = None, cell_offset: int = 0, timers: dict | None = None,
-                  graph: bool = False, streams: int = 1, merge_launches: bool = True):
+                  graph: bool = False, streams: int = 1, merge_launches: bool | None = None):
     """The |D| x |A| x n_mc grid of `simulate_game` (do_agent.py:1875-2089 / worker :129-287) with CLOSED-LOOP
     strategies, as one batch: cell (i, j, mc) is env slot i*|A|*n_mc + j*n_mc + mc.
 
@@ -253,9 +253,11 @@ def simulate_grid(batch, def_policies, att_policies, n_mc: int, T: int, randomiz
     graph=True: when every policy is tick_free and none can train, ticks 6, 7 are captured in a HIP graph (all
     streams) and replayed for the rest of the horizon (no host work per tick); otherwise the flag is ignored.
 
-    merge_launches (default): where the next role's whole plan is one actor launch over every env in env order and the batch has
-    the shape for it (BatchedCyberDefenseEnv.can_step_actor: 256 devices, fixed topology, at most 16 envs per CU), a tick and
-    the NEXT role's actor run as ONE launch (cygym_step_actor) -- a turn of the loop per launch.
+    merge_launches: where the next role's whole plan is one actor launch over every env in env order and the batch has the
+    shape for it (BatchedCyberDefenseEnv.can_step_actor: 256 devices, fixed topology, at most 16 envs per CU), a tick and the
+    NEXT role's actor run as ONE launch (cygym_step_actor) -- a turn of the loop per launch.  Default: in the eager loop only
+    (+5 % there; a replayed HIP graph already hides the second launch's ramp: 31.4 vs 32.0 us per tick at 1 x 1 x 4096,
+    34.7 vs 34.4 at 2 x 2 x 1024).
 
     Detector.train (defender action 10): when some defender policy can emit it the batch must have been created
     with detector=True; after every defender tick the 4-byte status word says whether any env asked, and the
@@ -279,6 +281,8 @@ def simulate_grid(batch, def_policies, att_policies, n_mc: int, T: int, randomiz
         raise ValueError("a defender strategy can emit action 10 (Detector.train): create the batch with detector=True "
                          "(or declare the policy's `action_types` without 10)")
     fused = hasattr(batch, "role_obs")            # the product batch: fused role views, scatter, return accumulators
+    if merge_launches is None:
+        merge_launches = not graph
     split = timers is not None and bool(timers.get("split"))
     S_sub = max(1, min(int(streams), N)) if (fused and not trains and not split) else 1
     cell_np = np.arange(cell_offset, cell_offset + N)

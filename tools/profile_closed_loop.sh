@@ -9,13 +9,18 @@ mkdir -p "$OUT"
 OUT=$(cd "$OUT" && pwd)
 cd /tmp && export TMPDIR=/tmp
 for g in 1x1 2x2; do
-  C="python3 $REPO/tools/exp_closed_loop.py --grid $g --no-randomize --eager --ticks 100 --loop-only"
+  C="python3 $REPO/tools/exp_closed_loop.py --grid $g --no-randomize --eager --ticks 100 --loop-only --no-merge"
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_$g" -- $C > "$OUT/kt_$g.out" 2> "$OUT/kt_$g.err"
   for f in $(find "$OUT/kt_$g" -name "*kernel_stats.csv" | head -1); do cp "$f" "$OUT/closed_loop_${g}_eager_kernel_stats.csv"; done
   rm -rf "$OUT/kt_$g"
   echo "traced $g"
 done
+# the same loop with the tick and the next role's actor as one kernel (cygym_step_actor)
 C="python3 $REPO/tools/exp_closed_loop.py --grid 1x1 --no-randomize --eager --ticks 100 --loop-only"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_merged" -- $C > "$OUT/kt_merged.out" 2> "$OUT/kt_merged.err"
+for f in $(find "$OUT/kt_merged" -name "*kernel_stats.csv" | head -1); do cp "$f" "$OUT/closed_loop_1x1_one_launch_eager_kernel_stats.csv"; done
+rm -rf "$OUT/kt_merged"
+C="python3 $REPO/tools/exp_closed_loop.py --grid 1x1 --no-randomize --eager --ticks 100 --loop-only --no-merge"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_$c" -- $C > /dev/null 2> "$OUT/pmc_$c.err"
   python3 - "$OUT/pmc_$c" $c > "$OUT/closed_loop_1x1_$c.txt" <<'PY'
