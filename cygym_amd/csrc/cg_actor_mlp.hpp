@@ -207,9 +207,11 @@ __device__ __forceinline__ void actor_mlp_body(cygym_actor_mlp ml, const cygym_a
     // row i / (MLP_STAGE / VW) of the tile, vector i % (MLP_STAGE / VW) of the stage's columns (consecutive lanes, consecutive
     // addresses).  VW = 4 / 2 / 1 by what the rows' alignment allows: base address and row stride (a dense attacker view of
     // 4 M + 6 floats: 2; the batch pads its rows to a multiple of 4 floats).
-    constexpr int VPS = MLP_STAGE / VW, NV = VPS * 16 / MLP_THREADS;   // vectors per row and stage; vectors per thread and stage
-    typedef float vec_t __attribute__((ext_vector_type(VW)));
-    if (vw.role == 0) {
+    // VW = 0: the role view built on chip (obs_role) -- its own instantiation, so that neither path carries the other's registers.
+    if constexpr (VW != 0) {
+      constexpr int VWc = VW > 0 ? VW : 1;
+      constexpr int VPS = MLP_STAGE / VWc, NV = VPS * 16 / MLP_THREADS;   // vectors per row and stage; vectors per thread and stage
+      typedef float vec_t __attribute__((ext_vector_type(VWc)));
       // (branch-free requests: a row or column outside the source is read from a valid address and replaced by zeros)
       size_t rbase[NV];
       bool rok[NV];

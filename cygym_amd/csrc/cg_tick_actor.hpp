@@ -18,6 +18,6 @@ __global__ __launch_bounds__(16 * WAVE, 4) void tick_actor_kernel(const KParams 
   }
   __syncthreads();   // every env of the workgroup has finished its tick (its planes and scalars are written back; the planes are still in LDS)
   extern __shared__ __align__(16) uint8_t smem_ta[];
-  actor_mlp_body<HEAD_OPL, 4, true>(ml, src, dst, P0.n_envs, P0.b.ienv, P0.c.seed, P0.c.env_id_base, nullptr, vw, smem_ta + P0.shared_lds, P0.wave_lds);
+  actor_mlp_body<HEAD_OPL, 0, true>(ml, src, dst, P0.n_envs, P0.b.ienv, P0.c.seed, P0.c.env_id_base, nullptr, vw, smem_ta + P0.shared_lds, P0.wave_lds);
 }
 #endif  // CG_TICK_ACTOR_HPP

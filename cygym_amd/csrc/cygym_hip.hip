@@ -824,12 +824,12 @@ int cygym_actor_mlp_decode(cygym_handle* h, const cygym_actor_mlp* mlp, const cy
   if (lds > 160 * 1024) return fail(h, CYGYM_EUNSUPPORTED, "cygym_actor_mlp_decode: the layer shapes do not fit in LDS%s", "");
   // widest vector the observation rows allow (base address and row stride)
   const uintptr_t al = mlp->obs_role ? 0 : ((uintptr_t)mlp->obs | ((uintptr_t)mlp->obs_stride * 4));   // (K itself may be anything <= obs_stride)
-  const int vw = (al & 15) == 0 ? 4 : (al & 7) == 0 ? 2 : 1;
+  const int vw = mlp->obs_role ? 0 : (al & 15) == 0 ? 4 : (al & 7) == 0 ? 2 : 1;   // (0: the role view built on chip)
   const void* k = nullptr;
-#define CG_MLP_CASE(O) case O: k = vw == 4 ? (const void*)actor_mlp_kernel<O, 4> : vw == 2 ? (const void*)actor_mlp_kernel<O, 2> : (const void*)actor_mlp_kernel<O, 1>; break;
+#define CG_MLP_CASE(O) case O: k = vw == 0 ? (const void*)actor_mlp_kernel<O, 0> : vw == 4 ? (const void*)actor_mlp_kernel<O, 4> : vw == 2 ? (const void*)actor_mlp_kernel<O, 2> : (const void*)actor_mlp_kernel<O, 1>; break;
   switch (n_out_p / WAVE) {
     CG_MLP_CASE(1) CG_MLP_CASE(2) CG_MLP_CASE(3) CG_MLP_CASE(4) CG_MLP_CASE(5) CG_MLP_CASE(6) CG_MLP_CASE(7)
-    default: k = vw == 4 ? (const void*)actor_mlp_kernel<8, 4> : vw == 2 ? (const void*)actor_mlp_kernel<8, 2> : (const void*)actor_mlp_kernel<8, 1>; break;
+    default: k = vw == 0 ? (const void*)actor_mlp_kernel<8, 0> : vw == 4 ? (const void*)actor_mlp_kernel<8, 4> : vw == 2 ? (const void*)actor_mlp_kernel<8, 2> : (const void*)actor_mlp_kernel<8, 1>; break;
   }
 #undef CG_MLP_CASE
   {   // raise the kernel's dynamic-LDS limit once per variant and device (not per launch: this sits in a closed loop's tick)
