@@ -449,7 +449,7 @@ def closed_loop_block(D: Dist, per_tick_value, seed, n_per_gpu, M=256, blocks=1,
         N = nD * nA * n_mc
         batch = BatchedCyberDefenseEnv(topo, cfg, N, init, device=dev, max_groups=1, max_devs=M)
         Dp, Ap = grid(nD, nA, batch)
-        simulate_grid(batch, Dp, Ap, n_mc, 16, randomize=False, graph=True)       # warm-up: allocator, GEMM heuristics, clocks
+        simulate_grid(batch, Dp, Ap, n_mc, 16, randomize=False, graph=True, local_only=True)       # warm-up: allocator, GEMM heuristics, clocks
         rec = {"cells": f"{nD} x {nA} x {n_mc}"}
         runs = {}
         for mode, graph, T in (("graph", True, 106), ("graph_long", True, 306), ("eager", False, 106)):
@@ -457,7 +457,7 @@ def closed_loop_block(D: Dist, per_tick_value, seed, n_per_gpu, M=256, blocks=1,
             for _ in range(3):
                 tm = {}
                 D.barrier()
-                simulate_grid(batch, Dp, Ap, n_mc, T, randomize=False, graph=graph, timers=tm)
+                simulate_grid(batch, Dp, Ap, n_mc, T, randomize=False, graph=graph, timers=tm, local_only=True)
                 t = D.max_over_ranks([tm["loop_s"]])[0]
                 best = t if best is None else min(best, t)
             runs[mode] = (best, T)
@@ -470,7 +470,7 @@ def closed_loop_block(D: Dist, per_tick_value, seed, n_per_gpu, M=256, blocks=1,
                                          "what": f"(loop time at {Tl} ticks - loop time at {Tg} ticks) / {Tl - Tg}: replays only"}}
         rec["eager"] = {"value": N * D.world * Te / te, "ms_per_tick": te / Te * 1e3, "ticks": Te}
         tm = {"split": True}
-        simulate_grid(batch, Dp, Ap, n_mc, 60, randomize=False, graph=False, timers=tm)
+        simulate_grid(batch, Dp, Ap, n_mc, 60, randomize=False, graph=False, timers=tm, local_only=True)
         rec["eager"]["split_us_per_tick"] = {k: tm[k] / 60 * 1e6 for k in ("observe", "policy+scatter", "step")}
         rec["mean_device_list"] = float(batch.act["dev_cnt"].float().mean())
         rec["launches_per_tick"] = ("1 cygym_actor_mlp_decode, 1 cygym_step" if nD * nA == 1 else
@@ -482,7 +482,7 @@ def closed_loop_block(D: Dist, per_tick_value, seed, n_per_gpu, M=256, blocks=1,
             for _ in range(3):
                 tm = {}
                 D.barrier()
-                simulate_grid(batch, Dp, Ap, n_mc, T, randomize=False, graph=True, timers=tm, merge_launches=True)
+                simulate_grid(batch, Dp, Ap, n_mc, T, randomize=False, graph=True, timers=tm, merge_launches=True, local_only=True)
                 t = D.max_over_ranks([tm["loop_s"]])[0]
                 best = t if best is None else min(best, t)
             one[T] = best
@@ -492,14 +492,14 @@ def closed_loop_block(D: Dist, per_tick_value, seed, n_per_gpu, M=256, blocks=1,
         if nD * nA == 1:      # the loop this replaces: first layer as a torch GEMM on the role view, last layer in the decode launch
             for p in Dp + Ap:
                 p.fuse_mlp = False
-            simulate_grid(batch, Dp, Ap, n_mc, 16, randomize=False, graph=True)
+            simulate_grid(batch, Dp, Ap, n_mc, 16, randomize=False, graph=True, local_only=True)
             tb = {}
             for T in (106, 306):
                 best = None
                 for _ in range(3):
                     tm = {}
                     D.barrier()
-                    simulate_grid(batch, Dp, Ap, n_mc, T, randomize=False, graph=True, timers=tm)
+                    simulate_grid(batch, Dp, Ap, n_mc, T, randomize=False, graph=True, timers=tm, local_only=True)
                     t = D.max_over_ranks([tm["loop_s"]])[0]
                     best = t if best is None else min(best, t)
                 tb[T] = best

@@ -227,7 +227,7 @@ def _group_actors(batch, items, M, env_order_rpg=None):
 
 def simulate_grid(batch, def_policies, att_policies, n_mc: int, T: int, randomize: bool = True,
                   group=None, n_total: int | None = None, cell_offset: int = 0, timers: dict | None = None,
-                  graph: bool = False, streams: int = 1, merge_launches: bool | None = None):
+                  graph: bool = False, streams: int = 1, merge_launches: bool | None = None, local_only: bool = False):
     """The |D| x |A| x n_mc grid of `simulate_game` (do_agent.py:1875-2089 / worker :129-287) with CLOSED-LOOP
     strategies, as one batch: cell (i, j, mc) is env slot i*|A|*n_mc + j*n_mc + mc.
 
@@ -264,6 +264,9 @@ def simulate_grid(batch, def_policies, att_policies, n_mc: int, T: int, randomiz
     requests are serviced before the next tick (the reference trains inside the tick, :961).  At the end any env
     that ran a scan without a current forest (CG_E_UNPINNED) raises -- payoffs are never returned from all-"D"
     scans silently.
+
+    local_only: the batch holds the WHOLE grid even though torch.distributed is initialised (every rank runs a grid of its
+    own: bench.py's weak-scaling leg) -- no gather across ranks.
 
     Returns (U_def, U_att) [|D|, |A|]: mean over mc of the per-role reward sums."""
     nD, nA = len(def_policies), len(att_policies)
@@ -464,7 +467,7 @@ def simulate_grid(batch, def_policies, att_policies, n_mc: int, T: int, randomiz
         names = ("observe", "policy+scatter", "step")
         for j, name in enumerate(names):
             timers[name] = timers.get(name, 0.0) + sum(ev[4 * i + j].elapsed_time(ev[4 * i + j + 1]) for i in range(len(ev) // 4)) * 1e-3
-    both = sharding.gather_by_env(totals, n_total, group)   # no-op on one rank
+    both = totals if local_only else sharding.gather_by_env(totals, n_total, group)   # no-op on one rank
     if both.shape[0] != cells:
         raise ValueError("gathered cells do not cover the grid")
     g = both.reshape(nD, nA, n_mc, 2).mean(dim=2)
