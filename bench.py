@@ -89,8 +89,9 @@ class Dist:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        # Rehearsal aid (one-GPU box): CYGYM_BENCH_SAME_GPU=1 runs every rank on cuda:0 (backend nccl = RCCL works
-        # there for <= 6 ranks; CYGYM_BENCH_BACKEND=gloo uses CPU collectives instead).
+        # Rehearsal aid (one-GPU box): CYGYM_BENCH_SAME_GPU=1 runs every rank on cuda:0 -- together with
+        # CYGYM_BENCH_BACKEND=gloo (CPU collectives): RCCL refuses two ranks on one device ("Duplicate GPU detected",
+        # tried in round 3), so the nccl branch needs one GPU per rank.
         self.backend = os.environ.get("CYGYM_BENCH_BACKEND", "nccl")
         if os.environ.get("CYGYM_BENCH_SAME_GPU") == "1":
             self.local_rank = 0
