@@ -207,8 +207,9 @@ class IntPerDeviceNet:
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("role", ["defender", "attacker"])
-def test_collect_equals_the_reference_loop_on_the_oracle(role):
+@pytest.mark.parametrize("role,M,N,lam,max_extra", [("defender", 64, 24, 0.0, 0), ("attacker", 64, 24, 0.0, 0), ("defender", 100, 9, 0.7, 16),
+                                                     ("attacker", 37, 17, 0.7, 0), ("defender", 256, 12, 0.7, 16), ("attacker", 256, 12, 0.0, 0)])
+def test_collect_equals_the_reference_loop_on_the_oracle(role, M, N, lam, max_extra):
     """ippo_rollout.collect (greedy decisions: no sampling noise between CPU and GPU) against the loop of IPPO.py:503-624
     run env by env logic on the CPU oracle: turn from step_num, visibility mask, per-device arg-max types, the reference's
     grouping, env.step(groups), opponent turns, the episode cap with its reset + ownership reshuffle -- states, rewards,
@@ -218,15 +219,15 @@ def test_collect_equals_the_reference_loop_on_the_oracle(role):
     from cygym_amd.batched_env import BatchedCyberDefenseEnv
     from cygym_amd.ippo_rollout import collect
     from cygym_amd.topology import make_topology
-    M, N, n_dec = 64, 24, 14
-    topo, init, ck = make_topology(M, 4, seed=8, n_active=56)
-    cfg = abi.EnvConfig(seed=8, auto_reset=1, episode_limit=11, **ck)          # the cap falls inside the rollout
+    n_dec = 14
+    topo, init, ck = make_topology(M, 4 if M == 64 else 1, seed=8, n_active=M - 8, max_extra=max_extra)
+    cfg = abi.EnvConfig(seed=8, auto_reset=1, episode_limit=11, lambda_events=lam, **ck)          # the cap falls inside the rollout
     X = cfg.max_exploits
     K = 14 if role == "defender" else X + 3
     noop = 8 if role == "defender" else 3
     other = "attacker" if role == "defender" else "defender"
     opp_seq = [(1, [0], [], 0), (2, [1], [], 0), (3, [0], [], 0)] if other == "attacker" else [(1, [0], [3, 9, 12], 0), (8, [0], [], 0), (6, [0], [1, 2], 0)]
-    net = IntPerDeviceNet(role, M, K, X, 5)
+    net = IntPerDeviceNet(role, M, K, X, 5 + M)
     batch = BatchedCyberDefenseEnv(topo, cfg, N, init, device="cuda:0", max_groups=14, max_devs=M)
     ro = collect(batch, role, net, opp_seq, n_dec, greedy=True)
     assert ro.logp.shape == (n_dec, N) and ro.per_dev_types.shape == (n_dec, N, M)
