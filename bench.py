@@ -525,6 +525,52 @@ def closed_loop_block(D: Dist, per_tick_value, seed, n_per_gpu, M=256, blocks=1,
     return out
 
 
+def ippo_collect_block(D: Dist, seed, n_per_gpu, M=256, blocks=1, hidden=64, decisions=40):
+    """The batched IPPO / MAPPO rollout collector timed end to end (cygym_amd/ippo_rollout.collect: the loop of IPPO.py:503-624 for
+    the batch): per decision one forward of a per-device MLP actor + centralised critic (torch), ONE launch that samples a
+    Categorical per visible device / exploit / app, sums the log-probabilities and groups the devices by action type
+    (cygym_sample_group_actions), and two ticks (the learner's grouped step, the baseline opponent's)."""
+    import time
+    import torch
+    from cygym_amd import abi
+    from cygym_amd.batched_env import BatchedCyberDefenseEnv
+    from cygym_amd.ippo_rollout import collect
+    from cygym_amd.topology import make_topology
+    dev = D.dev
+    topo, init, ck = make_topology(M, blocks, seed=seed, max_extra=0)
+    cfg = abi.EnvConfig(seed=seed, env_id_base=D.rank * n_per_gpu, lambda_events=0.0, auto_reset=1, **ck)
+    X, K, F = cfg.max_exploits, 14, 6
+    batch = BatchedCyberDefenseEnv(topo, cfg, n_per_gpu, init, device=dev, max_groups=14, max_devs=M)
+    torch.manual_seed(seed)
+    actor = torch.nn.Sequential(torch.nn.Linear(F, hidden), torch.nn.ReLU(), torch.nn.Linear(hidden, K)).to(dev).eval()
+    critic = torch.nn.Sequential(torch.nn.Linear(F * M, hidden), torch.nn.ReLU(), torch.nn.Linear(hidden, 1)).to(dev).eval()
+    heads = torch.nn.Linear(F * M, X + 4).to(dev).eval()
+
+    def net(state, vis):
+        x = state[:, : F * M]
+        h = heads(x)
+        return {"per_dev_type_logits": actor(x.reshape(-1, M, F)), "value": critic(x).squeeze(-1), "exp_logits": h[:, :X].contiguous(),
+                "app_logits": h[:, X:].contiguous()}
+
+    collect(batch, "defender", net, "No Attack", 4)
+    best = None
+    for _ in range(3):
+        D.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        collect(batch, "defender", net, "No Attack", decisions)
+        torch.cuda.synchronize(dev)
+        t = D.max_over_ranks([time.perf_counter() - t0])[0]
+        best = t if best is None else min(best, t)
+    batch.close()
+    return {"what": "ippo_rollout.collect, defender learner vs the 'No Attack' baseline: per decision 1 net forward (torch) + 1 "
+                    "cygym_sample_group_actions + 2 cygym_step; Step records kept as [T, N, ...] device tensors",
+            "envs": n_per_gpu, "devices": M, "decisions": decisions, "ticks": 2 * decisions,
+            "value": n_per_gpu * D.world * 2 * decisions / best, "unit": "env-steps/s",
+            "decisions_per_s": n_per_gpu * D.world * decisions / best, "ms_per_decision": best / decisions * 1e3,
+            "policy": f"per-device actor Linear(6, {hidden})-ReLU-Linear({hidden}, 14) + critic / exploit / app heads on the 6M view, fp32, random weights"}
+
+
 def brief(rec):
     """The sub-record of a secondary workload in the `configs` block."""
     out = {"workload": rec["workload"], "envs_per_gpu": rec["envs_per_gpu"], "devices": rec["devices"],
@@ -632,6 +678,7 @@ def main():
     if not args.no_closed_loop and name == "target" and not args.envs:
         per_tick_one = per_tick["single_launch"]["value"] if "single_launch" in per_tick else per_tick["value"]
         out["closed_loop_grid"] = closed_loop_block(D, per_tick_one, args.seed, n_per_gpu)
+        out["ippo_rollout_collect"] = ippo_collect_block(D, args.seed, n_per_gpu)
 
     # the other BASELINE configs as short sub-records (parity-test sizes, here timed on the current kernels):
     # N = 1: cfg2 / cfg3 / cfg5; N > 1: cfg4 = the per-GPU shard of the 131072-env config
