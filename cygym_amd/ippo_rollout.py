@@ -64,6 +64,16 @@ def gae(rewards: torch.Tensor, values: torch.Tensor, dones: torch.Tensor, gamma:
     return adv, adv + values[:-1]
 
 
+def masked_adjacency(vis: torch.Tensor) -> torch.Tensor:
+    """What the reference's GAT layers receive, for a batch: build_adjacency(env, D) is all ones for the reference's Subnet (it
+    has neither `edges()` nor a fallback other than np.ones, IPPO.py:52-72), and masked_adjacency (IPPO.py:98-110) turns it
+    into v v^T with the diagonal set to v.  vis [N, M] in {0, 1} -> [N, M, M] float32."""
+    v = vis.to(torch.float32)
+    out = v[:, :, None] * v[:, None, :]
+    eye = torch.eye(v.shape[1], device=v.device, dtype=torch.float32)[None] * v[:, :, None]
+    return out * (1 - eye) + eye
+
+
 def _opt(t):
     return None if t is None else t.float().contiguous()
 
@@ -86,7 +96,7 @@ def collect(batch, role: str, net, opponent, n_decisions: int, *, greedy: bool =
 
     net(state [N, W], vis [N, M]) -> dict with "per_dev_type_logits" [N, M, K], "value" [N] (or [N, 1]), optional
         "exp_logits" [N, E], "app_logits" [N, A] -- the outputs the reference's networks produce (:517-519, :541-555); how
-        the net uses the mask (a GAT over the masked adjacency, an MLP ...) is its own business.
+        the net uses the mask (a GAT over masked_adjacency(vis), an MLP ...) is its own business.
     opponent: what plays the other role -- a baseline name / fixed sequence (rollout_grid.SequencePolicy semantics), a
         policy(obs, t, M, L) -> action tensors, or an object with write(batch, act, rows, obs) (policies.ActorPolicy).
     The batch must have been created with max_groups >= the role's action types and max_devs >= M, and auto_reset on.

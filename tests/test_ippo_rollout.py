@@ -46,6 +46,19 @@ def test_gae_is_compute_gae():
         np.testing.assert_allclose(ret[:, n].numpy(), a + v[:-1, n], rtol=1e-5, atol=1e-5)
 
 
+def test_masked_adjacency_is_the_reference_formula():
+    """ippo_rollout.masked_adjacency against IPPO.py:98-110 applied to the all-ones adjacency build_adjacency returns for the
+    reference's Subnet: adj * (v v^T), diagonal put back for visible nodes only."""
+    from cygym_amd.ippo_rollout import masked_adjacency
+    rs = np.random.RandomState(1)
+    v = (rs.rand(5, 9) < 0.6).astype(np.float32)
+    got = masked_adjacency(torch.from_numpy(v)).numpy()
+    for n in range(5):
+        out = np.ones((9, 9), np.float32) * np.outer(v[n], v[n])
+        eye = np.eye(9, dtype=np.float32) * v[n][:, None]
+        np.testing.assert_array_equal(got[n], out * (1 - eye) + eye)
+
+
 @pytest.mark.gpu
 def test_group_actions_kernel_equals_the_numpy_grouping():
     """cygym_group_actions against IPPO.py:560-572 restated in numpy: per-type ascending device lists over the visible
