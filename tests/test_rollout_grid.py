@@ -521,11 +521,12 @@ def test_tick_and_next_actor_as_one_launch_equals_two_launches():
     from cygym_amd.topology import make_topology
     M = 256
     topo, init, ck = make_topology(M, 1, seed=11, max_extra=0)
-    cfg = abi.EnvConfig(seed=11, lambda_events=0.0, **ck)
-    X = cfg.max_exploits
+    X = abi.EnvConfig(seed=11, **ck).max_exploits
     dt, at = [1, 4, 5, 6, 7, 8, 9, 11, 12, 13, 2], [1, 2, 3]
-    for (nD, nA, n_mc), graph in (((2, 2, 16), True), ((1, 1, 48), False), ((3, 2, 32), False)):
+    # (the last case: episodes end inside the run -- the tick reloads the snapshot into LDS and the actor behind it must see that)
+    for (nD, nA, n_mc), graph, cap in (((2, 2, 16), True, 1000), ((1, 1, 48), False, 1000), ((3, 2, 32), False, 1000), ((1, 2, 16), False, 9)):
         N = nD * nA * n_mc
+        cfg = abi.EnvConfig(seed=11, lambda_events=0.0, auto_reset=int(cap < 1000), episode_limit=cap, **ck)
 
         def make():
             Dp = [ActorPolicy(mlp_actor(6 * M, len(dt) + M + X + 4, (32,), seed=100 + i, device="cuda:0"), len(dt), X, 4, type_map=dt, epsilon=0.3) for i in range(nD)]
