@@ -286,15 +286,24 @@ __global__ __launch_bounds__(SAMPLE_WPB * WAVE) void sample_group_actions_kernel
   const int row = src.rows ? src.rows[wave] : wave;
   if (row < 0 || row >= n_envs) return;
   const int Mp = (M + 63) & ~63;
-  uint8_t* ty = smem + (size_t)wv * Mp;
+  const int K = src.n_types;
+  const size_t per_wave = (size_t)Mp + (size_t)WAVE * K * sizeof(float);   // sampled types of the row + the logits of 64 devices
+  uint8_t* ty = smem + (size_t)wv * per_wave;
+  float* lg = reinterpret_cast<float*>(ty + Mp);
   const uint8_t* fl = live + (size_t)row * 4 * M;
   const uint32_t want = src.role == 2 ? (CG_F_KNOWN | CG_F_OWNED) : CG_F_OWNED;
   const uint32_t tick = (uint32_t)ienv[(size_t)row * CG_I_COUNT + CG_I_RNG_TICK];
   const uint32_t env_g = (uint32_t)(env_id_base + row), k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-  const int K = src.n_types;
   const bool greedy = src.greedy != 0;
   float lp = 0.f;
   for (int d0 = 0; d0 < M; d0 += WAVE) {
+    // the logits of 64 devices: coalesced into LDS (a lane's own K logits lie 4 K bytes from its neighbour's), then every lane
+    // walks its own row there
+    const int nd = M - d0 < WAVE ? M - d0 : WAVE;
+    const float* gl = src.logits + ((size_t)wave * M + d0) * K;
+    wsync();
+    for (int i = lane; i < nd * K; i += WAVE) lg[i] = gl[i];
+    wsync();
     const int d = d0 + lane;
     int t = 0;
     if (d < M) {
@@ -302,7 +311,7 @@ __global__ __launch_bounds__(SAMPLE_WPB * WAVE) void sample_group_actions_kernel
       if (vis) {   // never samples an invisible device: label 0, no log-probability (IPPO.py:530-537)
         const cg_u32x4 r = cg_philox4x32_10(env_g, tick, CG_SITE_SAMPLE, (uint32_t)d & 0xFFFFu, k0, k1);
         float l1;
-        t = sample_head(src.logits + ((size_t)wave * M + d) * K, K, r.v[0], greedy, l1);
+        t = sample_head(lg + lane * K, K, r.v[0], greedy, l1);
         lp += l1;
       }
       ty[d] = (uint8_t)t;

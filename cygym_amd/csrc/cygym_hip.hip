@@ -724,7 +724,7 @@ int cygym_sample_group_actions(cygym_handle* h, const cygym_device_logits* src, 
   if (src->n < 0 || (!src->rows && src->n > h->n_envs)) return fail(h, CYGYM_EINVAL, "cygym_sample_group_actions: bad row count%s", "");
   if (src->n == 0) return CYGYM_OK;
   HIPCHK(h, hipSetDevice(h->device_id));
-  const size_t lds = (size_t)SAMPLE_WPB * ((h->t.M + 63) & ~63);
+  const size_t lds = (size_t)SAMPLE_WPB * ((size_t)((h->t.M + 63) & ~63) + (size_t)WAVE * src->n_types * sizeof(float));
   hipLaunchKernelGGL(sample_group_actions_kernel, dim3((src->n + SAMPLE_WPB - 1) / SAMPLE_WPB), dim3(SAMPLE_WPB * WAVE), lds, (hipStream_t)stream,
                      *src, *dst, h->t.M, h->n_envs, (const uint8_t*)h->b.live, h->b.ienv, h->c.seed, h->c.env_id_base);
   HIPCHK(h, hipGetLastError());
