@@ -35,19 +35,4 @@ obs = torch.randn((N, 6 * M), generator=g).cuda(); W1 = torch.randn((H, 6 * M), 
 run("addmm_activation [4096x1536]x[1536x64]", lambda: torch._addmm_activation(b1, obs, W1.t()))
 env.gen_actions(0)
 run("cygym_step (synthetic script tick 0, repeated)", lambda: env.step())
-# the whole actor in one launch (cygym_actor_mlp_decode)
-W1s = W1 * 0.02
-hid = [(env.pack_linear(W1s), b1, H)]
-hd = (env.pack_linear(W, 64), b)
-run("actor_mlp_decode 1536->64->out (defender view, eps=1)", lambda: env.actor_mlp_decode(None, obs, hid, hd, n_types, X, n_apps, tm, epsilon=1.0))
-rows_all = torch.arange(N, dtype=torch.int32).cuda()
-run("actor_mlp_decode ..., rows read by env id", lambda: env.actor_mlp_decode(rows_all, obs, hid, hd, n_types, X, n_apps, tm, epsilon=1.0, obs_by_env=True))
-Ka = 4 * M + X
-obs_a = torch.randn((N, Ka), generator=g).cuda(); Wa = (torch.randn((H, Ka), generator=g) * 0.02).cuda()
-n_out_a = 3 + M + X
-Wha = (torch.randn((n_out_a, H), generator=g) * 0.1).cuda(); bha = torch.zeros(n_out_a).cuda()
-run("actor_mlp_decode 1030->64->out (attacker view)", lambda: env.actor_mlp_decode(None, obs_a, [(env.pack_linear(Wa), b1, H)], (env.pack_linear(Wha, 64), bha), 3, X, 0, None))
-W1b = (torch.randn((256, 6 * M), generator=g) * 0.02).cuda(); W2b = (torch.randn((256, 256), generator=g) * 0.05).cuda(); b256 = torch.zeros(256).cuda()
-Whb = (torch.randn((n_out, 256), generator=g) * 0.05).cuda()
-hid_b = [(env.pack_linear(W1b), b256, 256), (env.pack_linear(W2b), b256, 256)]
-run("actor_mlp_decode 1536->256->256->out (the reference's actor)", lambda: env.actor_mlp_decode(None, obs, hid_b, (env.pack_linear(Whb, 64), b), n_types, X, n_apps, tm, tanh=True))
+# (the whole actor in one launch, cygym_actor_mlp_decode: tools/exp_mlp.py)
