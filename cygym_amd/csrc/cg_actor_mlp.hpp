@@ -1,5 +1,6 @@
 // cg_actor_mlp.hpp -- cygym_actor_mlp_decode: the actor network of a closed-loop strategy (Linear-ReLU stack + last Linear layer,
-// do_agent.py:357-370) and decode_action (do_agent.py:970-998) in ONE launch.  Included by cg_aux_kernels.hpp (C-ABI unit).
+// do_agent.py:357-370) and decode_action (do_agent.py:970-998) in ONE launch.  Included through cg_decode.hpp (C-ABI unit and
+// the tick + actor unit).
 //
 // A workgroup of 16 waves owns 16 observation rows (= 16 envs).
 //   * Layer 0, [16 x K] x [K x N0]: the observation tile is requested from HBM in one go (up to 1536 columns = 96 KB per
@@ -60,9 +61,9 @@ __device__ __forceinline__ void mlp_b_load(float4 (&b)[NB], const float4* wp, co
     b[u] = wp[(size_t)(g < gmax ? g : gmax) * WAVE];
   }
 }
-// TWO accumulator chains per wave (the matrix instructions of a k-group alternate between them; summed at the end): a
-// dependent v_mfma_f32_16x16x4_f32 can issue every 40 cycles, an independent one every 32, and the SIMD runs the oldest ready
-// wave -- with one chain per wave the matrix pipe idles a fifth of the time and the waves of a SIMD finish one after another.
+// Two accumulator chains per wave (the matrix instructions of a k-group alternate between them; summed at the end).  Measured:
+// no faster than one chain -- a dependent v_mfma_f32_16x16x4_f32 already issues back to back here -- and four chains spill; two
+// cost four registers and keep the sums of even and odd k apart, which is what the exactness tests pin.
 struct MlpAcc {
   cg_floatx4 c[2];
   __device__ __forceinline__ void zero() { c[0] = cg_floatx4{0.f, 0.f, 0.f, 0.f}; c[1] = c[0]; }
@@ -206,7 +207,7 @@ __device__ __forceinline__ void actor_mlp_body(cygym_actor_mlp ml, const cygym_a
     // Each thread copies MLP_STAGE * 16 / 1024 / VW vectors of VW floats per stage: vector i = tid + 1024 * hh of the stage is
     // row i / (MLP_STAGE / VW) of the tile, vector i % (MLP_STAGE / VW) of the stage's columns (consecutive lanes, consecutive
     // addresses).  VW = 4 / 2 / 1 by what the rows' alignment allows: base address and row stride (a dense attacker view of
-    // 4 M + 6 floats: 2; the batch pads its rows to a multiple of 4 floats).
+    // 4 M + 6 floats: 2).
     // VW = 0: the role view built on chip (obs_role) -- its own instantiation, so that neither path carries the other's registers.
     if constexpr (VW != 0) {
       constexpr int VWc = VW > 0 ? VW : 1;
