@@ -504,7 +504,7 @@ class BatchedCyberDefenseEnv:
           obs            [n, K] float32 (unit inner stride); with obs_by_env the batch's [N, K] role view, read at rows `rows`
           hidden_layers  [(packed weights, bias, width), ...] 1 to 3 of them: pack_linear(nn.Linear.weight), widths multiples of
                          16 up to 256
-          head           (pack_linear(last.weight, 64), bias): n_out = n_types + M + n_exploits + n_apps <= 512
+          head           (pack_linear(last.weight, 64), bias): n_out = n_types + M + n_exploits + n_apps <= 8192
         n_groups = S > 1: a population of S same-shaped actors (packed tensors / biases of all actors concatenated, actor
         after actor), row r belongs to actor r // (n / S), n / S a multiple of 16.
         obs_role = "defender" / "attacker": `obs` is not read (pass None) -- the kernel builds the role's view of env rows[r]

@@ -151,9 +151,14 @@ __device__ __forceinline__ void actor_mlp_body(cygym_actor_mlp ml, const cygym_a
   extern __shared__ __align__(16) uint8_t smem[];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // (wave: an SGPR, so are the tile / k-slice indices)
   const int r = lane & 15, kk = lane >> 4;
-  constexpr int n_out_p = HEAD_OPL * WAVE;
+  // HEAD_OPL = 0: action vectors wider than 512 (more than ~490 devices) are produced and decoded in chunks of 512 outputs
+  // (STREAM); otherwise the whole vector is HEAD_OPL * 64 wide and decoded from registers in one go.
+  constexpr bool STREAM = HEAD_OPL == 0;
+  constexpr int OPLc = STREAM ? 8 : HEAD_OPL;
+  constexpr int n_out_p = OPLc * WAVE;            // width of the LDS action-vector tile (= the whole padded vector unless STREAM)
   const int K = ml.K, nt = src.n_types;
   const int n_out = nt + src.n_devices + src.n_exploits + src.n_apps;
+  const int n_out_pr = STREAM ? ((n_out + 63) & ~63) : n_out_p;   // the whole padded vector: what the packed last layer holds
   const MlpPlan pl = mlp_plan(K, ml.n_hidden, ml.width, n_out_p);
   const int kt = pl.kt, hp = pl.hp;
   float* At = reinterpret_cast<float*>(smem);
@@ -180,7 +185,7 @@ __device__ __forceinline__ void actor_mlp_body(cygym_actor_mlp ml, const cygym_a
       bl[l] = ml.b[l] + (ml.b[l] ? grp * wd : 0);
       kin = l < ml.n_hidden ? wd >> 4 : kin;
     }
-    w_head += grp * (size_t)(n_out_p >> 4) * kin * 256;
+    w_head += grp * (size_t)(n_out_pr >> 4) * kin * 256;
     b_head += b_head ? grp * n_out : 0;
   }
   // What the decode of this wave's row will need from global memory (row id, rng tick, type-map entry per lane) is requested
@@ -192,7 +197,8 @@ __device__ __forceinline__ void actor_mlp_body(cygym_actor_mlp ml, const cygym_a
 #pragma unroll
   for (int l = 1; l < CG_MLP_MAX_HIDDEN; ++l) w_last = l < ml.n_hidden ? ml.width[l] : w_last;
   const int Gh = w_last >> 4;   // k-groups of the last layer
-  constexpr int n_tiles_out = n_out_p / 16;   // (<= 32: at most two output tiles per wave)
+  const int n_tiles_tot = n_out_pr >> 4;                                   // output tiles of the last layer
+  const int n_tiles_out = n_tiles_tot < 32 ? n_tiles_tot : 32;             // ... of its first (or only) chunk: at most two per wave
   const float4* whp = reinterpret_cast<const float4*>(w_head) + lane;
   float4 hb0[MLP_NB_SMALL], hb1[MLP_NB_SMALL];   // first weight batches of the last layer's tiles `wave` and `wave + 16`
   // ---------------- layer 0: observation tile from HBM through LDS ----------------
@@ -419,35 +425,116 @@ __device__ __forceinline__ void actor_mlp_body(cygym_actor_mlp ml, const cygym_a
     }
   }
   // ---------------- last layer -> outs [16][n_out_p] ----------------
-  float bias_r[HEAD_OPL];   // (requested here: the loads fly under the last product)
-#pragma unroll
-  for (int i = 0; i < HEAD_OPL; ++i) { const int j = lane + i * WAVE; bias_r[i] = (b_head && j < n_out) ? b_head[j] : 0.f; }
-  {
+  if constexpr (!STREAM) {
+    float bias_r[OPLc];   // (requested here: the loads fly under the last product)
+  #pragma unroll
+    for (int i = 0; i < OPLc; ++i) { const int j = lane + i * WAVE; bias_r[i] = (b_head && j < n_out) ? b_head[j] : 0.f; }
+    {
+      const float* a_row = hin + r * hp;
+      if (wave < n_tiles_out) {
+        MlpAcc acc4;
+        acc4.zero();
+        mlp_mfma_batch<MLP_NB_SMALL>(acc4, a_row, r, kk, hb0, 0, Gh, 1);
+        mlp_mfma_groups<MLP_NB_SMALL>(acc4, a_row, r, kk, whp + (size_t)wave * Gh * WAVE, 0, Gh - 1, MLP_NB_SMALL, Gh, 1);
+        const cg_floatx4 acc = acc4.sum();
+  #pragma unroll
+        for (int v = 0; v < 4; ++v) outs[(4 * kk + v) * n_out_p + wave * 16 + r] = acc[v];
+      }
+      if (wave + 16 < n_tiles_out) {
+        MlpAcc acc4;
+        acc4.zero();
+        mlp_mfma_batch<MLP_NB_SMALL>(acc4, a_row, r, kk, hb1, 0, Gh, 1);
+        mlp_mfma_groups<MLP_NB_SMALL>(acc4, a_row, r, kk, whp + (size_t)(wave + 16) * Gh * WAVE, 0, Gh - 1, MLP_NB_SMALL, Gh, 1);
+        const cg_floatx4 acc = acc4.sum();
+  #pragma unroll
+        for (int v = 0; v < 4; ++v) outs[(4 * kk + v) * n_out_p + (wave + 16) * 16 + r] = acc[v];
+      }
+    }
+    __syncthreads();
+    MSTAMP(10);
+    if (row < 0) return;
+    head_decode_row<OPLc>(outs + wave * n_out_p, bias_r, ml.tanh_out, row, tick, tmap, src, dst, lane, seed, env_id_base);
+    MSTAMP(11);
+  } else {
+    // ---- STREAM: chunks of 512 outputs through the same LDS tile; a wave keeps its row's running arg-maxima and list length ----
+    const int M = src.n_devices, G = dst.max_groups, L = dst.max_devs;
+    const int lo1 = nt + M, lo2 = nt + M + src.n_exploits;
+    uint32_t bh0 = 0u, bl0 = 0u, bh1 = 0u, bl1 = 0u, bh2 = 0u, bl2 = 0u;   // (order bits, ~index) of types / exploit / app so far, per lane
+    int base = 0;
+    int16_t* out = const_cast<int16_t*>(dst.dev_idx) + (size_t)(row >= 0 ? row : 0) * L;
     const float* a_row = hin + r * hp;
-    if (wave < n_tiles_out) {
-      MlpAcc acc4;
-      acc4.zero();
-      mlp_mfma_batch<MLP_NB_SMALL>(acc4, a_row, r, kk, hb0, 0, Gh, 1);
-      mlp_mfma_groups<MLP_NB_SMALL>(acc4, a_row, r, kk, whp + (size_t)wave * Gh * WAVE, 0, Gh - 1, MLP_NB_SMALL, Gh, 1);
-      const cg_floatx4 acc = acc4.sum();
+    const int n_chunks = (n_tiles_tot + 31) >> 5;
+    for (int c = 0; c < n_chunks; ++c) {
+      const int tb = c << 5, te = tb + 32 < n_tiles_tot ? tb + 32 : n_tiles_tot;
+      float bias_r[OPLc];
 #pragma unroll
-      for (int v = 0; v < 4; ++v) outs[(4 * kk + v) * n_out_p + wave * 16 + r] = acc[v];
-    }
-    if (wave + 16 < n_tiles_out) {
-      MlpAcc acc4;
-      acc4.zero();
-      mlp_mfma_batch<MLP_NB_SMALL>(acc4, a_row, r, kk, hb1, 0, Gh, 1);
-      mlp_mfma_groups<MLP_NB_SMALL>(acc4, a_row, r, kk, whp + (size_t)(wave + 16) * Gh * WAVE, 0, Gh - 1, MLP_NB_SMALL, Gh, 1);
-      const cg_floatx4 acc = acc4.sum();
+      for (int i = 0; i < OPLc; ++i) { const int j = (c << 9) + lane + i * WAVE; bias_r[i] = (b_head && j < n_out) ? b_head[j] : 0.f; }
 #pragma unroll
-      for (int v = 0; v < 4; ++v) outs[(4 * kk + v) * n_out_p + (wave + 16) * 16 + r] = acc[v];
+      for (int half = 0; half < 2; ++half) {
+        const int t = tb + wave + 16 * half;
+        if (t < te) {   // (uniform)
+          MlpAcc acc4;
+          acc4.zero();
+          if (c == 0) {
+            mlp_mfma_batch<MLP_NB_SMALL>(acc4, a_row, r, kk, half ? hb1 : hb0, 0, Gh, 1);
+            mlp_mfma_groups<MLP_NB_SMALL>(acc4, a_row, r, kk, whp + (size_t)t * Gh * WAVE, 0, Gh - 1, MLP_NB_SMALL, Gh, 1);
+          } else {
+            mlp_mfma_groups<MLP_NB_SMALL>(acc4, a_row, r, kk, whp + (size_t)t * Gh * WAVE, 0, Gh - 1, 0, Gh, 1);
+          }
+          const cg_floatx4 acc = acc4.sum();
+#pragma unroll
+          for (int v = 0; v < 4; ++v) outs[(4 * kk + v) * n_out_p + (t - tb) * 16 + r] = acc[v];
+        }
+      }
+      __syncthreads();
+      if (row >= 0) {
+#pragma unroll
+        for (int i = 0; i < OPLc; ++i) {
+          const int j = (c << 9) + lane + i * WAVE;
+          if ((c << 9) + i * WAVE >= n_out) break;   // (uniform: past the vector)
+          const float x = outs[wave * n_out_p + lane + i * WAVE] + bias_r[i];
+          const float v = ml.tanh_out ? tanhf(x) : x;
+          const uint32_t ob = float_order_bits(v);
+          if (j < nt && ob > bh0) { bh0 = ob; bl0 = ~(uint32_t)j; }
+          if (j >= lo1 && j < lo2 && ob > bh1) { bh1 = ob; bl1 = ~(uint32_t)(j - lo1); }
+          if (j >= lo2 && j < n_out && ob > bh2) { bh2 = ob; bl2 = ~(uint32_t)(j - lo2); }
+          const int d = j - nt;
+          const bool on = d >= 0 && d < M && v > 0.f;
+          const uint64_t m = __ballot(on);
+          const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+          if (on && pos < L) out[pos] = (int16_t)d;
+          base += __popcll(m);
+        }
+      }
+      if (c + 1 < n_chunks) __syncthreads();   // the next chunk overwrites the tile
     }
+    MSTAMP(10);
+    if (row < 0) return;
+    auto wave_best = [&](uint32_t h, uint32_t l) -> int {
+      dpp_pair_max(h, l);
+      const uint32_t rl = (uint32_t)__builtin_amdgcn_readlane((int)l, 63), rh = (uint32_t)__builtin_amdgcn_readlane((int)h, 63);
+      return rh == 0u ? 0 : (int)~rl;
+    };
+    int at = nt > 0 ? wave_best(bh0, bl0) : 0;
+    if (src.epsilon_thr && nt > 0) {   // epsilon-greedy (do_agent.py:972-973)
+      const cg_u32x4 rr = cg_philox4x32_10((uint32_t)(env_id_base + row), tick, CG_SITE_EPS_TYPE, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+      if ((uint64_t)rr.v[0] < src.epsilon_thr) at = (int)cg_index(rr.v[1], (uint32_t)nt);
+    }
+    if (nt > 0) at = nt <= WAVE ? __shfl(tmap, at) : (src.type_map ? src.type_map[at] : at);
+    const int cnt = base < L ? base : L;
+    for (int q = cnt + lane; q < L; q += WAVE) out[q] = 0;
+    const int ex = src.n_exploits > 0 ? wave_best(bh1, bl1) : 0;
+    const int app = src.n_apps > 0 ? wave_best(bh2, bl2) : 0;
+    if (lane == 0) {
+      const_cast<int32_t*>(dst.atype)[(size_t)row * G] = at;
+      const_cast<int32_t*>(dst.exploit)[(size_t)row * G * CG_MAX_EXPLOITS] = ex;
+      const_cast<int32_t*>(dst.n_exploit)[(size_t)row * G] = 1;
+      const_cast<int32_t*>(dst.app)[(size_t)row * G] = app;
+      const_cast<int32_t*>(dst.dev_cnt)[(size_t)row * G] = cnt;
+      if (base > L && src.status) atomicOr(src.status, CG_DECODE_TRUNCATED);
+    }
+    MSTAMP(11);
   }
-  __syncthreads();
-  MSTAMP(10);
-  if (row < 0) return;
-  head_decode_row<HEAD_OPL>(outs + wave * n_out_p, bias_r, ml.tanh_out, row, tick, tmap, src, dst, lane, seed, env_id_base);
-  MSTAMP(11);
 #undef MSTAMP
 }
 

@@ -811,14 +811,15 @@ int cygym_actor_mlp_decode(cygym_handle* h, const cygym_actor_mlp* mlp, const cy
       return fail(h, CYGYM_EUNSUPPORTED, "cygym_actor_mlp_decode: hidden widths must be multiples of 16 up to 256%s", "");
   }
   const long long n_out = (long long)src->n_types + src->n_devices + src->n_exploits + src->n_apps;
-  if (n_out > (long long)HEAD_OPL_MAX * WAVE) return fail(h, CYGYM_EUNSUPPORTED, "cygym_actor_mlp_decode: more than 512 outputs%s", "");
+  if (n_out > 8192) return fail(h, CYGYM_EUNSUPPORTED, "cygym_actor_mlp_decode: more than 8192 outputs%s", "");
   if (src->n < 0 || (!src->rows && src->n > h->n_envs)) return fail(h, CYGYM_EINVAL, "cygym_actor_mlp_decode: bad row count%s", "");
   if (src->epsilon_thr && !h->bound) return fail(h, CYGYM_ENOTBOUND, "cygym_actor_mlp_decode: epsilon > 0 needs a bound handle%s", "");
   if (mlp->n_groups > 1 && (mlp->rows_per_group < 16 || (mlp->rows_per_group & 15)))   // (row r: actor (r / rows_per_group) % n_groups)
     return fail(h, CYGYM_EINVAL, "cygym_actor_mlp_decode: rows_per_group must be a multiple of 16%s", "");
   if (src->n == 0) return CYGYM_OK;
   HIPCHK(h, hipSetDevice(h->device_id));
-  const int n_out_p = ((int)n_out + 63) & ~63;
+  const bool wide_out = n_out > (long long)HEAD_OPL_MAX * WAVE;   // wider than 512: produced and decoded in chunks of 512 outputs
+  const int n_out_p = wide_out ? HEAD_OPL_MAX * WAVE : (((int)n_out + 63) & ~63);
   const MlpPlan pl = mlp_plan(mlp->K, mlp->n_hidden, mlp->width, n_out_p);
   const size_t lds = (size_t)pl.total * sizeof(float);
   if (lds > 160 * 1024) return fail(h, CYGYM_EUNSUPPORTED, "cygym_actor_mlp_decode: the layer shapes do not fit in LDS%s", "");
@@ -827,8 +828,8 @@ int cygym_actor_mlp_decode(cygym_handle* h, const cygym_actor_mlp* mlp, const cy
   const int vw = mlp->obs_role ? 0 : (al & 15) == 0 ? 4 : (al & 7) == 0 ? 2 : 1;   // (0: the role view built on chip)
   const void* k = nullptr;
 #define CG_MLP_CASE(O) case O: k = vw == 0 ? (const void*)actor_mlp_kernel<O, 0> : vw == 4 ? (const void*)actor_mlp_kernel<O, 4> : vw == 2 ? (const void*)actor_mlp_kernel<O, 2> : (const void*)actor_mlp_kernel<O, 1>; break;
-  switch (n_out_p / WAVE) {
-    CG_MLP_CASE(1) CG_MLP_CASE(2) CG_MLP_CASE(3) CG_MLP_CASE(4) CG_MLP_CASE(5) CG_MLP_CASE(6) CG_MLP_CASE(7)
+  switch (wide_out ? 0 : n_out_p / WAVE) {
+    CG_MLP_CASE(0) CG_MLP_CASE(1) CG_MLP_CASE(2) CG_MLP_CASE(3) CG_MLP_CASE(4) CG_MLP_CASE(5) CG_MLP_CASE(6) CG_MLP_CASE(7)
     default: k = vw == 0 ? (const void*)actor_mlp_kernel<8, 0> : vw == 4 ? (const void*)actor_mlp_kernel<8, 4> : vw == 2 ? (const void*)actor_mlp_kernel<8, 2> : (const void*)actor_mlp_kernel<8, 1>; break;
   }
 #undef CG_MLP_CASE

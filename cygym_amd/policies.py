@@ -31,26 +31,28 @@ class ActorPolicy:
             self.type_map = self.type_map.to(device)
         return self.type_map
 
-    def _split_head(self, M):
+    def _split_head(self, M, max_out=512):
         """(body modules, last nn.Linear, tanh?) when the actor is a Sequential ending in Linear [+ Tanh] that the fused
-        head kernel can take (cygym_actor_head_decode: H <= 256, <= 512 outputs), else None.  Cached."""
-        if not hasattr(self, "_head"):
-            self._head = None
+        head kernel can take (cygym_actor_head_decode: H <= 256, <= 512 outputs), else None.  Cached per output limit."""
+        cache = self.__dict__.setdefault("_heads", {})
+        if max_out not in cache:
+            cache[max_out] = None
             if isinstance(self.net, nn.Sequential) and len(self.net) >= 2:
                 mods = list(self.net)
                 tanh = isinstance(mods[-1], nn.Tanh)
                 last = mods[-2] if tanh else mods[-1]
-                if isinstance(last, nn.Linear) and last.in_features <= 256 and last.out_features <= 512 \
+                if isinstance(last, nn.Linear) and last.in_features <= 256 and last.out_features <= max_out \
                         and last.out_features == self.n_types + M + self.n_exploits + self.n_apps and last.weight.dtype == torch.float32:
-                    self._head = (type(self.net)(*mods[: -2 if tanh else -1]), last, tanh)
-        return self._head
+                    cache[max_out] = (type(self.net)(*mods[: -2 if tanh else -1]), last, tanh)
+        return cache[max_out]
 
     def _split_mlp(self, M):
         """(hidden nn.Linear layers, last nn.Linear, tanh?) when the WHOLE actor is a Linear-ReLU stack the fused actor kernel
-        can take (cygym_actor_mlp_decode: 1 to 3 hidden layers, widths multiples of 16 up to 256, <= 512 outputs), else None."""
+        can take (cygym_actor_mlp_decode: 1 to 3 hidden layers, widths multiples of 16 up to 256, <= 8192 outputs -- vectors wider
+        than 512 are decoded in chunks), else None."""
         if not hasattr(self, "_mlp"):
             self._mlp = None
-            head = self._split_head(M)
+            head = self._split_head(M, max_out=8192)
             if head is not None:
                 body, last, tanh = head
                 mods = list(body)

@@ -377,7 +377,8 @@ int cygym_sample_group_actions(cygym_handle* h, const cygym_device_logits* src, 
  * activations stay in LDS) and decodes the rows from registers like cygym_actor_head_decode.  Neither the hidden
  * activations nor the action vectors touch HBM.
  *   layer l (0 <= l < n_hidden):  x <- relu(x W_l^T + b_l),  width[l] outputs (a multiple of 16, <= 256)
- *   head:                         v  = act(x W_head^T + b_head),  n_out = n_types + n_devices + n_exploits + n_apps <= 512
+ *   head:                         v  = act(x W_head^T + b_head),  n_out = n_types + n_devices + n_exploits + n_apps <= 8192
+ *                                 (vectors wider than 512 -- more than ~490 devices -- are produced and decoded in chunks of 512)
  * Weights are PACKED in the order the matrix-core fragments read them (cygym_amd.batched_env.pack_linear): for a layer
  * with K inputs and N outputs, [ceil(N / 16)][ceil(K / 16)][64][4] floats with
  *   packed[t][g][lane][i] = W[16 t + lane % 16][16 g + 4 (lane / 16) + i]      (W = nn.Linear.weight [N][K]; 0 outside)

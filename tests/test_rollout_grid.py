@@ -356,7 +356,10 @@ def test_actor_mlp_kernel_equals_torch_forward_plus_decode():
              (64,  (256, 256),    384,  388,    14,     2,      False,  1),
              (37,  (48, 32, 16),  229,  229,    5,      7,      False,  1),      # odd width and stride: dword copies; 3 tiles of 16
              (64,  (128,),        3400, 3400,   4,      0,      False,  1),      # three observation tiles, the last one partial
-             (256, (64, 32),      1536, 1536,   9,      3,      True,   3))
+             (256, (64, 32),      1536, 1536,   9,      3,      True,   3),
+             (600, (32,),         520,  520,    5,      7,      False,  1),      # 614 outputs: decoded in two chunks of 512
+             (1100, (64, 16),     300,  300,    12,     4,      True,   1),      # 1118 outputs: three chunks, the app values in the last
+             (600, (32,),         256,  256,    70,     3,      False,  2))      # more than 64 action types (type map from memory), a population
     for M, widths, K, stride, n_types, n_apps, by_env, S_ in cases:
         topo, init, ck = make_topology(M, 1 if M != 64 else 4, seed=2, n_active=max(8, M - 8))
         cfg = abi.EnvConfig(seed=2, **ck)
@@ -366,7 +369,7 @@ def test_actor_mlp_kernel_equals_torch_forward_plus_decode():
         n_out = n_types + M + X + n_apps
         g = torch.Generator().manual_seed(M + K)
         obs = torch.randint(-1, 3, (N, stride), generator=g).float().to(dev)[:, :K]
-        n = 144 if S_ > 1 else 150
+        n = 48 * S_ if S_ > 1 else 150
         rows = torch.randperm(N, generator=g)[:n].sort().values.to(dev)
         tm = torch.arange(n_types, dtype=torch.int32, device=dev) + 1
         actors = []
@@ -423,12 +426,12 @@ def test_actor_mlp_kernel_equals_torch_forward_plus_decode():
 def test_actor_mlp_builds_the_role_view_on_chip_from_the_state():
     """cygym_actor_mlp.obs_role: the fused actor builds the defender / attacker view of its 16 envs in LDS from the flag plane
     and the static columns instead of reading a view tensor -- same actions as the same actor run on cygym_observe's view
-    (integer weights: exact), at 64 / 256 devices (one tile) and 400 (two tiles, the second one partial), also with rows
+    (integer weights: exact), at 64 / 256 devices (one tile), 400 (two tiles, the second one partial), 600 and 2048 (action vectors wider than 512: decoded in chunks), also with rows
     given by env id and with the per-env anomaly plane of the slow-scan mode."""
     from cygym_amd.batched_env import BatchedCyberDefenseEnv
     from cygym_amd.topology import make_topology
     dev = "cuda:0"
-    for M, N, slow in ((256, 203, False), (64, 96, True), (400, 40, False)):
+    for M, N, slow in ((256, 203, False), (64, 96, True), (400, 40, False), (600, 24, False), (2048, 20, False)):
         topo, init, ck = make_topology(M, 1 if M != 64 else 4, seed=5, n_active=M - 6)
         cfg = abi.EnvConfig(seed=5, **({**ck, "fast_scan": 0} if slow else ck))
         env = BatchedCyberDefenseEnv(topo, cfg, N, init, device=dev, max_groups=1, max_devs=max(4, M // 8), **({"detector": True} if slow else {}))
@@ -440,8 +443,6 @@ def test_actor_mlp_builds_the_role_view_on_chip_from_the_state():
         for role, code, n_types, n_apps in (("defender", 1, 12, 3), ("attacker", 2, 3, 0)):
             K = env.role_width(role)
             n_out = n_types + M + X + n_apps
-            if n_out > 512:
-                continue
             view = env.observe(code)
             assert view.shape == (N, K)
             W1 = torch.randint(-1, 2, (32, K), generator=g).float().to(dev)

@@ -25,7 +25,7 @@ ap.add_argument("--loop-only", action="store_true", help="stop after the timed l
 a = ap.parse_args()
 nD, nA = (int(x) for x in a.grid.split("x"))
 M = a.M
-topo, init, ck = make_topology(M, 1, seed=0, max_extra=0)
+topo, init, ck = make_topology(M, {64: 4, 2048: 32}.get(M, 1), seed=0, max_extra=0)
 cfg = abi.EnvConfig(seed=0, lambda_events=0.0, **ck)
 X = cfg.max_exploits
 dt, at = [1, 4, 5, 6, 7, 8, 9, 11, 12, 13, 2], [1, 2, 3]
