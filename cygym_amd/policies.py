@@ -154,9 +154,14 @@ class ActorPolicyGroup:
     @staticmethod
     def key(p, M):
         """Hashable architecture signature of an ActorPolicy that the group forward can run, or None."""
-        if not isinstance(p, ActorPolicy) or not p.fuse_head or p._split_head(M) is None:
+        if not isinstance(p, ActorPolicy) or not p.fuse_head:
             return None
-        body, last, tanh = p._split_head(M)
+        split = p._split_head(M)
+        if split is None and p.fuse_mlp and p._split_mlp(M) is not None:      # more than 512 outputs: the whole-actor launch only
+            split = p._split_head(M, max_out=8192)
+        if split is None:
+            return None
+        body, last, tanh = split
         sig = []
         for m in body:
             if isinstance(m, nn.Linear):
@@ -225,6 +230,8 @@ class ActorPolicyGroup:
             batch.actor_mlp_decode(rows, obs, hidden, head_p, self.n_types, self.n_exploits, self.n_apps, p0._map(obs.device), act,
                                    epsilon=self.epsilon, tanh=p0._split_mlp(batch.M)[2], n_groups=S)
             return
+        if self.policies[0]._split_head(batch.M) is None:
+            raise ValueError("a population with more than 512 outputs runs through the whole-actor launch only (float32 observations)")
         body, last, tanh = self.policies[0]._split_head(batch.M)
         Ws, bs, Wh, bh = self._stacked(batch)
         x = obs.reshape(S, obs.shape[0] // S, obs.shape[1])

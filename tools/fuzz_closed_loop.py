@@ -62,7 +62,7 @@ def main():
     t0 = time.time()
     for case in range(a.seed0, a.seed0 + a.cases):
         rs = np.random.RandomState(case)
-        M = int(rs.choice([16, 24, 37, 64, 100, 130, 256, 256]))
+        M = int(rs.choice([16, 24, 37, 64, 100, 130, 256, 256, 600]))      # (600: action vectors wider than 512)
         blocks = 4 if M == 64 else 1
         topo, init, ck = make_topology(M, blocks, seed=case, n_active=max(8, M - int(rs.randint(0, M // 4 + 1))), max_extra=int(rs.choice([0, 16])))
         cfg = abi.EnvConfig(seed=case, lambda_events=float(rs.choice([0.0, 0.7])), **ck)
