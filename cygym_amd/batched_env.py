@@ -108,6 +108,8 @@ class BatchedCyberDefenseEnv:
             rc = self.lib.cygym_create(C.byref(t), C.byref(c), self.N, self.device.index or 0, C.byref(self._h))
         _lib.check(rc, None, "cygym_create")
         self.K = self.topo.max_extra
+        self._epoch = 0          # bumped by every launch through this object (_stream): per-env views cache their counter rows against it
+        self._dirty_views = []   # views holding counter writes that have not reached the device yet (env_view.py)
         self.state = _alloc_state(self.N, self.M, self.EW, self.device, self.K, self.detector, self.slow_scan)
         self._scratch = None   # cygym_randomize's shuffle keys, allocated on first use
         self._act_cache = {}   # id(action dict) -> (data pointers, shapes, validated C struct)
@@ -184,7 +186,30 @@ class BatchedCyberDefenseEnv:
         _lib.check(self.lib.cygym_derive(self._h, C.byref(_buffers_struct(st)), self._stream()), self._h, "cygym_derive")
 
     def _stream(self):
+        """The stream argument of a library call.  Every launch passes through here, so this is also where the per-env
+        views' pending counter writes are uploaded (before the launch) and their cached counter rows expire."""
+        if self._dirty_views:
+            self._flush_views()
+        self._epoch += 1
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # `state` is what every consumer (and foreign code) reads the device tensors through: a view's pending counter writes
+    # (env_view.py: `env.step_num = 0` ... held back so that a run of them is ONE upload) are flushed on access.
+    @property
+    def state(self):
+        if self._dirty_views:
+            self._flush_views()
+        self._epoch += 1   # the caller may write through what it gets: cached counter rows expire
+        return self._state
+
+    @state.setter
+    def state(self, st):
+        self._state = st
+
+    def _flush_views(self):
+        views, self._dirty_views = self._dirty_views, []
+        for v in views:
+            v._flush()
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:

@@ -228,6 +228,9 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
     wsync();
     SUBSTAMP(10);
     [[maybe_unused]] int n_rounds = 0;   // read by the stamps of diagnostic builds
+#ifdef CG_STAMPS
+    int dg_full = 0, dg_coop = 0, dg_lost = 0, dg_resc = 0;   // full-row sources, cooperative rows, conflicting takes, rescans in sweeps >= 1
+#endif
     // Sweep 0: every source scans its row from the start and takes its pick.  Sweeps >= 1: a source whose pick an
     // EARLIER source took (the only way to lose one: dc sources and reachable targets never lose) resumes behind it.
     // The sources are in id order and a take only matters to later sources, so within a sweep the blocks run in
@@ -275,6 +278,9 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
             } else {
               coop = true;
             }
+#ifdef CG_STAMPS
+            if (sweep == 0) { dg_full += full ? 1 : 0; dg_coop += coop ? 1 : 0; } else dg_resc += 1;
+#endif
           }
         }
         uint64_t nm = ballot(coop);   // long rows that are not "full": wave-cooperative (re)scan
@@ -338,10 +344,17 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
       // a verification sweep)
       if constexpr (XE) { if (COLD(xany)) { if (spread_x_round(e, T, cur, slist, n_src, sweep) || sweep == 0) lost_any = true; } }
       wsync();
+#ifdef CG_STAMPS
+      dg_lost += lost_any ? 1 : 0;
+#endif
       if (!__any(lost_any)) break;
     }
     SUBSTAMP(11);
     SUBVAL(15, n_rounds);
+#ifdef CG_STAMPS
+    { const int a = wave_sum(dg_full), b = wave_sum(dg_coop), c = wave_sum(dg_lost), d = wave_sum(dg_resc);
+      SUBVAL(16, n_src); SUBVAL(17, a | (b << 16)); SUBVAL(18, c | (d << 16)); }
+#endif
     // apply the compromise flags (:1163-1185) now: T is dead from here on (cntv reuses its storage)
 #pragma nounroll
     for (int c0 = 0; c0 < MC; c0 += GS) {
@@ -454,6 +467,305 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
     wsync();
     SUBSTAMP(13);
     SUBSTAMP(14);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The spread at a compile-time size without added edges (lean kernels, 64 / 256 devices), written against what the launch
+// time of a one-residency-round batch is made of: the slowest env's chain of DEPENDENT LDS round trips (~300 cycles each
+// while all sixteen waves of a CU are alive) and its instruction count (profiles/r04_tail_hist.txt: the spread env that
+// finishes last lives 39 k cycles; a sweep costs 3-6 k).  Same fix point as attacker_spread below -- any processing order
+// reaches it: a sweep without a conflicting take leaves every pick standing -- but:
+//   * the sources are compacted ONCE, straight from the ballots of the flag bytes (no source bitmask round trip);
+//   * lane i of block b owns source b * 64 + i for the whole action: its row bounds, static byte, pick and entry count live
+//     in registers (three VGPRs per block) -- no `cur` / `cntv` arrays, no pass re-reads slist / optr / dst / cur;
+//   * sweep 0 scans a row in stages, two blocks at a time: [source id] -> [row bounds + static byte] -> [first four
+//     neighbours + the row's blocked words] -> [their T words]; a full row (attacker-owned hub: every other device,
+//     ascending) rides in the same stages -- its first candidate comes from the candidate masks (uniform), so its
+//     stage-3 / 4 reads are the blocked word and T word of that one slot;
+//   * a verification sweep (only after a conflict) is ONE round trip for all blocks -- the T words of the picks -- and
+//     only the sources that lost theirs rescan.
+template <int MCT, bool WIDE, class KP>
+__device__ __forceinline__ void attacker_spread_ct(Env& e, const KP& P, const int32_t* expl, int ex0, int n_expl) {
+  const int M = e.M, E1 = P.t.E > 0 ? P.t.E - 1 : 0;
+  const int lane = e.lane;
+  uint32_t* T = e.scr;                          // [Mp] first-compromise time (source id + 1) << 2 | eligibility bits
+  uint16_t* slist = e.lsrc;                     // [Mp] the sources in id order (snapshot :1127)
+  uint64_t* cand = (uint64_t*)e.marks;          // [MC] candidate-device bitmask (LDS copy for the per-lane rescans)
+  // :1127 snapshot of the sources, once per action: compact list in id order
+  int n_src = 0;
+  {
+    uint32_t fj[MCT];
+#pragma unroll
+    for (int c = 0; c < MCT; ++c) fj[c] = e.flags[c * WAVE + lane < M ? c * WAVE + lane : 0];
+#pragma unroll
+    for (int c = 0; c < MCT; ++c) {
+      const int d = c * WAVE + lane;
+      const uint64_t m = ballot(d < M && (fj[c] & (CG_F_COMP | CG_F_OWNED)));
+      if ((m >> lane) & 1ull) slist[n_src + below(m)] = (uint16_t)d;
+      n_src += __popcll(m);
+    }
+  }
+  int zocc = 0;
+  for (int jx = 0; jx < n_expl; ++jx) {
+    int raw = jx == 0 ? ex0 : expl[jx];   // expl[0] was fetched with the tick's header
+    if (P.c.zero_day) {  // :1131-1146
+      uint32_t mask = (uint32_t)P.c.zero_day_owned_mask;
+      bool in = raw >= 0 && raw < 32 && ((mask >> raw) & 1u);
+      if (!in) {
+        int cnt = __popc(mask);
+        if (cnt == 0) continue;
+        int r = (int)cg_index(e.draw(CG_SITE_ZERODAY, zocc++, 0), (uint32_t)cnt);
+        raw = nth_bit32(mask, r);
+      }
+    }
+    if (raw < 0 || raw >= P.t.X) continue;
+    const uint8_t ebit = (uint8_t)(1u << raw);
+    // ---- T words and candidate masks from the flag / vulnerability bytes (device-major, one round trip) ----
+    int u1 = -1, u2 = -1;   // the two lowest candidates (uniform): a full row's first pick is the lowest one that is not itself
+    {
+      uint32_t fj[MCT], vj[MCT];
+#pragma unroll
+      for (int c = 0; c < MCT; ++c) { const int d = c * WAVE + lane, dc = d < M ? d : 0; fj[c] = e.flags[dc]; vj[c] = e.vul[dc]; }
+#pragma unroll
+      for (int c = 0; c < MCT; ++c) {
+        const int d = c * WAVE + lane;
+        const uint32_t f = d < M ? fj[c] : 0u;
+        const uint32_t x = ((f & CG_F_REACH) ? 1u : 0u) | (((f & CG_F_KNOWN) && (vj[c] & ebit)) ? 2u : 0u);
+        uint64_t cm = ballot((x & 1u) || ((x & 2u) && !(f & CG_F_COMP)));
+        T[d] = (((f & CG_F_COMP) ? 0u : T_TIME_INF) << 2) | x;
+        if (lane == 0) cand[c] = cm;
+        if (u1 < 0 && cm) { u1 = c * WAVE + __builtin_ctzll(cm); cm &= cm - 1; }
+        if (u1 >= 0 && u2 < 0 && cm) u2 = c * WAVE + __builtin_ctzll(cm);
+      }
+    }
+    wsync();
+    SUBSTAMP(10);
+    // ---- per-source registers: block b, lane i <-> source b * 64 + i ----
+    uint32_t sst[MCT];   // source id | static byte << 16
+    uint32_t row[MCT];   // o0 | o1 << 16
+    uint32_t pkv[MCT];   // pick: slot k (o1 = none) | target device << 16
+#pragma unroll
+    for (int b = 0; b < MCT; ++b) { sst[b] = 0; row[b] = 0; pkv[b] = 0; }
+    bool lost_any = false;     // some take hit a target another source had taken in this tick: a verification sweep is due
+    constexpr int NS = 4;      // slots staged per row
+    constexpr int BP = (WIDE && MCT >= 2) ? 2 : 1;   // blocks per staged group (two where the registers allow it: the kernels capped at 80 VGPRs spill with two)
+#pragma unroll
+    for (int b0 = 0; b0 < MCT; b0 += BP) {
+      if (b0 * WAVE >= n_src) break;
+      int sv[BP], o0[BP], o1[BP];
+      uint32_t stv[BP];
+      bool act[BP];
+#pragma unroll
+      for (int q = 0; q < BP; ++q) { const int i = (b0 + q) * WAVE + lane; act[q] = i < n_src; sv[q] = slist[act[q] ? i : 0]; }
+#pragma unroll
+      for (int q = 0; q < BP; ++q) { o0[q] = e.optr[sv[q]]; o1[q] = e.optr[sv[q] + 1]; stv[q] = e.dst[sv[q]]; }
+      uint32_t b_lo[BP], b_hi[BP];
+      int vv[BP][NS];
+      int kf[BP], v0[BP];
+      bool full[BP];
+#pragma unroll
+      for (int q = 0; q < BP; ++q) {
+        const int len = o1[q] - o0[q];
+        const bool dc = stv[q] & CG_D_DC;
+        full[q] = len > LONG_ROW && (stv[q] & CG_D_FULLROW) && !dc;
+        v0[q] = u1 == sv[q] ? u2 : u1;                                  // a full row's first candidate ...
+        kf[q] = o0[q] + (v0[q] > 0 ? v0[q] : 0) - (v0[q] > sv[q] ? 1 : 0);   // ... sits at this slot
+        const int base = full[q] ? kf[q] : o0[q];
+        const int w0 = base >> 5, wl = ((P.t.EW + 3) & ~3) - 1;
+        b_lo[q] = e.blk[w0]; b_hi[q] = e.blk[w0 < wl ? w0 + 1 : w0];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) { const int k = o0[q] + j; vv[q][j] = e.ocol[k < E1 ? k : E1]; }
+      }
+      uint32_t tt[BP][NS];
+#pragma unroll
+      for (int q = 0; q < BP; ++q) {
+        if (full[q]) vv[q][0] = v0[q] > 0 ? v0[q] : 0;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) { const int v = vv[q][j] < M ? vv[q][j] : M - 1; tt[q][j] = T[v]; }
+      }
+#pragma unroll
+      for (int q = 0; q < BP; ++q)
+#pragma unroll
+        for (int j = 0; j < NS; ++j) PIN(tt[q][j]);
+#pragma unroll
+      for (int q = 0; q < BP; ++q) {
+        const int s = sv[q];
+        const int len = o1[q] - o0[q];
+        const bool dc = stv[q] & CG_D_DC;
+        const bool shortrow = len <= LONG_ROW;
+        int k = o1[q], v = 0;
+        uint32_t low = 0;
+        if (act[q] && shortrow) {
+          const uint64_t bits = ((uint64_t)b_lo[q] | ((uint64_t)b_hi[q] << 32)) >> (o0[q] & 31);   // bit i <-> slot o0 + i (rows of <= 8 slots)
+          bool found = false;
+#pragma unroll
+          for (int j = 0; j < NS; ++j) {
+            const uint32_t t = tt[q][j];
+            const bool okv = (t & 1u) || ((t & 2u) && ((t >> 2) >= (uint32_t)(s + 1)));
+            if (!found && j < len && !((bits >> j) & 1ull) && (dc || okv)) { found = true; k = o0[q] + j; v = vv[q][j]; low = t & 3u; }
+          }
+          if (!found && len > NS) {   // slots 4..7 of a short row: one by one (few rows are that long)
+            uint64_t b2 = bits >> NS;
+            for (int kk = o0[q] + NS; kk < o1[q]; ++kk, b2 >>= 1) {
+              if (b2 & 1ull) continue;
+              const int vk = e.ocol[kk];
+              const uint32_t tk = T[vk];
+              if (dc || (tk & 1u) || ((tk & 2u) && ((tk >> 2) >= (uint32_t)(s + 1)))) { k = kk; v = vk; low = tk & 3u; break; }
+            }
+          }
+        } else if (act[q] && full[q] && v0[q] >= 0) {
+          const uint32_t t = tt[q][0];
+          const bool okv = (t & 1u) || ((t & 2u) && ((t >> 2) >= (uint32_t)(s + 1)));
+          if (!((b_lo[q] >> (kf[q] & 31)) & 1u) && okv) { k = kf[q]; v = v0[q]; low = t & 3u; }
+          else {   // the lowest candidate is blocked for this hub (or was taken a moment ago): walk on from behind it
+            k = spread_scan_full(e, T, cand, s, kf[q] + 1, o0[q], o1[q]);
+            if (k < o1[q]) { v = (k - o0[q]) + ((k - o0[q]) >= s ? 1 : 0); low = T[v] & 3u; }
+          }
+        }
+        // long rows that are not "full" (e.g. a domain controller with many neighbours): one row at a time, 64 slots per step
+        uint64_t nm = ballot(act[q] && !shortrow && !full[q]);
+        while (nm) {
+          const int sl = __builtin_ctzll(nm);
+          nm &= nm - 1;
+          const int rs = __builtin_amdgcn_readlane(s, sl), ro0 = __builtin_amdgcn_readlane(o0[q], sl), ro1 = __builtin_amdgcn_readlane(o1[q], sl);
+          const bool rdc = __builtin_amdgcn_readlane((int)stv[q], sl) & CG_D_DC;
+          const int kc = spread_scan_coop(e, T, rs, rdc, ro0, ro1);
+          if (lane == sl) { k = kc; if (kc < ro1) { v = e.ocol[kc]; low = T[v] & 3u; } }
+        }
+        if (act[q] && k < o1[q] && spread_take_c(T, v, s, low)) lost_any = true;
+        sst[b0 + q] = (uint32_t)s | (stv[q] << 16);
+        row[b0 + q] = (uint32_t)o0[q] | ((uint32_t)o1[q] << 16);
+        pkv[b0 + q] = (uint32_t)k | ((uint32_t)v << 16);
+      }
+    }
+    wsync();
+    [[maybe_unused]] int n_rounds = 1;   // read by the stamps of diagnostic builds
+    // ---- sweeps >= 1, only while some take reported a conflict: every pick is verified (one round trip for all blocks);
+    // a source whose pick an EARLIER source took rescans from behind it, block after block in ascending order
+    while (__any(lost_any)) {
+      ++n_rounds;
+      lost_any = false;
+      uint32_t tv[MCT];
+#pragma unroll
+      for (int b = 0; b < MCT; ++b) tv[b] = T[pkv[b] >> 16];
+#pragma unroll
+      for (int b = 0; b < MCT; ++b) {
+        if (b * WAVE >= n_src) break;
+        const int s = (int)(sst[b] & 0xFFFFu), o0 = (int)(row[b] & 0xFFFFu), o1 = (int)(row[b] >> 16), k0 = (int)(pkv[b] & 0xFFFFu);
+        const uint32_t st = sst[b] >> 16;
+        const bool dc = st & CG_D_DC;
+        // lost: an earlier source holds the target (reachable targets and dc sources never lose)
+        const bool lost = b * WAVE + lane < n_src && k0 < o1 && !dc && !(tv[b] & 1u) && (tv[b] >> 2) < (uint32_t)(s + 1);
+        if (ballot(lost) == 0ull) continue;
+        const bool shortrow = o1 - o0 <= LONG_ROW;
+        const bool full = !shortrow && (st & CG_D_FULLROW);
+        int k = k0, v = (int)(pkv[b] >> 16);
+        if (lost && (shortrow || full)) {
+          if (shortrow) { k = spread_scan_lane(e, T, s, false, k0 + 1, o1); v = k < o1 ? (int)e.ocol[k] : 0; }
+          else { k = spread_scan_full(e, T, cand, s, k0 + 1, o0, o1); v = k < o1 ? (k - o0) + ((k - o0) >= s ? 1 : 0) : 0; }
+          if (k < o1 && spread_take_c(T, v, s, T[v] & 3u)) lost_any = true;
+        }
+        uint64_t nm = ballot(lost && !shortrow && !full);
+        while (nm) {
+          const int sl = __builtin_ctzll(nm);
+          nm &= nm - 1;
+          const int rs = __builtin_amdgcn_readlane(s, sl), ro1 = __builtin_amdgcn_readlane(o1, sl), rk = __builtin_amdgcn_readlane(k0, sl);
+          const int kc = spread_scan_coop(e, T, rs, false, rk + 1, ro1);
+          if (lane == sl) {
+            k = kc; v = 0;
+            if (kc < ro1) { v = e.ocol[kc]; if (spread_take_c(T, v, rs, T[v] & 3u)) lost_any = true; }
+          }
+        }
+        pkv[b] = (uint32_t)k | ((uint32_t)v << 16);
+        wsync();   // the next block's rescans see these takes
+      }
+    }
+    SUBSTAMP(11);
+    SUBVAL(15, n_rounds);
+    // ---- apply the compromise flags (:1163-1185) ----
+    {
+      uint32_t tj[MCT], fj[MCT];
+#pragma unroll
+      for (int c = 0; c < MCT; ++c) { const int d = c * WAVE + lane, dc = d < M ? d : 0; tj[c] = T[dc]; fj[c] = e.flags[dc]; }
+#pragma unroll
+      for (int c = 0; c < MCT; ++c) {
+        const int d = c * WAVE + lane;
+        if (d < M && (tj[c] >> 2) != T_TIME_INF && (tj[c] >> 2) != 0u) e.flags[d] = (uint8_t)(fj[c] | CG_F_COMP);
+      }
+    }
+    // ---- log entries of every source: the unblocked out-entries up to and including its pick (+ the domain-controller
+    // attribution of that pick, :1163-1168); the counts stay in registers
+    int cnt[MCT];
+    int total_new = 0;
+#pragma unroll
+    for (int b = 0; b < MCT; ++b) {
+      cnt[b] = 0;
+      if (b * WAVE >= n_src) continue;   // (uniform)
+      const int o0 = (int)(row[b] & 0xFFFFu), o1 = (int)(row[b] >> 16), k = (int)(pkv[b] & 0xFFFFu);
+      int n = 0;
+      if (b * WAVE + lane < n_src) {
+        const int end = k < o1 ? k + 1 : o1;
+        n = (end - o0) - (WIDE ? range_popc_wide(e.blk, o0, end) : range_popc(e.blk, o0, end));
+        if (((sst[b] >> 16) & CG_D_DC) && k < o1) cby_or(e, (int)(pkv[b] >> 16), ebit);
+      }
+      cnt[b] = n;
+      total_new += wave_sum(n);
+    }
+    wsync();
+    SUBSTAMP(12);
+    // ring: only the last CG_LOG_RING entries (global order: source id, then row order) matter
+    if (total_new > 0) {
+      const uint32_t base = (uint32_t)e.log_total;
+      const uint32_t end = base + (uint32_t)total_new;
+      const uint32_t lo = end > CG_LOG_RING ? end - CG_LOG_RING : 0;
+      uint32_t after = end;   // global index just past the current block of sources
+#pragma unroll
+      for (int b = MCT - 1; b >= 0; --b) {
+        if (b * WAVE >= n_src) continue;   // (uniform)
+        if (after <= lo) break;
+        const int s = (int)(sst[b] & 0xFFFFu), o0 = (int)(row[b] & 0xFFFFu), o1 = (int)(row[b] >> 16), k = (int)(pkv[b] & 0xFFFFu);
+        const int n = cnt[b];
+        const int incl = wave_incl_scan(n, lane);
+        const int blk_total = __builtin_amdgcn_readlane(incl, 63);
+        const uint32_t cbase = after - (uint32_t)blk_total;
+        const uint32_t off = cbase + (uint32_t)(incl - n);
+        const bool mine = n > 0 && off + (uint32_t)n > lo;
+        const bool is_long = mine && (o1 - o0) > LONG_ROW;
+        const int last = k < o1 ? k : o1 - 1;
+        if (mine && !is_long) {
+          uint32_t idx = off;
+          for (int kk = o0; kk <= last; ++kk) {
+            if (e.blocked(kk)) continue;
+            if (idx >= lo) { e.ring[2 * (idx % CG_LOG_RING)] = (uint16_t)s; e.ring[2 * (idx % CG_LOG_RING) + 1] = e.ocol[kk]; }
+            ++idx;
+          }
+        }
+        uint64_t lm = ballot(is_long);
+        while (lm) {
+          const int ll = __builtin_ctzll(lm);
+          lm &= lm - 1;
+          const int ls = __builtin_amdgcn_readlane(s, ll);
+          uint32_t idx0 = (uint32_t)__builtin_amdgcn_readlane((int)off, ll);
+          const int lo0 = __builtin_amdgcn_readlane(o0, ll), llast = __builtin_amdgcn_readlane(last, ll);
+          for (int k0 = lo0; k0 <= llast; k0 += WAVE) {
+            const int kk = k0 + lane;
+            const bool p = kk <= llast && !e.blocked(kk);
+            const uint64_t m = ballot(p);
+            const uint32_t idx = idx0 + (uint32_t)below(m);
+            if (p && idx >= lo) { e.ring[2 * (idx % CG_LOG_RING)] = (uint16_t)ls; e.ring[2 * (idx % CG_LOG_RING) + 1] = e.ocol[kk]; }
+            idx0 += (uint32_t)__popcll(m);
+          }
+        }
+        after = cbase;
+      }
+      e.log_total = (int)end;
+      e.ring_dirty = true;
+    }
+    wsync();
+    SUBSTAMP(13);
+    SUBSTAMP(14);
+    SUBVAL(16, n_src); SUBVAL(17, 0); SUBVAL(18, 0);
   }
 }
 

@@ -433,6 +433,7 @@ __device__ __forceinline__ void def_per_device(Env& e, const KP& P, int at, cons
       SUBVAL(15, n_pass_all);
       SUBVAL(14, n_act);
       SUBVAL(13, (simple ? 0 : 1) | (xany ? 2 : 0));
+      SUBVAL(16, L);
     }
     cost += -0.5 * n_act * ds;
     fe[CG_D_DEF_COST] += 0.5 * n_act * ds;

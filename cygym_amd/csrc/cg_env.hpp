@@ -27,6 +27,7 @@ struct Env {
   const float *osv, *ver, *ano;
   // in-CSR columns + slot<->entry maps: global memory (L2-resident blob), or LDS in the WIDE kernel; read by block/unblock only
   const uint16_t *icol_g, *ieid_g, *oeid_g;
+  float4* obs_stage; // [192] 3 KB: the observation's LDS stage (WIDE kernel only, see write_obs_staged)
   uint8_t* stash;    // global [4][M] of this env
   // Device.compromised_by: staged in LDS like the other planes (`cby`), or -- run-time sizes, where the per-env LDS
   // footprint decides how many waves a CU holds -- left in global memory (`cby_g`, plane 3 of the env's live block):

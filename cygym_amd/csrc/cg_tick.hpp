@@ -19,6 +19,28 @@ __device__ __forceinline__ float2 ld_ano2(const float2* p, bool vol) {
   return make_float2(q[0], q[1]);
 }
 __device__ __forceinline__ float ld_ano(const float* p, bool vol) { return vol ? *(const volatile float*)p : *p; }
+// How the observation leaves the chip.  0: plain stores (lines stay dirty in the XCD's L2 and are written back when the
+// launch ends: ~1.5 us of a one-tick launch's 3.2 us gap to the next launch, tools/exp_gap.py); 1: non-temporal; 2: sc1
+// (written through as the kernel runs).
+#ifndef CG_OBS_STORE
+#define CG_OBS_STORE 0
+#endif
+typedef float cg_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void obs_store4(float4* p, float4 v) {
+  [[maybe_unused]] const cg_f4v vv = {v.x, v.y, v.z, v.w};
+  [[maybe_unused]] const uint64_t pa = (uint64_t)p;
+#if CG_OBS_STORE == 1
+  __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y); __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);
+#elif CG_OBS_STORE == 2
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(pa), "v"(vv) : "memory");
+#elif CG_OBS_STORE == 3
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(pa), "v"(vv) : "memory");
+#elif CG_OBS_STORE == 4
+  asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(pa), "v"(vv) : "memory");
+#else
+  *p = v;
+#endif
+}
 template <int GP>   // pairs per lane and step
 __device__ __forceinline__ void write_obs(const uint8_t* flags, const float* osv, const float* ver, const float* ano,
                                           float* obs, int M, int lane, bool vol = false) {
@@ -48,9 +70,9 @@ __device__ __forceinline__ void write_obs(const uint8_t* flags, const float* osv
         const int p = p0 + j * WAVE;
         if (p >= npairs) break;
         const uint32_t fa = f2[j] & 0xFFu, fb = f2[j] >> 8;
-        out4[3 * p + 0] = make_float4(o[j].x, v[j].x, (float)(fa & 1u), a[j].x);
-        out4[3 * p + 1] = make_float4((float)((fa >> 2) & 1u), (float)((fa >> 4) & 1u), o[j].y, v[j].y);
-        out4[3 * p + 2] = make_float4((float)(fb & 1u), a[j].y, (float)((fb >> 2) & 1u), (float)((fb >> 4) & 1u));
+        obs_store4(&out4[3 * p + 0], make_float4(o[j].x, v[j].x, (float)(fa & 1u), a[j].x));
+        obs_store4(&out4[3 * p + 1], make_float4((float)((fa >> 2) & 1u), (float)((fa >> 4) & 1u), o[j].y, v[j].y));
+        obs_store4(&out4[3 * p + 2], make_float4((float)(fb & 1u), a[j].y, (float)((fb >> 2) & 1u), (float)((fb >> 4) & 1u)));
       }
     }
   } else {   // odd M: rows are not 16-byte aligned across envs
@@ -66,6 +88,44 @@ __device__ __forceinline__ void write_obs(const uint8_t* flags, const float* osv
 // in LDS -- what cygym_observe computes from global memory in a launch of its own.
 // _get_defender_state (CyberDefenseEnv.py:243-257): rows of not-yet-added or non-attacker-owned devices are all -1,
 // column 2 (isCompromised) is -1 everywhere.  One lane per device PAIR, three 16-byte stores (even M).
+// The observation through an LDS stage (the WIDE per-tick kernel: one 16-wave workgroup per CU, LDS to spare): a one-tick
+// launch leaves its 25 MB of observations dirty in the XCDs' L2s, and writing them back when the launch ends is ~1.5 us of
+// the 3.2 us that separate two launches (tools/exp_gap.py).  Written THROUGH as the kernel runs (sc1) they cost that much
+// less at the end -- but only as whole lines: in the pair-per-lane layout above a store instruction covers 3 KB in 16-byte
+// pieces every 48 bytes, and as partial-line write-throughs that was 20 % slower than the plain stores.  So the three
+// float4 of 64 pairs (3 KB) cross LDS once and leave as three store instructions of 1 KB each, lane after lane.
+__device__ __forceinline__ void write_obs_staged(const uint8_t* flags, const float* osv, const float* ver, const float* ano,
+                                                 float* obs, int M, int lane, float4* stage) {
+  const int npairs = M >> 1;   // (M even: checked by the caller)
+  const uint16_t* F2 = (const uint16_t*)flags;
+  const float2* os2 = (const float2*)osv;
+  const float2* ve2 = (const float2*)ver;
+  const float2* an2 = (const float2*)ano;
+  for (int p0 = 0; p0 < npairs; p0 += WAVE) {
+    const int p = p0 + lane, pc = p < npairs ? p : npairs - 1;
+    const uint32_t f2 = F2[pc];
+    const float2 o = os2[pc], v = ve2[pc], a = an2[pc];
+    const uint32_t fa = f2 & 0xFFu, fb = f2 >> 8;
+    stage[3 * lane + 0] = make_float4(o.x, v.x, (float)(fa & 1u), a.x);
+    stage[3 * lane + 1] = make_float4((float)((fa >> 2) & 1u), (float)((fa >> 4) & 1u), o.y, v.y);
+    stage[3 * lane + 2] = make_float4((float)(fb & 1u), a.y, (float)((fb >> 2) & 1u), (float)((fb >> 4) & 1u));
+    wsync();
+    const int n16 = (npairs - p0 < WAVE ? npairs - p0 : WAVE) * 3;   // 16-byte items of this step
+    float4* out4 = (float4*)obs + 3 * p0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int i = c * WAVE + lane;
+      const float4 w = stage[i < n16 ? i : 0];
+      if (i < n16) {
+        const cg_f4v wv = {w.x, w.y, w.z, w.w};
+        const uint64_t pa = (uint64_t)(out4 + i);
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(pa), "v"(wv) : "memory");
+      }
+    }
+    wsync();
+  }
+}
+
 __device__ __forceinline__ void write_obs_def(const uint8_t* flags, const float* osv, const float* ver, const float* ano,
                                               float* out, int M, int lane, bool vol = false) {
   if (!(M & 1)) {
@@ -117,6 +177,7 @@ __device__ __forceinline__ void write_obs_att(const uint8_t* flags, const float*
   if (lane < max_exploits) out[4 * M + lane] = lane < X ? 1.f : 0.f;
 }
 
+#define CG_OBS_STAGE_BYTES 3072   // 64 pairs x 48 bytes
 struct WaveAux { uint64_t* srcb; int32_t* park; };
 // MAPS: the in-CSR columns and slot maps are staged in LDS too (the WIDE per-tick kernel, one 16-wave workgroup per CU)
 template <bool MAPS, bool RT, class KP>   // RT: run-time size (comp_by may stay in global memory: one plane less in LDS)
@@ -136,6 +197,7 @@ __device__ __forceinline__ WaveAux env_setup(Env& e, uint8_t* smem, const KP& P,
   e.devl = (int16_t*)(e.lsrc + Mp);
   x.park = (int32_t*)(wb + P.wave_lds - 128);   // [16 i32 + 3 f64] per-env scalars between fused ticks
   e.xk = (uint32_t*)(wb + P.wave_lds - 128 - P.t.x_bytes);
+  e.obs_stage = (float4*)(wb + P.wave_lds - 128 - CG_OBS_STAGE_BYTES);   // (WIDE: lean kernel, no extra-edge section; the host adds the bytes)
   e.xb = e.xk + P.t.K;
   e.xmo = (uint64_t*)(e.xb + ((P.t.KW + 1) & ~1));
   e.xmi = e.xmo + MC;

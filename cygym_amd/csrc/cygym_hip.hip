@@ -239,8 +239,9 @@ static int choose_launch_with(cygym_handle* h, int max_devs, int* waves_out) {
   // slot maps in LDS as well, so a speculation pass no longer waits on global memory.  Compile-time size 256, lean only.
   h->wide = false;
   // (its nine-word pool reads cover rows of at most 256 slots: max_row is checked here, there is no fallback in the kernel)
-  if (h->few_waves && t.M == 256 && !full_feature(h) && !forced && h->max_row <= 256 && (size_t)h->o_maps_end + wave * 16 <= lds_cap) {
+  if (h->few_waves && t.M == 256 && !full_feature(h) && !forced && h->max_row <= 256 && (size_t)h->o_maps_end + (wave + CG_OBS_STAGE_BYTES) * 16 <= lds_cap) {
     h->wide = true;
+    h->wave_lds = (int)wave + CG_OBS_STAGE_BYTES;   // + the observation's LDS stage (write_obs_staged)
     h->wpb = 16; h->wpb_fused = 16; h->shared_lds = h->o_maps_end;
     t.lds_bytes = h->o_maps_end; t.in_lds = 1;
   }
@@ -549,6 +550,7 @@ static int launch_ticks(cygym_handle* h, int32_t n_ticks, int32_t env_begin, int
   const dim3 grid((n + wpb - 1) / wpb), block(wpb * WAVE);
   hipStream_t s = (hipStream_t)stream;
   {
+    fill_hot(P);
     void* args[] = {(void*)&P};
     HIPCHK(h, hipLaunchKernel(pick_kernel(h, n_ticks > 1), grid, block, args, (size_t)lds, s));
   }
@@ -626,6 +628,7 @@ int cygym_step_actor(cygym_handle* h, const cygym_actions* a, const cygym_output
     }
   }
   MlpView view = {h->b.live, h->t.os_val, h->t.version, h->t.anomaly, h->b.anomaly, h->t.M, h->t.X, h->c.max_exploits, mlp->obs_role};
+  fill_hot(P);
   void* args[] = {(void*)&P, (void*)mlp, (void*)layout, (void*)next, &view};
   HIPCHK(h, hipLaunchKernel(k, dim3(h->n_envs / 16), dim3(16 * WAVE), args, lds, (hipStream_t)stream));
   HIPCHK(h, hipGetLastError());

@@ -10,9 +10,16 @@ behaviour.  Every tick runs in the HIP kernel; this class only marshals.
     env.mode = "defender"
     state, raw, shaped, done, info, logs = env.step((1, [0], [3, 7], 0))
 
-Batch-wide vs per-env: scalar knobs (`base_line`, `comp_scale`, `work_scale`, ...) live
-in the handle's config and therefore apply to every env of the batch; counters, flags
-and `mode` are per env.
+Batch-wide vs per-env: scalar knobs (`comp_scale`, `work_scale`, ...) and the Philox seed live
+in the handle's config and therefore apply to every env of the batch; counters, flags, `mode`
+and `base_line` are per env -- `env.base_line = ...` (the reference's loops assign it per env and
+turn, do_agent.py:218-221) travels in THIS env's mode word (CG_MODE_BASELINE), so two views of one
+batch driven by two reference loops do not disturb each other.
+
+Host traffic: the counters (`step_num`, `work_done`, ...) of an env are read as ONE row copy that stays
+valid until the batch launches again, and a run of counter writes (the reference zeroes twelve of them
+before a rollout, do_agent.py:192-196, each behind a `hasattr`) is held back and uploaded as one row
+before the next launch or the next access to `batch.state`.
 """
 from __future__ import annotations
 
@@ -57,6 +64,7 @@ _COUNTER_COLS = {
     "edges_added": S.I_EDGES_ADDED,
 }
 _FLOAT_COLS = {"defensive_cost": S.D_DEF_COST, "clearning_cost": S.D_CLEAN_COST}
+_BASELINE_NAMES = {v: k for k, v in abi.BASELINES.items()}
 _CONFIG_ATTRS = {"comp_scale", "work_scale", "def_scale", "lambda_events", "p_add", "p_attacker",
                  "workload_cap", "zero_day", "fast_scan", "scaling_vulnerability"}
 
@@ -67,6 +75,10 @@ class CyberDefenseEnvView:
         object.__setattr__(self, "_i", int(index))
         if not (0 <= self._i < batch.N):
             raise IndexError("env index out of range")
+        object.__setattr__(self, "_base_line", None)    # None: the batch's configured baseline
+        object.__setattr__(self, "_rows", None)         # (batch epoch, ienv row int64, fenv row float64) as last fetched
+        object.__setattr__(self, "_pend_i", {})         # counter writes not uploaded yet: column -> value
+        object.__setattr__(self, "_pend_f", {})
         self.mode = None                     # CyberDefenseEnv.py:31
         self.state = self._get_state()
         self.debug = False
@@ -83,11 +95,18 @@ class CyberDefenseEnvView:
         b = object.__getattribute__(self, "_b")
         i = object.__getattribute__(self, "_i")
         if name in _COUNTER_COLS:
-            return int(b.state["ienv"][i, _COUNTER_COLS[name]].item())
+            col = _COUNTER_COLS[name]
+            pend = object.__getattribute__(self, "_pend_i")
+            return int(pend[col]) if col in pend else int(self._counter_rows()[0][col])
         if name in _FLOAT_COLS:
-            return float(b.state["fenv"][i, _FLOAT_COLS[name]].item())
+            col = _FLOAT_COLS[name]
+            pend = object.__getattribute__(self, "_pend_f")
+            return float(pend[col]) if col in pend else float(self._counter_rows()[1][col])
         if name == "base_line":
-            return b.cfg.baseline
+            own = object.__getattribute__(self, "_base_line")
+            if own is None:
+                own = b.cfg.baseline
+            return own if isinstance(own, str) else _BASELINE_NAMES[int(own)]
         if name in _CONFIG_ATTRS:
             v = getattr(b.cfg, name)
             if name == "workload_cap":
@@ -115,13 +134,17 @@ class CyberDefenseEnvView:
         b = object.__getattribute__(self, "_b")
         i = object.__getattribute__(self, "_i")
         if name in _COUNTER_COLS:
-            b.state["ienv"][i, _COUNTER_COLS[name]] = int(value)
+            self._pend_i[_COUNTER_COLS[name]] = int(value)
+            if self not in b._dirty_views:
+                b._dirty_views.append(self)
         elif name in _FLOAT_COLS:
-            b.state["fenv"][i, _FLOAT_COLS[name]] = float(value)
+            self._pend_f[_FLOAT_COLS[name]] = float(value)
+            if self not in b._dirty_views:
+                b._dirty_views.append(self)
         elif name == "base_line":
             if value not in abi.BASELINES:
                 raise ValueError(f"unknown base_line {value!r}")
-            b.set_config(dataclasses.replace(b.cfg, baseline=value))
+            object.__setattr__(self, "_base_line", value)   # THIS env's: carried in its mode word every tick (_launch)
         elif name in _CONFIG_ATTRS:
             if name == "workload_cap":
                 value = -1 if value is None else int(value)
@@ -137,6 +160,38 @@ class CyberDefenseEnvView:
                 raise ValueError(f"{name} is fixed by the topology of the batch")
         else:
             object.__setattr__(self, name, value)
+
+    # ---- counters: one row copy per batch epoch, writes coalesced ---------------
+    def _counter_rows(self):
+        """(ienv row, fenv row) of this env as numpy arrays: ONE device-to-host copy, reused until the batch launches again
+        (or its `state` is handed out): every launch bumps `batch._epoch`."""
+        b, i = self._b, self._i
+        rows = object.__getattribute__(self, "_rows")
+        if rows is None or rows[0] != b._epoch:
+            st = b._state     # (not `b.state`: that access would expire the row being fetched)
+            pack = torch.cat([st["ienv"][i].double(), st["fenv"][i]]).cpu().numpy()
+            rows = (b._epoch, pack[:S.I_COUNT].astype(np.int64), pack[S.I_COUNT:].copy())
+            object.__setattr__(self, "_rows", rows)
+        return rows[1], rows[2]
+
+    def _flush(self):
+        """Upload the pending counter writes of this env: one row copy per touched table (called by the batch before its
+        next launch and whenever `batch.state` is handed out)."""
+        pi, pf = self._pend_i, self._pend_f
+        if not pi and not pf:
+            return
+        b, i = self._b, self._i
+        ie, fe = self._counter_rows()
+        if pi:
+            for col, v in pi.items():
+                ie[col] = v
+            b._state["ienv"][i].copy_(torch.from_numpy(ie.astype(np.int32)))
+            pi.clear()
+        if pf:
+            for col, v in pf.items():
+                fe[col] = v
+            b._state["fenv"][i].copy_(torch.from_numpy(fe.astype(np.float64)))
+            pf.clear()
 
     # ---- small helpers of the reference -----------------------------------
     def get_num_action_types(self, mode=None):           # volt_typhoon_env.py:514-520
@@ -155,8 +210,29 @@ class CyberDefenseEnvView:
     def get_num_app_indices(self):                       # :528-533 (unique app ids: every device has its own)
         return int(self._b.topo.napps.astype(np.int64).sum())
 
-    def seed(self, seed=None):
+    def seed(self, seed=None):                           # CyberDefenseEnv.py:261-268
+        """The reference seeds the process-global `random` / `numpy.random` streams its tick draws from.  Here the tick's
+        draws are addressed Philox draws keyed by the batch's seed, so this sets THAT seed -- for
+        every env of the batch, from the next tick on (an env keeps its own stream through its env id) -- together with the
+        host streams `sample_action` uses.  seed=None draws one, like gym's seeding helper."""
+        if seed is None:
+            seed = random.SystemRandom().getrandbits(63)
+        seed = int(seed)
+        if seed < 0:
+            raise ValueError("seed must be a non-negative integer")
+        random.seed(seed)
+        np.random.seed(seed & 0xFFFFFFFF)
+        self._b.set_config(dataclasses.replace(self._b.cfg, seed=seed & 0xFFFFFFFFFFFFFFFF))
         return [seed]
+
+    def set_exploit_seed(self, seed: int):               # CyberDefenseEnv.py:65-72
+        object.__setattr__(self, "_exploit_seed", seed)
+        object.__setattr__(self, "_rng", np.random.RandomState(seed))
+
+    def sample_exploits(self):                           # CyberDefenseEnv.py:73-85
+        if not hasattr(self, "_rng"):
+            object.__setattr__(self, "_rng", np.random.RandomState())
+        return self._rng.randint(low=0, high=self.get_num_exploit_indices(), size=(self._b.M,))
 
     def _flags(self) -> np.ndarray:
         return self._b.state["flags"][self._i].cpu().numpy()
@@ -223,6 +299,8 @@ class CyberDefenseEnvView:
         HL.encode_into(row, 0, self.mode, groups, grouped, b.M)
         if partial:
             row["mode"][0] |= S.MODE_PARTIAL
+        # env.base_line of THIS env, this tick (it persists: the view sends it with every tick)
+        row["mode"][0] |= (abi.BASELINES[self.base_line] + 1) << S.MODE_BASELINE_SHIFT
         for k, v in b.act.items():
             v[i:i + 1].copy_(torch.from_numpy(row[k]))
         obs, raw, shaped, done = b.step_range(i, 1)
@@ -230,13 +308,15 @@ class CyberDefenseEnvView:
             b.service_detectors([i])     # Detector.train is synchronous in the reference (volt_typhoon_env.py:961); only THIS env's request
         # ONE device-to-host copy for everything the 6-tuple and `info` need: the observation, the rewards, done and the
         # env's counter rows (all exactly representable in f64), instead of a copy / .item() per field
-        st = b.state
+        st = b._state
+        epoch = b._epoch     # (after service_detectors: it may have changed this env's flag word)
         pack = torch.cat([obs[i].reshape(-1).double(), raw[i:i + 1], shaped[i:i + 1], done[i:i + 1].double(),
                           st["ienv"][i].double(), st["fenv"][i]]).cpu().numpy()      # (.cpu() synchronises with the launch)
         n = 6 * b.M
         self.state = pack[:n].copy()
         self._last_ie = pack[n + 3: n + 3 + S.I_COUNT].astype(np.int64)
         self._last_fe = pack[n + 3 + S.I_COUNT:]
+        object.__setattr__(self, "_rows", (epoch, self._last_ie.copy(), self._last_fe.copy()))   # counter reads until the next launch: no copy
         return float(pack[n]), float(pack[n + 1]), bool(pack[n + 2])
 
     def _info(self, action_taken, executed=None, grouped=False, partial=False):
@@ -279,7 +359,7 @@ class CyberDefenseEnvView:
         if action is None:
             action = HL.default_action(self.mode, self.base_line, self._flags())
         cfg = self._b.cfg
-        norm = HL.validate_single(self.mode, cfg.baseline, action, self._b.M, cfg.n_def_actions, cfg.n_att_actions)
+        norm = HL.validate_single(self.mode, self.base_line, action, self._b.M, cfg.n_def_actions, cfg.n_att_actions)
         raw, shaped, done = self._launch([norm], grouped=False, partial=partial)
         executed = int(self._last_ie[S.I_LAST_ATYPE])
         return self.state, raw, shaped, done, self._info(action, executed, partial=partial), self._logs(self._last_ie[S.I_LOG_TOTAL])

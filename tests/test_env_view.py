@@ -197,3 +197,90 @@ def test_logs_come_from_the_long_history_when_the_batch_keeps_one():
         rec = logs[j - (total - len(logs))]
         assert (rec["from_device"], rec["to_device"], rec["kind"], rec["time_step"]) == (int(f), int(t), "A", 0)
     batch.close()
+
+
+def test_views_of_one_batch_keep_their_own_base_line():
+    """`env.base_line` is a plain attribute of each reference env object, assigned per turn by the rollout loops
+    (do_agent.py:218-221).  Three views of ONE batch under three baselines must reproduce the three single-env fixtures the
+    reference generated with those baselines (same network, env ids 0 / 1 / 2) -- ticking interleaved, none disturbing another."""
+    from cygym_amd.batched_env import BatchedCyberDefenseEnv
+    from cygym_amd.env_view import CyberDefenseEnvView
+    import dataclasses
+    names = ["s16_baselines_no_defense", "s16_baselines_no_attack", "s16_baselines_preset"]
+    fxs = [gio.Fixture(n) for n in names]
+    f0 = fxs[0]
+    for j, fx in enumerate(fxs):      # one shared network, consecutive env ids: the three fixtures ARE one batch
+        assert fx.N == 1 and fx.cfg.env_id_base == j and fx.cfg.seed == f0.cfg.seed
+        for k in ("out_ptr", "out_col", "in_col", "dstatic", "vuln", "os_val"):
+            np.testing.assert_array_equal(getattr(fx.topo, k), getattr(f0.topo, k))
+    init = {k: np.concatenate([fx.init[k] for fx in fxs]) for k in gio.STATE_KEYS}
+    cfg = dataclasses.replace(f0.cfg, baseline="Nash", env_id_base=0)   # the batch's own setting is none of the three
+    L = max(fx.L for fx in fxs)
+    batch = BatchedCyberDefenseEnv(f0.topo, cfg, 3, init, device="cuda:0", max_groups=max(fx.G for fx in fxs), max_devs=L)
+    views = [CyberDefenseEnvView(batch, e) for e in range(3)]
+    bls = ["No Defense", "No Attack", "Preset"]
+    T = min(fx.T for fx in fxs)
+    for t in range(T):
+        for e, (env, fx) in enumerate(zip(views, fxs)):
+            env.mode = fx.mode_name(0, t)
+            env.base_line = bls[e]          # per turn, like the reference loop
+            state, raw, shaped, done, info, logs = env.step(fx.python_action(0, t))
+            np.testing.assert_array_equal(state, fx.exp["obs"][0, t].reshape(-1).astype(np.float64), err_msg=f"{names[e]} t={t}")
+            assert abs(raw - fx.exp["raw"][0, t]) < 1e-9 and abs(shaped - fx.exp["shaped"][0, t]) < 1e-9
+            assert info["executed_atype"] == int(fx.exp["ienv"][0, t][S.I_LAST_ATYPE])
+        got = batch.state_numpy()
+        for e, fx in enumerate(fxs):
+            np.testing.assert_array_equal(got["flags"][e], fx.exp["flags"][0, t].astype(np.uint8))
+            np.testing.assert_array_equal(got["ienv"][e][: S.I_FLAGS], fx.exp["ienv"][0, t][: S.I_FLAGS])
+    assert [v.base_line for v in views] == bls and batch.cfg.baseline == "Nash"
+    batch.close()
+
+
+def test_counters_are_one_row_copy_and_writes_are_coalesced():
+    """The reference zeroes twelve counters before a rollout, each behind a hasattr (do_agent.py:192-196): through the view that
+    is ONE device-to-host row copy and ONE upload before the next launch, and the values land on the device."""
+    from cygym_amd.batched_env import BatchedCyberDefenseEnv
+    from cygym_amd.env_view import CyberDefenseEnvView
+    fx = gio.Fixture("s16_mixed")
+    batch = BatchedCyberDefenseEnv(fx.topo, fx.cfg, fx.N, fx.init, device="cuda:0", max_groups=fx.G, max_devs=fx.L)
+    env, other = CyberDefenseEnvView(batch, 1), CyberDefenseEnvView(batch, 0)
+    for t in range(12):
+        env.mode = fx.mode_name(1, t)
+        env.step(fx.python_action(1, t))
+    assert env.step_num == 12 and env.work_done == int(fx.exp["ienv"][1, 11][S.I_WORK_DONE])
+    fetches = []
+    orig = CyberDefenseEnvView._counter_rows
+
+    def counting(self):
+        before = self._rows
+        out = orig(self)
+        if self._rows is not before:
+            fetches.append(1)
+        return out
+    CyberDefenseEnvView._counter_rows = counting
+    try:
+        attrs = ["step_num", "defender_step", "attacker_step", "work_done", "checkpoint_count", "defensive_cost", "clearning_cost",
+                 "revert_count", "scan_cnt", "compromised_devices_cnt", "edges_blocked", "edges_added"]
+        for a in attrs:
+            if hasattr(env, a):
+                setattr(env, a, 0)
+        assert len(fetches) == 0          # the row the last step brought back served all twelve reads
+        assert env.step_num == 0 and env.defensive_cost == 0.0      # pending writes read back
+        assert int(batch._state["ienv"][1, S.I_STEP_NUM].item()) == 12     # ... not on the device yet
+        ie = batch.state["ienv"][1].cpu().numpy()                          # handing out `state` uploads them
+        assert ie[S.I_STEP_NUM] == 0 and ie[S.I_WORK_DONE] == 0 and float(batch.state["fenv"][1, S.D_DEF_COST].item()) == 0.0
+        assert ie[S.I_RNG_TICK] == int(fx.exp["ienv"][1, 11][S.I_RNG_TICK])     # untouched columns keep their values
+        assert other.step_num == 0 and len(fetches) == 1                      # another view: its own row, one copy
+        env.work_done = 7
+        env.mode = fx.mode_name(1, 12)
+        env.step(fx.python_action(1, 12))                                      # the launch flushes first
+        assert env.step_num == 1 and env.work_done >= 7
+    finally:
+        CyberDefenseEnvView._counter_rows = orig
+    s = env.seed(1234)
+    assert s == [1234] and batch.cfg.seed == 1234
+    env.set_exploit_seed(5)
+    a = env.sample_exploits()
+    env.set_exploit_seed(5)
+    np.testing.assert_array_equal(a, env.sample_exploits())
+    batch.close()
