@@ -22,7 +22,12 @@ EXPORTS = [
 
 
 class CygymError(RuntimeError):
-    pass
+    """`code`: the library's return code (include/cygym_abi.h: CYGYM_EINVAL -1, CYGYM_EHIP -2, CYGYM_EUNSUPPORTED -3,
+    CYGYM_ENOTBOUND -4), None for errors raised on the Python side."""
+    code = None
+
+
+EUNSUPPORTED = -3
 
 
 _lib = None
@@ -80,4 +85,6 @@ def load():
 def check(rc: int, handle=None, what: str = ""):
     if rc != 0:
         msg = load().cygym_last_error(handle)
-        raise CygymError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+        err = CygymError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+        err.code = int(rc)
+        raise err

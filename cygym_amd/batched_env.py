@@ -637,7 +637,7 @@ class BatchedCyberDefenseEnv:
         dst = self.actions_struct(act)
         if role not in ("defender", "attacker"):
             raise ValueError("role must be 'attacker' or 'defender'")
-        n_types = (14 if role == "defender" else self.cfg.max_exploits + 3) if n_types is None else int(n_types)
+        n_types = (14 if role == "defender" else 3) if n_types is None else int(n_types)   # get_num_action_types (volt_typhoon_env.py:514-520): the attacker's no-op (3) lies outside its range
         noop = (8 if role == "defender" else 3) if noop is None else int(noop)
         if types.dim() != 2 or int(types.shape[1]) != self.M or types.device != self.device:
             raise ValueError("types must be an [n, M] integer tensor on the batch's device")

@@ -220,7 +220,7 @@ __device__ __forceinline__ void actor_mlp_body(cygym_actor_mlp ml, const cygym_a
       constexpr int VPS = MLP_STAGE / VWc, NV = VPS * 16 / MLP_THREADS;   // vectors per row and stage; vectors per thread and stage
       typedef float vec_t __attribute__((ext_vector_type(VWc)));
       // (branch-free requests: a row or column outside the source is read from a valid address and replaced by zeros)
-      size_t rbase[NV];
+      uint32_t rbase[NV];   // element offset of the row (32 bits: the host refuses views of 2^32 floats or more)
       bool rok[NV];
   #pragma unroll
       for (int hh = 0; hh < NV; ++hh) {
@@ -232,24 +232,29 @@ __device__ __forceinline__ void actor_mlp_body(cygym_actor_mlp ml, const cygym_a
           ok = ok && orow >= 0 && orow < n_envs;
           orow = ok ? orow : 0;
         }
-        rbase[hh] = (size_t)orow * ml.obs_stride;
+        rbase[hh] = (uint32_t)((size_t)orow * ml.obs_stride);
         rok[hh] = ok;
       }
       for (int kc0 = 0; kc0 < K; kc0 += MLP_KT) {
         const int rem64 = (K - kc0 + 63) & ~63;
         const int kcur = rem64 < kt ? rem64 : kt;   // columns of this tile that hold data (a multiple of 64)
-        vec_t x[MLP_STAGES][NV];
+        // VW == 1 (rows that are only 4-byte aligned: odd strides) holds eight scalars per thread and stage: with all three
+        // stages requested up front it spilled 10-11 VGPRs.  It copies a stage when it consumes it, four scalars at a time.
+        constexpr bool PRE = VW != 1;
+        vec_t x[PRE ? MLP_STAGES : 1][PRE ? NV : 1];
         const int gofs = kc0 >> 4, gw = G0 - gofs, gk = kcur >> 4;
         float4 b0[MLP_NB];
         // Request order = arrival order (the memory counters retire in order): stage 0 of the tile, the weights of stage 0,
         // then the rest of the tile.
   #pragma unroll
         for (int s = 0; s < MLP_STAGES; ++s) {
+          if constexpr (PRE) {
   #pragma unroll
           for (int hh = 0; hh < NV; ++hh) {
             const int col = kc0 + MLP_STAGE * s + VW * ((tid + MLP_THREADS * hh) % VPS);
             const bool in = col < K;   // (a vector that straddles K reads into the row's padding: obs_stride % VW == 0; zeroed below)
-            x[s][hh] = *reinterpret_cast<const vec_t*>(ml.obs + rbase[hh] + (in ? col : 0));   // (zeroed when stored: no wait here)
+            x[s][hh] = *reinterpret_cast<const vec_t*>(ml.obs + (size_t)rbase[hh] + (in ? col : 0));   // (zeroed when stored: no wait here)
+          }
           }
           if (s == 0) {
             __builtin_amdgcn_sched_barrier(0);
@@ -272,6 +277,7 @@ __device__ __forceinline__ void actor_mlp_body(cygym_actor_mlp ml, const cygym_a
               for (int u = 0; u < MLP_NB; ++u) b[u] = b0[u];
             } else
             mlp_b_load<MLP_NB>(b, wp, gofs, G0 - 1, g0, ksplit);   // the stage's first weights fly under the stores and the barrier
+            if constexpr (PRE) {
   #pragma unroll
             for (int hh = 0; hh < NV; ++hh) {
               const int i = tid + MLP_THREADS * hh, trow = i / VPS, c = MLP_STAGE * s + VW * (i % VPS);
@@ -279,6 +285,23 @@ __device__ __forceinline__ void actor_mlp_body(cygym_actor_mlp ml, const cygym_a
   #pragma unroll
               for (int j = 0; j < VW; ++j) v[j] = (kc0 + c + j < K && rok[hh]) ? v[j] : 0.f;
               *reinterpret_cast<vec_t*>(At + trow * kt + ((((c >> 2) ^ trow) << 2) | (c & 3))) = v;
+            }
+            } else {
+              constexpr int HB = NV >= 4 ? 4 : NV;   // scalars in flight per thread
+  #pragma unroll
+              for (int h0 = 0; h0 < NV; h0 += HB) {
+                float y[HB];
+  #pragma unroll
+                for (int h = 0; h < HB; ++h) {
+                  const int col = kc0 + MLP_STAGE * s + ((tid + MLP_THREADS * (h0 + h)) % VPS);
+                  y[h] = ml.obs[(size_t)rbase[h0 + h] + (col < K ? col : 0)];
+                }
+  #pragma unroll
+                for (int h = 0; h < HB; ++h) {
+                  const int i = tid + MLP_THREADS * (h0 + h), trow = i / VPS, c = MLP_STAGE * s + (i % VPS);
+                  At[trow * kt + ((((c >> 2) ^ trow) << 2) | (c & 3))] = (kc0 + c < K && rok[h0 + h]) ? y[h] : 0.f;
+                }
+              }
             }
             __syncthreads();
             MSTAMP(2 + 2 * s);

@@ -18,7 +18,7 @@ __device__ __forceinline__ void dpp_pair_max(uint32_t& hi, uint32_t& lo) {
 #undef CG_PMAX
 }
 __device__ __forceinline__ uint32_t float_order_bits(float x) {   // a < b  <=>  bits(a) < bits(b) (finite values)
-  const uint32_t u = __float_as_uint(x);
+  const uint32_t u = __float_as_uint(x + 0.0f);   // (-0.0 + 0.0 = +0.0: the two zeros tie, like in np.argmax, and the first index wins)
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 // Decode of ONE row by one wave (do_agent.py:970-998), shared by the matrix-core kernels: the row's action vector comes out

@@ -94,33 +94,35 @@ __device__ __forceinline__ void write_obs(const uint8_t* flags, const float* osv
 // less at the end -- but only as whole lines: in the pair-per-lane layout above a store instruction covers 3 KB in 16-byte
 // pieces every 48 bytes, and as partial-line write-throughs that was 20 % slower than the plain stores.  So the three
 // float4 of 64 pairs (3 KB) cross LDS once and leave as three store instructions of 1 KB each, lane after lane.
+// PS pairs (48 bytes each) per step through `stage` (PS * 48 bytes of this wave's LDS): the WIDE kernel owns a 3 KB stage (64
+// pairs: one pair per lane and step).  (Measured and dropped for the other per-tick kernels, which would have to borrow the
+// env's 1.5 KB scratch area -- 32 pairs per step, four steps: 16384 x 256 +-0, 4096 x 64 -3 %, 4096 x 2048 -4 %: their launches are
+// longer or their observations smaller, so the end-of-launch write-back weighs less than the extra LDS passes.)
 __device__ __forceinline__ void write_obs_staged(const uint8_t* flags, const float* osv, const float* ver, const float* ano,
-                                                 float* obs, int M, int lane, float4* stage) {
+                                                 float* obs, int M, int lane, float4* stage, int PS) {
   const int npairs = M >> 1;   // (M even: checked by the caller)
   const uint16_t* F2 = (const uint16_t*)flags;
   const float2* os2 = (const float2*)osv;
   const float2* ve2 = (const float2*)ver;
   const float2* an2 = (const float2*)ano;
-  for (int p0 = 0; p0 < npairs; p0 += WAVE) {
-    const int p = p0 + lane, pc = p < npairs ? p : npairs - 1;
-    const uint32_t f2 = F2[pc];
-    const float2 o = os2[pc], v = ve2[pc], a = an2[pc];
-    const uint32_t fa = f2 & 0xFFu, fb = f2 >> 8;
-    stage[3 * lane + 0] = make_float4(o.x, v.x, (float)(fa & 1u), a.x);
-    stage[3 * lane + 1] = make_float4((float)((fa >> 2) & 1u), (float)((fa >> 4) & 1u), o.y, v.y);
-    stage[3 * lane + 2] = make_float4((float)(fb & 1u), a.y, (float)((fb >> 2) & 1u), (float)((fb >> 4) & 1u));
+  for (int p0 = 0; p0 < npairs; p0 += PS) {
+    for (int q = lane; q < PS; q += WAVE) {
+      const int p = p0 + q, pc = p < npairs ? p : npairs - 1;
+      const uint32_t f2 = F2[pc];
+      const float2 o = os2[pc], v = ve2[pc], a = an2[pc];
+      const uint32_t fa = f2 & 0xFFu, fb = f2 >> 8;
+      stage[3 * q + 0] = make_float4(o.x, v.x, (float)(fa & 1u), a.x);
+      stage[3 * q + 1] = make_float4((float)((fa >> 2) & 1u), (float)((fa >> 4) & 1u), o.y, v.y);
+      stage[3 * q + 2] = make_float4((float)(fb & 1u), a.y, (float)((fb >> 2) & 1u), (float)((fb >> 4) & 1u));
+    }
     wsync();
-    const int n16 = (npairs - p0 < WAVE ? npairs - p0 : WAVE) * 3;   // 16-byte items of this step
+    const int n16 = (npairs - p0 < PS ? npairs - p0 : PS) * 3;   // 16-byte items of this step
     float4* out4 = (float4*)obs + 3 * p0;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const int i = c * WAVE + lane;
-      const float4 w = stage[i < n16 ? i : 0];
-      if (i < n16) {
-        const cg_f4v wv = {w.x, w.y, w.z, w.w};
-        const uint64_t pa = (uint64_t)(out4 + i);
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(pa), "v"(wv) : "memory");
-      }
+    for (int i = lane; i < n16; i += WAVE) {
+      const float4 w = stage[i];
+      const cg_f4v wv = {w.x, w.y, w.z, w.w};
+      const uint64_t pa = (uint64_t)(out4 + i);
+      asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(pa), "v"(wv) : "memory");
     }
     wsync();
   }

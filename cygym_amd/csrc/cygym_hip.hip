@@ -531,6 +531,7 @@ static int launch_ticks(cygym_handle* h, int32_t n_ticks, int32_t env_begin, int
   if (a->max_devs > 32767) return fail(h, CYGYM_EINVAL, "cygym_step: max_devs too large%s", "");
   if (a->max_devs > h->max_devs) {   // the device list lives in LDS: re-plan the launch for a longer list
     if (choose_launch(h, a->max_devs) != 0) return fail(h, CYGYM_EUNSUPPORTED, "device list does not fit in LDS%s", "");
+    HIPCHK(h, hipSetDevice(h->device_id));   // (the attribute belongs to the HANDLE's device, whatever the caller's current one is)
     HIPCHK(h, set_lds_attr(h));
   }
   if (h->c.auto_reset && !h->has_snap) return fail(h, CYGYM_EINVAL, "auto_reset needs cygym_set_snapshot first%s", "");
@@ -580,6 +581,7 @@ int cygym_step_actor(cygym_handle* h, const cygym_actions* a, const cygym_output
     return fail(h, CYGYM_EINVAL, "cygym_step_actor: bad action / output tensors%s", "");
   if (a->max_devs > h->max_devs) {   // the device list lives in LDS: re-plan the launch for a longer list (as cygym_step does)
     if (choose_launch(h, a->max_devs) != 0) return fail(h, CYGYM_EUNSUPPORTED, "device list does not fit in LDS%s", "");
+    HIPCHK(h, hipSetDevice(h->device_id));
     HIPCHK(h, set_lds_attr(h));
   }
   // the shape both halves share: the lean WIDE per-tick kernel (256 devices, one 16-wave workgroup per CU = 16 envs) over the whole batch
@@ -819,6 +821,8 @@ int cygym_actor_mlp_decode(cygym_handle* h, const cygym_actor_mlp* mlp, const cy
   if (src->epsilon_thr && !h->bound) return fail(h, CYGYM_ENOTBOUND, "cygym_actor_mlp_decode: epsilon > 0 needs a bound handle%s", "");
   if (mlp->n_groups > 1 && (mlp->rows_per_group < 16 || (mlp->rows_per_group & 15)))   // (row r: actor (r / rows_per_group) % n_groups)
     return fail(h, CYGYM_EINVAL, "cygym_actor_mlp_decode: rows_per_group must be a multiple of 16%s", "");
+  if (!mlp->obs_role && (unsigned long long)(mlp->obs_by_env ? h->n_envs : src->n) * (unsigned long long)mlp->obs_stride >= (1ull << 32))
+    return fail(h, CYGYM_EUNSUPPORTED, "cygym_actor_mlp_decode: observation matrices of 2^32 floats or more%s", "");   // (32-bit row offsets in the kernel)
   if (src->n == 0) return CYGYM_OK;
   HIPCHK(h, hipSetDevice(h->device_id));
   const bool wide_out = n_out > (long long)HEAD_OPL_MAX * WAVE;   // wider than 512: produced and decoded in chunks of 512 outputs

@@ -31,7 +31,9 @@ class Transitions:
     action_vec: torch.Tensor   # [T, N, n_out] the clipped noisy action vector that was decoded
     reward: torch.Tensor       # [T, N] float64 shaped reward (the third return of env.step)
     raw_reward: torch.Tensor   # [T, N] float64
-    next_state: torch.Tensor   # [T, N, W] the learner's view right after its own step
+    next_state: torch.Tensor   # [T, N, W] the learner's view right after its own step.  On a row whose step reported `done` (batches
+                               # with auto_reset) this is the view of the RELOADED state -- the tick writes the view of what it leaves behind
+                               # -- where the reference pushes the terminal state's view; `done` masks the bootstrap term either way
     done: torch.Tensor         # [T, N] bool
     noise_std: float           # where the exploration schedule ended
 

@@ -178,7 +178,7 @@ def collect(batch, role: str, net, opponent, n_decisions: int, *, greedy: bool =
         _, raw, shaped, done = batch.step(act, view=nxt, full_obs=False)
         if turn == role:
             rec["state"].append(state_rec); rec["logp"].append(logp); rec["value"].append(out["value"].reshape(N).float())
-            rec["reward"].append(shaped.to(torch.float32).nan_to_num(0.0, 0.0, 0.0).clamp(-1e6, 1e6)); rec["raw_reward"].append(raw.clone())
+            rec["reward"].append(torch.where(torch.isfinite(shaped), shaped, raw.nan_to_num(0.0, 0.0, 0.0)).to(torch.float32).clamp(-1e6, 1e6)); rec["raw_reward"].append(raw.clone())   # (IPPO.py:575-581: a non-finite shaped reward falls back to nan_to_num(raw))
             rec["done"].append(done != 0); rec["per_dev_types"].append(types); rec["exp"].append(exp_i); rec["app"].append(app_i)
             rec["vis_mask"].append(vis)
         s += 1

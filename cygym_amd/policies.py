@@ -35,13 +35,14 @@ class ActorPolicy:
         """(body modules, last nn.Linear, tanh?) when the actor is a Sequential ending in Linear [+ Tanh] that the fused
         head kernel can take (cygym_actor_head_decode: H <= 256, <= 512 outputs), else None.  Cached per output limit."""
         cache = self.__dict__.setdefault("_heads", {})
+        max_out = (int(M), max_out, id(self.net))   # (the split depends on the device count and on WHICH net: a policy may serve several batches)
         if max_out not in cache:
             cache[max_out] = None
             if isinstance(self.net, nn.Sequential) and len(self.net) >= 2:
                 mods = list(self.net)
                 tanh = isinstance(mods[-1], nn.Tanh)
                 last = mods[-2] if tanh else mods[-1]
-                if isinstance(last, nn.Linear) and last.in_features <= 256 and last.out_features <= max_out \
+                if isinstance(last, nn.Linear) and last.in_features <= 256 and last.out_features <= max_out[1] \
                         and last.out_features == self.n_types + M + self.n_exploits + self.n_apps and last.weight.dtype == torch.float32:
                     cache[max_out] = (type(self.net)(*mods[: -2 if tanh else -1]), last, tanh)
         return cache[max_out]
@@ -50,8 +51,10 @@ class ActorPolicy:
         """(hidden nn.Linear layers, last nn.Linear, tanh?) when the WHOLE actor is a Linear-ReLU stack the fused actor kernel
         can take (cygym_actor_mlp_decode: 1 to 3 hidden layers, widths multiples of 16 up to 256, <= 8192 outputs -- vectors wider
         than 512 are decoded in chunks), else None."""
-        if not hasattr(self, "_mlp"):
-            self._mlp = None
+        cache = self.__dict__.setdefault("_mlps", {})
+        key = (int(M), id(self.net))   # (per device count and net: a policy may serve batches of different sizes, or get a new net)
+        if key not in cache:
+            cache[key] = None
             head = self._split_head(M, max_out=8192)
             if head is not None:
                 body, last, tanh = head
@@ -60,13 +63,13 @@ class ActorPolicy:
                 if (len(mods) % 2 == 0 and 1 <= len(lins) <= 3 and all(isinstance(m, nn.ReLU) for m in mods[1::2])
                         and all(isinstance(m, nn.Linear) and m.weight.dtype == torch.float32 and m.out_features % 16 == 0
                                 and 16 <= m.out_features <= 256 for m in lins)):
-                    self._mlp = (lins, last, tanh)
-        return self._mlp
+                    cache[key] = (lins, last, tanh)
+        return cache[key]
 
     def _packed(self, batch, M):
         """Fragment-ordered copies of the actor's weights (batch.pack_linear), redone when a parameter changes."""
         lins, last, tanh = self._split_mlp(M)
-        ver = tuple((m.weight._version, m.weight.data_ptr(), None if m.bias is None else m.bias._version) for m in lins + [last])
+        ver = (int(M),) + tuple((m.weight._version, m.weight.data_ptr(), None if m.bias is None else m.bias._version) for m in lins + [last])
         if getattr(self, "_pk_ver", None) != ver:
             self._pk = ([(batch.pack_linear(m.weight), None if m.bias is None else m.bias.detach().contiguous(), m.out_features) for m in lins],
                         (batch.pack_linear(last.weight, 64), None if last.bias is None else last.bias.detach().contiguous()))

@@ -33,7 +33,7 @@ import torch
 
 from . import abi
 from . import host_logic as HL
-from ._lib import CygymError as _CygymError
+from ._lib import CygymError as _CygymError, EUNSUPPORTED as _EUNSUPPORTED
 from . import sharding
 from . import spec as S
 
@@ -391,7 +391,7 @@ def simulate_grid(batch, def_policies, att_policies, n_mc: int, T: int, randomiz
                 p.write_by_env(batch, acts[nxt], None, None, nxt, step={"act": act, "view": None, "full_obs": False, "returns": True}, **kw)
                 pending[nxt] = True
             except _CygymError as exc:      # (the handle's launch plan does not have the shared shape after all: two launches)
-                if "cygym_step_actor" not in str(exc):
+                if getattr(exc, "code", None) != _EUNSUPPORTED:      # (anything but "this launch shape is not available" is an error)
                     raise
                 carried[HL.DEFENDER] = carried[HL.ATTACKER] = False
                 batch.step_range(lo, hi - lo, act, view=nxt if needs_view[nxt] else None, full_obs=False, returns=True)

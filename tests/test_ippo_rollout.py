@@ -111,6 +111,12 @@ def test_group_actions_kernel_equals_the_numpy_grouping():
         a = {k: v.cpu().numpy() for k, v in small.act.items()}
         assert (a["n_groups"] == 2).all() and (a["dev_cnt"].sum(axis=1) <= 4).all()
         small.close()
+        # the attacker's default: exactly its 3 action types (get_num_action_types('attacker') == 3; the no-op, 3, lies outside):
+        # type ids above 2 in a caller's tensor must never be grouped and stepped as attacker actions
+        types = (torch.arange(M) % 7)[None, :].repeat(N, 1)
+        env.group_actions(None, types.to("cuda:0"), None, None, "attacker", visible=torch.ones((N, M), dtype=torch.uint8, device="cuda:0"))
+        a = {k: v.cpu().numpy() for k, v in env.act.items()}
+        assert (a["n_groups"] == 3).all() and sorted(set(a["atype"][:, :3].reshape(-1).tolist())) == [0, 1, 2]
         env.close()
 
 
