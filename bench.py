@@ -58,7 +58,20 @@ DEFAULT_SUB = {"target": 1, "cfg2": 1, "cfg3": 2, "cfg4": 2, "cfg5": 4}
 DEFAULT_MAX_EXTRA = {"target": 0, "cfg2": 0, "cfg3": 0, "cfg4": 0, "cfg5": -1}
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PMC_SUMMARY = "r03_pmc_summary.json"   # profiles/: per workload and kernel class, bytes per launch from the --pmc passes
+PMC_SUMMARY = "r04_pmc_summary.json"   # profiles/: per workload and kernel class, bytes per launch from the --pmc passes
+REFERENCE_PYTHON = "r04_reference_python.json"   # profiles/: the reference's own step() timed in the build container
+
+
+def kernel_source_hash() -> str:
+    """sha256 over the kernel sources (cygym_amd/csrc/*, include/*.h), 16 hex digits: the PMC summary under profiles/ carries the
+    hash of the kernels it was collected on, and `roofline.traffic` is only filled in from it when this run's kernels are the same."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "cygym_amd", "csrc", "*")) + glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def algorithmic_bytes(M: int, E: int) -> float:
@@ -103,6 +116,31 @@ class Dist:
                 dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
             else:
                 dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
+
+    def identity(self):
+        """What every rank saw, gathered on all ranks: rank, local rank, device index, the device's uuid / PCI bus id, the
+        backend and the world size IT reports -- so that "N ranks on N distinct devices over RCCL" is checkable from the
+        bench line.  Distinct devices are REQUIRED unless CYGYM_BENCH_SAME_GPU=1 (the one-GPU rehearsal)."""
+        torch, dist = self.torch, self.dist
+        p = torch.cuda.get_device_properties(self.dev)
+        parts = [f"name={p.name}"]
+        for attr in ("uuid", "pci_domain_id", "pci_bus_id", "pci_device_id"):   # (whichever this torch build exposes)
+            v = getattr(p, attr, None)
+            if v is not None:
+                parts.append(f"{attr}={v}")
+        dev_id = "|".join(parts)
+        me = {"rank": self.rank, "local_rank": self.local_rank, "device_index": self.dev.index, "device": dev_id or "unknown",
+              "backend": (dist.get_backend() if self.world > 1 else "none"), "world_size_reported": (dist.get_world_size() if self.world > 1 else 1)}
+        ranks = [me]
+        if self.world > 1:
+            ranks = [None] * self.world
+            dist.all_gather_object(ranks, me)
+        distinct = len({(r["device_index"], r["device"]) for r in ranks}) == len(ranks)
+        same_ok = os.environ.get("CYGYM_BENCH_SAME_GPU") == "1"
+        if self.world > 1 and not distinct and not same_ok:
+            raise RuntimeError(f"ranks share a device: {ranks} (set CYGYM_BENCH_SAME_GPU=1 only for the one-GPU rehearsal)")
+        return {"ranks": ranks, "distinct_devices": distinct, "same_gpu_rehearsal": same_ok,
+                "collectives": "barrier + MAX all_reduce of the timings + one all_gather of per-env returns; none on the step path"}
 
     def barrier(self):
         self.torch.cuda.synchronize(self.dev)
@@ -209,7 +247,7 @@ def run_workload(D: Dist, name, n_per_gpu, K, W, reps, sub, fused_T, seed, max_e
 
     def leg(issue, launches_per_tick, what):
         wall, ev, walls = timed_reps(D, env, keep, reps, issue)
-        r = roofline_block(N * B, ev / K, "step_kernel<WPB, M, FUSED=0, ..>", 1)
+        r = roofline_block(N * B, ev / K, "step_kernel<WPB, M, FUSED=0, ..>", 1, wall / K)
         r["launches_per_tick"] = launches_per_tick
         return {"what": what, "value": total_envs * K / wall, "unit": "env-steps/s", "ms_per_step": wall / K * 1e3,
                 "sub_batches": launches_per_tick, "reps": reps, "rep_spread": [min(walls) / K * 1e3, max(walls) / K * 1e3],
@@ -245,8 +283,8 @@ def run_workload(D: Dist, name, n_per_gpu, K, W, reps, sub, fused_T, seed, max_e
                 env.rollout(act, out, check=False)    # asynchronous form; the status word is read once, after the timed region
         wall, ev, walls = timed_reps(D, env, keep, reps, fused)
         n_launch = len(chunks)
-        r = roofline_block(N * B * K / n_launch, ev / n_launch, "step_kernel<WPB, M, FUSED=1, ..>", K / n_launch)
-        r["frac_without_state_term"] = (N * (B - state_term_bytes(M)) * K / n_launch) / (ev / n_launch) / 1e9 / HBM_PEAK_GBS
+        r = roofline_block(N * B * K / n_launch, ev / n_launch, "step_kernel<WPB, M, FUSED=1, ..>", K / n_launch, wall / n_launch)
+        r["frac_without_state_term"] = (N * (B - state_term_bytes(M)) * K / n_launch) / (max(ev, wall) / n_launch) / 1e9 / HBM_PEAK_GBS
         rollout = {"what": f"cygym_rollout: {T} ticks per launch (open loop, pre-staged action script; state on chip between "
                            "ticks; every tick's obs / reward / done written to HBM)",
                    "value": total_envs * K / wall, "unit": "env-steps/s", "ms_per_step": wall / K * 1e3, "reps": reps,
@@ -273,9 +311,20 @@ def attach_traffic(rec, name, n_envs):
     run's launch shape; `frac_traffic` = those bytes / launch time / peak."""
     pmc = os.path.join(ROOT, "profiles", PMC_SUMMARY)
     if not os.path.exists(pmc):
+        for leg in (rec["per_tick_stepping"], rec["fused_rollout"]):
+            if leg is not None:
+                leg["roofline"]["traffic_source"] = f"none: profiles/{PMC_SUMMARY} is missing (tools/profile_all.sh collects it)"
         return
     try:
-        c = json.load(open(pmc)).get(name)
+        summary = json.load(open(pmc))
+        have, want = summary.get("kernel_source_hash"), kernel_source_hash()
+        if have != want:   # counters of OTHER kernels say nothing about this run: leave traffic / frac_traffic null and say why
+            for leg in (rec["per_tick_stepping"], rec["fused_rollout"]):
+                if leg is not None:
+                    leg["roofline"]["traffic_source"] = (f"none: profiles/{PMC_SUMMARY} was collected on kernels {have}, this run's are {want} "
+                                                         "(re-run tools/profile_all.sh)")
+            return
+        c = summary.get(name)
         # (the summary counts WAVES per launch: the env count rounded up to whole workgroups of up to 16 waves)
         if not c or not (n_envs <= c.get("envs_per_launch", -1) < n_envs + 16):
             return
@@ -287,16 +336,24 @@ def attach_traffic(rec, name, n_envs):
             for r in [leg["roofline"]] + ([leg["single_launch"]["roofline"]] if "single_launch" in leg else []):
                 r["traffic"] = per_tick_bytes * r["ticks_per_launch"]
                 r["traffic_unit"] = "bytes per tick of the whole batch" if key == "per_tick" else "bytes per launch"
-                r["frac_traffic"] = r["traffic"] / (r["launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
-                r["traffic_source"] = f"profiles/{PMC_SUMMARY} (rocprofv3 --pmc passes, tools/rocprof_summary.py)"
+                t_us = max(r["launch_us"], r.get("launch_us_wall") or 0.0)   # the slower clock, like the headline fraction
+                r["frac_traffic"] = r["traffic"] / (t_us * 1e-6) / 1e9 / HBM_PEAK_GBS
+                r["traffic_source"] = f"profiles/{PMC_SUMMARY} (rocprofv3 --pmc passes of this same command on kernels {want}, tools/rocprof_summary.py)"
     except Exception as e:   # a malformed summary must not break the bench line
         print(f"[bench] warning: could not read {pmc}: {e}", file=sys.stderr)
 
 
-def roofline_block(bytes_per_launch, launch_s, kernel, ticks_per_launch):
-    achieved = bytes_per_launch / launch_s / 1e9
-    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+def roofline_block(bytes_per_launch, launch_s, kernel, ticks_per_launch, wall_s=None):
+    """`launch_s`: average time per launch from HIP events around the timed region (on the launch stream); `wall_s`: the same
+    region on the host clock (what `ms_per_step` is made of: it also holds the final synchronisation).  The HEADLINE fraction is
+    the lower of the two; both are given."""
+    ev_frac = bytes_per_launch / launch_s / 1e9 / HBM_PEAK_GBS
+    wall_frac = bytes_per_launch / wall_s / 1e9 / HBM_PEAK_GBS if wall_s else None
+    frac = min(ev_frac, wall_frac) if wall_frac is not None else ev_frac
+    return {"bound": "hbm", "achieved": frac * HBM_PEAK_GBS, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac,
+            "frac_hip_events": ev_frac, "frac_on_ms_per_step": wall_frac,
             "traffic": None, "frac_traffic": None, "kernel": kernel, "launch_us": launch_s * 1e6,
+            "launch_us_wall": wall_s * 1e6 if wall_s else None,
             "ticks_per_launch": ticks_per_launch, "algorithmic_bytes_per_launch": bytes_per_launch}
 
 
@@ -343,7 +400,27 @@ def gathered_returns_check(D: Dist, env, scripts, topo, init, cfg, L, n_check=64
     return ok
 
 
-def cpu_baseline(topo, init, cfg, M, L, scripts, W, budget_s):
+def reference_python_block(M):
+    """The reference's own Python step(), as timed in the BUILD CONTAINER (oracle/harness/time_reference.py: the reference
+    cannot travel to the GPU box), from profiles/: machine and core count named there.  A baseline, not the target."""
+    path = os.path.join(ROOT, "profiles", REFERENCE_PYTHON)
+    try:
+        d = json.load(open(path))
+        row = d["by_devices"].get(str(M))
+        if row is None:
+            return None
+        return {"value": row["steps_per_s_8_processes"], "unit": "env-steps/s", "cores": 8, "kind": "reference",
+                "single_process": row["steps_per_s_1_process"], "machine": d["machine"], "measured": d["measured"],
+                "sample": f"unmodified reference step() at {M} devices, alternating random defender / attacker actions; 8 processes "
+                          "x 6 s each and one process x 6 s (oracle/harness/time_reference.py)",
+                "note": "NOT the GPU box's host: the reference stays in the build container; " + d["what"],
+                "source": f"profiles/{REFERENCE_PYTHON}"}
+    except Exception as e:
+        print(f"[bench] warning: could not read {path}: {e}", file=sys.stderr)
+        return None
+
+
+def cpu_baseline(topo, init, cfg, M, L, scripts, W, budget_s, max_threads=16):
     """The CPU oracle (C restatement) on a bounded sample of the same workload: the first n envs per thread,
     replaying the same pre-generated script from the initial state until the time budget is spent.  Two legs,
     half the budget each: one thread, then one thread per host core of this process's CPU share (envs are
@@ -358,7 +435,9 @@ def cpu_baseline(topo, init, cfg, M, L, scripts, W, budget_s):
         share = len(os.sched_getaffinity(0))
     except AttributeError:
         share = os.cpu_count() or 1
-    threads = max(1, min(share, 16, n_all // per))
+    # `max_threads` (--cpu-threads, default 16): the GPU box grants a one-GPU job a 16-CPU share (its process guard kills jobs that
+    # start more workers than that), whatever sched_getaffinity reports -- so "all cores" here means all cores of the share
+    threads = max(1, min(share, max_threads, n_all // per))
 
     def leg(n_thr, seconds):
         n = per * n_thr
@@ -386,7 +465,11 @@ def cpu_baseline(topo, init, cfg, M, L, scripts, W, budget_s):
     out = {"value": v1, "unit": "env-steps/s", "cores": 1, "kind": "port",
            "sample": f"oracle/cygym_oracle.c, 1 thread: first {n1} envs x {len(scripts)} ticks of the same script, "
                      f"replayed {r1}x ({s1} env-steps in {d1:.1f} s)",
-           "host_cores_available": share}
+           "host_cores_visible": share, "cores_cap": max_threads,
+           "cores_cap_reason": "the GPU box's CPU share for a one-GPU job (16); sched_getaffinity still lists every core of the host"}
+    ref = reference_python_block(M)
+    if ref is not None:
+        out["reference_python"] = ref
     if threads > 1:
         vt, nt, rt, st, dt = leg(threads, budget_s / 2)
         out["single_thread"] = {"value": v1, "cores": 1, "sample": out["sample"]}
@@ -616,6 +699,7 @@ def main():
                          "whose sparse topology has ONE star hub: once a defender takes it out the next evolve re-links "
                          "the star with added edges, so that workload runs with the list (-1)")
     ap.add_argument("--cpu-seconds", type=float, default=16.0)
+    ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the CPU baseline's all-cores leg (the GPU box's CPU share for one GPU is 16)")
     ap.add_argument("--fused", type=int, default=-1,
                     help="ticks per cygym_rollout launch (-1 = all K steps in one launch, 0 = skip the rollout leg)")
     ap.add_argument("--headline", default="per_tick", choices=["per_tick", "rollout"],
@@ -661,6 +745,9 @@ def main():
         bw = measured_copy_gbs(D.dev)
         out["roofline"]["measured_copy_peak"] = bw
         out["roofline"]["frac_of_measured_copy"] = out["roofline"]["achieved"] / bw if bw else None
+    ident = D.identity()       # (a collective when N > 1: every rank calls it)
+    if D.world > 1:
+        out["ranks"] = ident
     if D.world > 1:
         # end-of-rollout gather of per-env returns over RCCL, checked against a single-rank recomputation:
         # restart from the initial state and run the first W + 4 ticks on every rank
@@ -670,7 +757,7 @@ def main():
             env.step(scripts[t])
         out["check"]["gathered_returns_match_single_rank"] = gathered_returns_check(D, env, scripts[:n_ticks], topo, init, cfg, L)
     if D.rank == 0 and D.world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(topo, init, cfg, M, L, scripts, W, args.cpu_seconds)
+        out["cpu_baseline"] = cpu_baseline(topo, init, cfg, M, L, scripts, W, args.cpu_seconds, args.cpu_threads)
     st = env.take_status()
     out["check"]["status_word"] = {"unpinned_scan": bool(st & 0x200), "busy_saturated": bool(st & 0x40)}
     env.close()

@@ -10,24 +10,48 @@ constexpr int LONG_ROW = 8;
 
 // T[v] = (first-compromise time << 2) | eligibility bits (bit0 reachable, bit1 known & vulnerable to this
 // exploit): one LDS word answers "can source s take v".  atomicMin keeps the (constant) low bits intact.
+// The word is 32 bits at the compile-time sizes and 16 bits at run-time sizes (times <= 2049 there: M <= 2048), where the
+// table's 4 KB decide whether a CU holds four or five envs of 2048 devices with an extra-edge list: LDS has no 16-bit
+// atomic minimum, so a take is a compare-and-swap loop on the 32-bit word that holds the entry.
 #define T_TIME_INF 0x3FFFFFFFu
-__device__ __forceinline__ bool spread_ok(const uint32_t* T, int v, int s) {
+template <bool RT> struct TWord { using type = uint32_t; };
+template <> struct TWord<true> { using type = uint16_t; };
+template <class TW> __device__ __forceinline__ constexpr uint32_t t_inf() { return sizeof(TW) == 2 ? 0x3FFFu : T_TIME_INF; }
+template <class TW>
+__device__ __forceinline__ bool spread_ok(const TW* T, int v, int s) {
   const uint32_t t = T[v];
   return (t & 1u) || ((t & 2u) && ((t >> 2) >= (uint32_t)(s + 1)));
 }
-__device__ __forceinline__ void spread_take(uint32_t* T, int v, int s) {
-  atomicMin(&T[v], ((uint32_t)(s + 1) << 2) | (T[v] & 3u));
+// minimum into T[v]; returns the old entry
+__device__ __forceinline__ uint32_t t_min(uint32_t* T, int v, uint32_t val) { return atomicMin(&T[v], val); }
+__device__ __forceinline__ uint32_t t_min(uint16_t* T, int v, uint32_t val) {
+  uint32_t* w = (uint32_t*)(T + (v & ~1));
+  const int sh = (v & 1) * 16;
+  uint32_t old = *w;
+  for (;;) {
+    const uint32_t cur = (old >> sh) & 0xFFFFu;
+    if (cur <= val) return cur;
+    const uint32_t prev = atomicCAS(w, old, (old & ~(0xFFFFu << sh)) | (val << sh));
+    if (prev == old) return cur;
+    old = prev;
+  }
+}
+template <class TW>
+__device__ __forceinline__ void spread_take(TW* T, int v, int s) {
+  t_min(T, v, ((uint32_t)(s + 1) << 2) | ((uint32_t)T[v] & 3u));
 }
 // A take that reports whether `v` had ALREADY been taken by another source in this tick (its old time is neither "never"
 // nor "compromised before the action"): one of the two then holds a pick the other one overrides -- a conflict that a
 // verification sweep has to settle.  A sweep without a single conflict leaves every pick standing: it IS the fix point,
 // no confirming sweep needed (see attacker_spread).
-__device__ __forceinline__ bool spread_take_c(uint32_t* T, int v, int s, uint32_t low) {
-  const uint32_t old = atomicMin(&T[v], ((uint32_t)(s + 1) << 2) | low) >> 2;
-  return old != T_TIME_INF && old != 0u;
+template <class TW>
+__device__ __forceinline__ bool spread_take_c(TW* T, int v, int s, uint32_t low) {
+  const uint32_t old = t_min(T, v, ((uint32_t)(s + 1) << 2) | low) >> 2;
+  return old != t_inf<TW>() && old != 0u;
 }
 // first slot k in [from, o1) that source s can take, or o1
-__device__ __forceinline__ int spread_scan_lane(const Env& e, const uint32_t* T, int s, bool dc,
+template <class TW>
+__device__ __forceinline__ int spread_scan_lane(const Env& e, const TW* T, int s, bool dc,
                                                 int from, int o1) {
   if (from >= o1) return o1;
   // the row (<= LONG_ROW slots) spans at most two words of the blocked bitmask: read them once, not per slot
@@ -44,7 +68,8 @@ __device__ __forceinline__ int spread_scan_lane(const Env& e, const uint32_t* T,
 // The same with v / low = the device and the constant low bits of T[v], STAGED (run-time sizes, where one resident wave
 // per SIMD leaves every LDS round trip exposed; at 256 devices with 4 waves per SIMD it measured -1 %): the row's blocked words and its first four neighbours are read together, then the four T words -- two LDS
 // round trips for the usual two- or three-slot row instead of two per slot.
-__device__ __forceinline__ int spread_scan_lane_st(const Env& e, const uint32_t* T, int s, bool dc,
+template <class TW>
+__device__ __forceinline__ int spread_scan_lane_st(const Env& e, const TW* T, int s, bool dc,
                                                 int from, int o1, int& v, uint32_t& low) {
   if (from >= o1) return o1;
   // the row (<= LONG_ROW slots) spans at most two words of the blocked bitmask
@@ -77,7 +102,8 @@ __device__ __forceinline__ int spread_scan_lane_st(const Env& e, const uint32_t*
 }
 // same for a FULL row (slot k <-> device v = k - o0 + (k - o0 >= s)): walk the candidate-device bitmask
 // instead of the row; `cand` holds reach | (known & vulnerable & not compromised at the start)
-__device__ __forceinline__ int spread_scan_full(const Env& e, const uint32_t* T, const uint64_t* cand,
+template <class TW>
+__device__ __forceinline__ int spread_scan_full(const Env& e, const TW* T, const uint64_t* cand,
                                                 int s, int from, int o0, int o1) {
   if (from >= o1) return o1;
   int v_from = from - o0; if (v_from >= s) ++v_from;
@@ -95,7 +121,8 @@ __device__ __forceinline__ int spread_scan_full(const Env& e, const uint32_t* T,
   }
   return o1;
 }
-__device__ __forceinline__ int spread_scan_coop(const Env& e, const uint32_t* T, int s, bool dc,
+template <class TW>
+__device__ __forceinline__ int spread_scan_coop(const Env& e, const TW* T, int s, bool dc,
                                                 int from, int o1) {
   for (int k0 = from; k0 < o1; k0 += WAVE) {
     int k = k0 + e.lane;
@@ -110,7 +137,8 @@ __device__ __forceinline__ int spread_scan_coop(const Env& e, const uint32_t* T,
 // One fix-point round for the sources whose rows carry ADDED edges: per-lane walk of the merged row;
 // cur[s] = o0 + index in the merged row (o0 + merged length = nothing to take).  Kept out of the main
 // round loop so that its registers are not live there.
-__device__ __forceinline__ bool spread_x_round(const Env& e, uint32_t* T, uint16_t* cur, const uint16_t* slist, int n_src, int round) {
+template <class TW>
+__device__ __forceinline__ bool spread_x_round(const Env& e, TW* T, uint16_t* cur, const uint16_t* slist, int n_src, int round) {
   bool changed = false;
 #pragma nounroll
   for (int b0 = 0; b0 < n_src; b0 += WAVE) {
@@ -165,12 +193,12 @@ __device__ __forceinline__ int spread_x_counts(Env& e, const uint16_t* cur, cons
 // CR > 1 also selects the staged per-lane scan)
 // GS: chunks per staged group of a chunk loop (4, or the whole env at a compile-time size)
 // WIDE: the log counts read a row's blocked words nine at a time (rows of <= 256 slots, see range_popc_wide)
-template <bool XE, int CR, int GS, bool WIDE, class KP>
+template <bool XE, int CR, int GS, bool WIDE, class TW, class KP>
 __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32_t* expl, int ex0, int n_expl,
                                                 uint64_t* srcb) {
   const int M = e.M, MC = e.MC, Mp = MC * WAVE;
-  uint32_t* T = e.scr;                          // [Mp] first-compromise time (source id + 1)
-  uint16_t* cur = (uint16_t*)(e.scr + Mp);      // [Mp] current pick (slot) per source DEVICE, row end = none
+  TW* T = (TW*)e.scr;                           // [Mp] first-compromise time (source id + 1); TW: see t_min above
+  uint16_t* cur = (uint16_t*)(T + Mp);          // [Mp] current pick (slot) per source DEVICE, row end = none
   uint16_t* cntv = (uint16_t*)T;                // [Mp] log entries per COMPACT source index: reuses T, which is applied
                                                 //      to the flags right after the sweeps (4 KB less LDS per 2048-device env)
   uint16_t* slist = e.lsrc;                     // [Mp] the sources in id order (snapshot :1127)
@@ -219,7 +247,7 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
         const uint8_t x = (uint8_t)(((f & CG_F_REACH) ? 1 : 0) | (((f & CG_F_KNOWN) && (vj[j] & ebit)) ? 2 : 0));
         const uint64_t cm = ballot((x & 1) || ((x & 2) && !(f & CG_F_COMP)));
         if (c0 + j < MC) {
-          T[d] = (((f & CG_F_COMP) ? 0u : T_TIME_INF) << 2) | x;
+          T[d] = (TW)((((f & CG_F_COMP) ? 0u : t_inf<TW>()) << 2) | x);
           cur[d] = d < M ? (uint16_t)oj[j] : (uint16_t)0;
           if (e.lane == 0) cand[c0 + j] = cm;
         }
@@ -364,7 +392,7 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
 #pragma unroll
       for (int j = 0; j < GS; ++j) {
         const int d = (c0 + j) * WAVE + e.lane;
-        if (d < M && (tj[j] >> 2) != T_TIME_INF && (tj[j] >> 2) != 0u) e.flags[d] = (uint8_t)(fj[j] | CG_F_COMP);
+        if (d < M && (tj[j] >> 2) != t_inf<TW>() && (tj[j] >> 2) != 0u) e.flags[d] = (uint8_t)(fj[j] | CG_F_COMP);
       }
     }
     wsync();

@@ -347,7 +347,7 @@ __device__ __forceinline__ void def_per_device(Env& e, const KP& P, int at, cons
     const uint32_t site = at == 6 ? CG_SITE_PICK_BLOCK : CG_SITE_PICK_UNBLOCK;
     const bool want = (at == 9);
     const bool simple = list_is_simple(e, dev, L);   // no device twice => occurrence number is always 0
-    uint8_t* occ = (uint8_t*)(e.scr + e.MC * WAVE);   // second scratch half (first half: first-touch table)
+    uint8_t* occ = (uint8_t*)e.lsrc;   // occurrence numbers (the spread's source list is idle here; the scratch area holds the first-touch table)
     if (!simple) {
       for (int i = e.lane; i < (e.MC * WAVE) / 4; i += WAVE) ((uint32_t*)occ)[i] = 0;
       wsync();

@@ -189,7 +189,9 @@ __device__ __forceinline__ WaveAux env_setup(Env& e, uint8_t* smem, const KP& P,
   e.flags = wb; e.busy = wb + MS; e.wl = wb + 2 * MS; e.cby = wb + 3 * MS;
   const int n_planes = (RT && P.t.cby_global) ? 3 : 4;   // (comp_by left in global memory: Env::cby_g)
   e.scr = (uint32_t*)(wb + ((n_planes * MS + 15) & ~15));
-  e.blk = e.scr + Mp + Mp / 2;   // scratch: [Mp] words + [Mp] halfwords (must match wave_lds_bytes on the host)
+  // scratch: [Mp] words + [Mp] halfwords at the compile-time sizes, [Mp] words at run-time sizes -- where the spread's T table
+  // is 16 bits wide and shares them with its `cur` array (must match wave_lds_bytes on the host)
+  e.blk = e.scr + (RT ? Mp : Mp + Mp / 2);
   e.bin = e.blk + ((P.t.EW + 3) & ~3);
   e.ring = (uint16_t*)(e.bin + ((P.t.EW + 3) & ~3));
   e.marks = (uint32_t*)(e.ring + 2 * CG_LOG_RING);

@@ -230,8 +230,12 @@ def compare_state(got: dict, exp: dict, label: str, ring_total=None):
                 bad.append(f"{label}: extra-edge blocked bits env {e}: got {gb} exp {xb}")
     gf = np.asarray(got["fenv"], np.float64)
     xf = np.asarray(exp["fenv"], np.float64)
-    if not np.allclose(gf, xf, rtol=0, atol=1e-9):
-        idx = np.argwhere(~np.isclose(gf, xf, rtol=0, atol=1e-9))[0]
+    # cumulative f64 cost accumulators: 1e-9 absolute + 1e-12 relative (the north star asks for 1e-6 on float rewards).  The
+    # relative part is for the per-log scan path (fast_scan = False): the reference adds 0.5 * def_scale once per scanned log
+    # entry -- thousands of equal terms per tick -- where the kernel adds their product; after a hundred ticks at 2048 devices
+    # the two sums differ by ~1e-9 at 5e4 (tools/fuzz.py case 41011, same on every build since the path exists).
+    if not np.allclose(gf, xf, rtol=1e-12, atol=1e-9):
+        idx = np.argwhere(~np.isclose(gf, xf, rtol=1e-12, atol=1e-9))[0]
         bad.append(f"{label}: fenv differs at {tuple(idx)}: got {gf[tuple(idx)]} exp {xf[tuple(idx)]}")
     return bad
 

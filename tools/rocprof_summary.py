@@ -28,6 +28,7 @@ import argparse
 import csv
 import glob
 import json
+import sys
 import os
 import re
 from collections import defaultdict
@@ -124,6 +125,9 @@ def main():
                              "min_us": min(v), "max_us": max(v)} for (cls, n), v in sorted(tr.items())]
     if a.out_pmc and pmc_out:
         with open(a.out_pmc, "w") as f:
+            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            from bench import kernel_source_hash      # the summary is tied to the kernels it was taken on: bench.py drops it on a mismatch
+            pmc_out["kernel_source_hash"] = kernel_source_hash()
             json.dump(pmc_out, f, indent=1, sort_keys=True)
         print("pmc summary ->", a.out_pmc, sorted(pmc_out))
     if a.out_stats and stats_out:
