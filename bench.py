@@ -146,7 +146,7 @@ class Dist:
         self.torch.cuda.synchronize(self.dev)
         if self.world > 1:
             self.dist.barrier()
-        self.torch.cuda.synchronize(self.dev)
+            self.torch.cuda.synchronize(self.dev)
 
     def max_over_ranks(self, values):
         if self.world == 1:
@@ -169,14 +169,17 @@ def timed_reps(D: Dist, env, keep, reps, issue):
         for k, v in keep.items():
             env.state[k].copy_(v)
         D.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
-        env.timer_start()          # HIP events on the stream the kernels are launched on (the current stream)
+        e0.record()                # HIP events on the stream the kernels are launched on (torch's current stream)
         issue()
-        ev_ms = env.timer_stop()
-        torch.cuda.synchronize(D.dev)
+        e1.record()
+        # ONE wait for the region: torch.cuda.synchronize (+ the ranks' barrier).  Round 3 waited on the stop event first
+        # (hipEventSynchronize: a sleeping wait, ~40 us to wake up) and then synchronised three more times: 50 us of host
+        # latency per region, 2.5 us per step at K = 20, inside `ms_per_step` (tools/exp_sync.py).
         D.barrier()
         walls.append(time.perf_counter() - t0)
-        evs.append(ev_ms / 1e3)
+        evs.append(e0.elapsed_time(e1) / 1e3)
     walls = D.max_over_ranks(walls)
     evs = D.max_over_ranks(evs)
     return float(np.median(walls)), float(np.median(evs)), walls
@@ -676,6 +679,20 @@ def brief(rec):
     return out
 
 
+def spin_wait():
+    """Host wait policy: spin instead of sleeping in hipDeviceSynchronize (hipDeviceScheduleSpin; must be set before the
+    runtime creates its context, i.e. before torch touches the GPU).  A sleeping wait wakes up tens of microseconds after a
+    20-step region of ~340 us has finished."""
+    if os.environ.get("CYGYM_BENCH_NO_SPIN") == "1":
+        return "default"
+    try:
+        import ctypes
+        rc = ctypes.CDLL("libamdhip64.so").hipSetDeviceFlags(1)   # hipDeviceScheduleSpin
+        return "spin" if rc == 0 else f"default (hipSetDeviceFlags -> {rc})"
+    except OSError as e:
+        return f"default ({e})"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -712,6 +729,7 @@ def main():
         print(f"[bench] error: --gpus {args.gpus} but WORLD_SIZE={world_env}: launch with `python -m torch.distributed.run --nnodes=1 "
               f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...`", file=sys.stderr)
         sys.exit(2)
+    wait_policy = spin_wait()
     D = Dist()
     K, W = args.steps, args.warmup
     name = args.workload
@@ -730,7 +748,7 @@ def main():
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": rec["workload"], "envs_per_gpu": n_per_gpu, "devices": M, "edges": topo.E,
                    "exploits": topo.X, "lambda_events": 0.0, "max_extra_edges": topo.max_extra,
-                   "stepping": head["what"], "reps": args.reps,
+                   "stepping": head["what"], "reps": args.reps, "host_wait": wait_policy,
                    "parallelism": f"env-batch split x{D.world}, no step-path collective"},
         "roofline": dict(head["roofline"]),
         "check": rec["check"],
