@@ -201,7 +201,8 @@ __device__ __forceinline__ WaveAux env_setup(Env& e, uint8_t* smem, const KP& P,
   e.devl = (int16_t*)(e.lsrc + Mp);
   x.park = (int32_t*)(wb + P.wave_lds - 128);   // [16 i32 + 3 f64] per-env scalars between fused ticks
   e.xk = (uint32_t*)(wb + P.wave_lds - 128 - P.t.x_bytes);
-  e.obs_stage = (float4*)(wb + P.wave_lds - 128 - CG_OBS_STAGE_BYTES);   // (WIDE: lean kernel, no extra-edge section; the host adds the bytes)
+  // (below the extra-edge section; the host adds the bytes: 3 KB for the WIDE kernel, 1.5 KB -- all 32 pairs -- at 64 devices)
+  e.obs_stage = (float4*)(wb + P.wave_lds - 128 - P.t.x_bytes - (M == 64 ? CG_OBS_STAGE_BYTES / 2 : CG_OBS_STAGE_BYTES));
   e.xb = e.xk + P.t.K;
   e.xmo = (uint64_t*)(e.xb + ((P.t.KW + 1) & ~1));
   e.xmi = e.xmo + MC;

@@ -169,7 +169,8 @@ static size_t wave_lds_bytes(const DevTopo& t, int max_devs) {
   const bool rt = t.M != 64 && t.M != 256;   // run-time size: 4 bytes of scratch per device (16-bit T table), else 6 (env_setup)
   size_t w = align_up((size_t)(t.cby_global ? 3 : 4) * ((t.M + 3) & ~3), 16) + (size_t)t.Mp * (rt ? 4 : 6) + (size_t)((t.EW + 3) & ~3) * 4 * 2 + CG_LOG_RING * 4 +
              (size_t)((t.Mp / 32 + 2) & ~1) * 4 + (size_t)t.MC * 8 + (size_t)t.Mp * 2 +
-             align_up((size_t)max_devs * 2, 16) + (size_t)t.x_bytes + 128 /* scalar parking of the fused kernel */;
+             align_up((size_t)max_devs * 2, 16) + (size_t)t.x_bytes + 128 /* scalar parking of the fused kernel */ +
+             (t.M == 64 ? CG_OBS_STAGE_BYTES / 2 : 0) /* the observation's LDS stage at 64 devices (write_obs_staged) */;
   return align_up(w, 16);
 }
 // The in-CSR columns and slot maps (icol/ieid/oeid, ~2/3 of the blob) are read by block/unblock only (~9 % of
