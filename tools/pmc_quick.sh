@@ -9,8 +9,9 @@ for set in "$@"; do
 done
 cd "$REPO"
 python3 - "$OUT" <<'PY'
-import csv, glob, sys, collections
+import csv, glob, json, sys, collections
 out = sys.argv[1]
+summary = collections.defaultdict(dict)
 for f in sorted(glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True)):
     acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
     for r in csv.DictReader(open(f)):
@@ -21,4 +22,13 @@ for f in sorted(glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True
         n[(k, r["Counter_Name"])] += 1
     for k, d in acc.items():
         print(k, {c: (round(v / n[(k, c)], 1), n[(k, c)]) for c, v in d.items()})
+        for c, v in d.items():
+            summary[k][c] = {"per_launch": v / n[(k, c)], "launches": n[(k, c)]}
+for k, d in summary.items():   # per-wave figures (SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles: x4 = shader cycles)
+    w = d.get("SQ_WAVES", {}).get("per_launch")
+    if w:
+        d["per_wave"] = {c: v["per_launch"] / w * (4.0 if c.startswith(("SQ_WAVE_CYCLES", "SQ_WAIT", "SQ_ACTIVE_INST", "SQ_BUSY")) else 1.0)
+                         for c, v in d.items() if c != "SQ_WAVES" and isinstance(v, dict) and "per_launch" in v}
+        d["per_wave_note"] = "instructions per wave and launch; cycle counters in shader cycles (quad-cycle counts x 4)"
+json.dump(summary, open(out + "/sq_counters.json", "w"), indent=1, sort_keys=True)
 PY
