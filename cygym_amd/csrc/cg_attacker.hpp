@@ -732,11 +732,19 @@ __device__ __forceinline__ void attacker_spread_ct(Env& e, const KP& P, const in
       if (b * WAVE >= n_src) continue;   // (uniform)
       const int o0 = (int)(row[b] & 0xFFFFu), o1 = (int)(row[b] >> 16), k = (int)(pkv[b] & 0xFFFFu);
       int n = 0;
-      if (b * WAVE + lane < n_src) {
-        const int end = k < o1 ? k + 1 : o1;
-        n = (end - o0) - (WIDE ? range_popc_wide(e.blk, o0, end) : range_popc(e.blk, o0, end));
-        if (((sst[b] >> 16) & CG_D_DC) && k < o1) cby_or(e, (int)(pkv[b] >> 16), ebit);
+      const bool mine = b * WAVE + lane < n_src;
+      const int end = k < o1 ? k + 1 : o1;
+      // the prefix [o0, end) of nearly every source -- short rows, and hubs whose pick is one of their first neighbours -- spans
+      // at most two words of the blocked bitmask: two reads and one 64-bit popcount; the nine-word form only where some lane needs it
+      const bool far = mine && end - o0 > 33;
+      if (mine && !far) {
+        const int w0 = o0 >> 5, wl = ((P.t.EW + 3) & ~3) - 1;
+        const uint64_t bits = ((uint64_t)e.blk[w0] | ((uint64_t)e.blk[w0 < wl ? w0 + 1 : w0] << 32)) >> (o0 & 31);
+        const int len = end - o0;   // 0..33
+        n = len - __popcll(len > 0 ? bits & (~0ull >> (64 - len)) : 0ull);
       }
+      if (__any(far)) { if (far) n = (end - o0) - (WIDE ? range_popc_wide(e.blk, o0, end) : range_popc(e.blk, o0, end)); }
+      if (mine && ((sst[b] >> 16) & CG_D_DC) && k < o1) cby_or(e, (int)(pkv[b] >> 16), ebit);
       cnt[b] = n;
       total_new += wave_sum(n);
     }

@@ -169,14 +169,15 @@ def test_tick_kernels_do_not_spill():
         if mt and xe and not fused:       # choose_launch counts on 5 resident waves per SIMD for these
             assert r["vgprs"] <= 102, (name, r)
         if mt and not fused and not xe:   # lean per-tick kernel at a compile-time size: parameters are read next to
-            assert r["sgpr_spill"] <= 128, (name, r)   # their uses (laundered kernarg pointer), few SGPRs spill
+            assert r["sgpr_spill"] <= 160, (name, r)   # their uses (laundered kernarg pointer), few SGPRs spill (round 4: the wave id and
+            # the per-wave LDS pointers derived from it are scalars now -- 5-14 VGPRs freed for ~30 more SGPRs parked in VGPR lanes)
     assert seen == {(False, False), (False, True), (True, False), (True, True)}
 
 
 def test_every_shipped_kernel_is_free_of_spilled_vgprs():
     """Not only the tick: every kernel of libcygym_hip.so (actor network, decode, grouping / sampling, reset, observe, ...)
     keeps its vector registers out of scratch memory.  Round 3's build had 10-11 spilled VGPRs in every 4-byte-aligned actor
-    instantiation (`actor_mlp_kernel<*, 1>`); the tick + actor kernel keeps ~280 SGPRs in VGPR lanes at the 128-VGPR cap
+    instantiation (`actor_mlp_kernel<*, 1>`); the tick + actor kernel keeps ~310 SGPRs in VGPR lanes at the 128-VGPR cap
     -- tolerable only as long as no VGPR spills beside them (the combination CG_LB in csrc/cg_device.hpp records as
     miscompiled once), so that is capped too."""
     import json
@@ -195,7 +196,7 @@ def test_every_shipped_kernel_is_free_of_spilled_vgprs():
             if fam in name:
                 families.add(fam)
         if "tick_actor_kernel" in name:
-            assert r["sgpr_spill"] <= 300 and r["scratch"] == 0, (name, r)
+            assert r["sgpr_spill"] <= 350 and r["scratch"] == 0, (name, r)   # (a static count of spill slots in VGPR lanes, not a cost: the bound only keeps it from doubling unnoticed)
     assert {"actor_mlp_kernel", "tick_actor_kernel", "actor_head", "sample_group_actions_kernel", "group_actions_kernel", "step_kernel"} <= families
 
 
