@@ -17,7 +17,7 @@ EXPORTS = [
     "cygym_version", "cygym_sizeof", "cygym_last_error", "cygym_create", "cygym_destroy", "cygym_set_config", "cygym_bind", "cygym_derive",
     "cygym_set_snapshot", "cygym_reset", "cygym_randomize", "cygym_step", "cygym_step_range", "cygym_rollout", "cygym_observe",
     "cygym_gen_actions", "cygym_write_actions", "cygym_decode_actions", "cygym_actor_head_decode", "cygym_actor_mlp_decode", "cygym_step_actor", "cygym_group_actions", "cygym_sample_group_actions", "cygym_fit_forests",
-    "cygym_timer_start", "cygym_timer_stop",
+    "cygym_timer_start", "cygym_timer_stop", "cygym_launch_plan",
 ]
 
 
@@ -72,6 +72,7 @@ def load():
     L.cygym_gen_actions.argtypes = [H, C.c_int32] + [C.c_void_p] * 8 + [C.c_int32, C.c_void_p]
     L.cygym_timer_start.argtypes = [H, C.c_void_p]
     L.cygym_timer_stop.argtypes = [H, C.c_void_p, C.POINTER(C.c_float)]
+    L.cygym_launch_plan.argtypes = [H, C.POINTER(C.c_int32)]
     if L.cygym_version() != abi.ABI_VERSION:
         raise CygymError(f"ABI mismatch: library {L.cygym_version()} vs python {abi.ABI_VERSION}")
     L.cygym_sizeof.argtypes = [C.c_int32]

@@ -934,6 +934,14 @@ class BatchedCyberDefenseEnv:
             raise ValueError("role must be 'attacker' or 'defender'")
         return ((f & (want | S.F_NYA)) == want).to(torch.float32)
 
+    def launch_plan(self) -> dict:
+        """How the tick kernels of this batch are launched (cygym_launch_plan, include/cygym_abi.h)."""
+        out = (C.c_int32 * 8)()
+        _lib.check(self.lib.cygym_launch_plan(self._h, out), self._h, "cygym_launch_plan")
+        keys = ("waves_per_workgroup", "waves_per_workgroup_rollout", "lds_bytes_per_wave", "lds_bytes_shared",
+                "comp_by_in_global", "lists_in_global", "reserved", "wide")
+        return dict(zip(keys, (int(v) for v in out)))
+
     def timer_start(self):
         _lib.check(self.lib.cygym_timer_start(self._h, self._stream()), self._h, "cygym_timer_start")
 

@@ -19,6 +19,7 @@ struct DevTopo {
   int blob_bytes, lds_bytes, in_lds, multi;
   int K, KW, x_bytes;   // extra-edge list: capacity, blocked-bit words, bytes of its per-wave LDS section
   int cby_global;       // run-time sizes with M % 4 == 0: the comp_by plane stays in global memory (3 planes staged, Env::cby_g)
+  int lists_global;     // ... and so do the tick's device list, the extra-edge list and the in-row bounds (choose_launch: where that buys a resident wave)
   const double* apl;    // [CG_DET_APL_N] leaf-term table of the trained detector (global; tail of the blob), or nullptr
   // global views (host-side convenience; kernels outside the tick use them)
   const uint8_t *dstatic, *vuln, *napps;
@@ -36,7 +37,7 @@ struct DevTopo {
 // env_setup() takes either.  Filled by fill_hot() on the host from the complete KParams.
 struct KHot {
   struct {
-    int M, MC, EW, K, KW, x_bytes, cby_global, multi, lds_bytes, pad0;
+    int M, MC, EW, K, KW, x_bytes, cby_global, multi, lds_bytes, lists_global;
     const uint8_t* blob;
     int o_optr, o_ocol, o_os, o_ver, o_ano, o_dst, o_vul, o_nap, o_iptr, o_icol, o_ieid, o_oeid;
   } t;
@@ -65,7 +66,7 @@ struct KParams {
 inline void fill_hot(KParams& P) {   // host side, once the rest of P is complete
   KHot& h = P.h;
   h.t.M = P.t.M; h.t.MC = P.t.MC; h.t.EW = P.t.EW; h.t.K = P.t.K; h.t.KW = P.t.KW; h.t.x_bytes = P.t.x_bytes;
-  h.t.cby_global = P.t.cby_global; h.t.multi = P.t.multi; h.t.lds_bytes = P.t.lds_bytes; h.t.pad0 = 0; h.t.blob = P.t.blob;
+  h.t.cby_global = P.t.cby_global; h.t.multi = P.t.multi; h.t.lds_bytes = P.t.lds_bytes; h.t.lists_global = P.t.lists_global; h.t.blob = P.t.blob;
   h.t.o_optr = P.t.o_optr; h.t.o_ocol = P.t.o_ocol; h.t.o_os = P.t.o_os; h.t.o_ver = P.t.o_ver; h.t.o_ano = P.t.o_ano;
   h.t.o_dst = P.t.o_dst; h.t.o_vul = P.t.o_vul; h.t.o_nap = P.t.o_nap; h.t.o_iptr = P.t.o_iptr; h.t.o_icol = P.t.o_icol;
   h.t.o_ieid = P.t.o_ieid; h.t.o_oeid = P.t.o_oeid;

@@ -205,12 +205,14 @@ __device__ __forceinline__ WaveAux env_setup(Env& e, uint8_t* smem, const KP& P,
   e.obs_stage = (float4*)(wb + P.wave_lds - 128 - P.t.x_bytes - (M == 64 ? CG_OBS_STAGE_BYTES / 2 : CG_OBS_STAGE_BYTES));
   e.xb = e.xk + P.t.K;
   e.xmo = (uint64_t*)(e.xb + ((P.t.KW + 1) & ~1));
+  const bool lists_global = RT && P.t.lists_global;   // device list / extra-edge list / in-row bounds read where they lie (see choose_launch)
+  if (lists_global) { e.xmo = (uint64_t*)e.xk; e.xk = nullptr; e.xb = nullptr; e.devl = nullptr; }   // (the tick body points them at the env's global rows)
   e.xmi = e.xmo + MC;
   e.K = P.t.K;
   e.optr = (const uint16_t*)(smem + P.t.o_optr); e.ocol = (const uint16_t*)(smem + P.t.o_ocol);
   e.osv = (const float*)(smem + P.t.o_os); e.ver = (const float*)(smem + P.t.o_ver); e.ano = (const float*)(smem + P.t.o_ano);   // valid when P.t.in_lds
   e.dst = smem + P.t.o_dst; e.vul = smem + P.t.o_vul; e.nap = smem + P.t.o_nap;
-  e.iptr_l = (const uint16_t*)(smem + P.t.o_iptr);
+  e.iptr_l = lists_global ? (const uint16_t*)(P.t.blob + P.t.o_iptr) : (const uint16_t*)(smem + P.t.o_iptr);
   if constexpr (MAPS) {   // LDS: block / unblock picks no longer pay a global-memory hop per pass
     e.icol_g = (const uint16_t*)(smem + P.t.o_icol); e.ieid_g = (const uint16_t*)(smem + P.t.o_ieid); e.oeid_g = (const uint16_t*)(smem + P.t.o_oeid);
   } else {

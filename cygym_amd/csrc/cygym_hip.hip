@@ -165,11 +165,17 @@ const char* cygym_last_error(const cygym_handle* h) { return h ? h->err : g_err;
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // LDS budget: shared blob prefix + WPB per-wave regions.  Prefers staging the in-CSR too.
+// Bytes of the extra-edge section of a wave's LDS block: keys + blocked bits + the per-chunk in / out masks, or -- lists_global --
+// the masks alone (the list itself is then read and edited in its global row)
+static int x_section_bytes(const DevTopo& t, bool lists_global) {
+  if (t.K <= 0) return 0;
+  return (int)align_up((lists_global ? 0 : (size_t)4 * (t.K + ((t.KW + 1) & ~1))) + (size_t)16 * t.MC, 16);
+}
 static size_t wave_lds_bytes(const DevTopo& t, int max_devs) {
   const bool rt = t.M != 64 && t.M != 256;   // run-time size: 4 bytes of scratch per device (16-bit T table), else 6 (env_setup)
   size_t w = align_up((size_t)(t.cby_global ? 3 : 4) * ((t.M + 3) & ~3), 16) + (size_t)t.Mp * (rt ? 4 : 6) + (size_t)((t.EW + 3) & ~3) * 4 * 2 + CG_LOG_RING * 4 +
              (size_t)((t.Mp / 32 + 2) & ~1) * 4 + (size_t)t.MC * 8 + (size_t)t.Mp * 2 +
-             align_up((size_t)max_devs * 2, 16) + (size_t)t.x_bytes + 128 /* scalar parking of the fused kernel */ +
+             (t.lists_global ? 0 : align_up((size_t)max_devs * 2, 16)) + (size_t)x_section_bytes(t, t.lists_global) + 128 /* scalar parking of the fused kernel */ +
              (t.M == 64 ? CG_OBS_STAGE_BYTES / 2 : 0) /* the observation's LDS stage at 64 devices (write_obs_staged) */;
   return align_up(w, 16);
 }
@@ -182,12 +188,22 @@ static int choose_launch(cygym_handle* h, int max_devs) {
   // another resident wave per CU (2048 devices without an extra-edge list: 4 -> 5)
   DevTopo& t = h->t;
   int w_lds = 0, w_glob = 0;
-  t.cby_global = 0;
+  t.cby_global = 0; t.lists_global = 0;
   const int rc = choose_launch_with(h, max_devs, &w_lds);
   const bool can = t.M != 64 && t.M != 256 && (t.M & 3) == 0 && !getenv("CYGYM_CBY_LDS");
   if (can) {
     t.cby_global = 1;
-    if (choose_launch_with(h, max_devs, &w_glob) == 0 && (rc != 0 || w_glob > w_lds || getenv("CYGYM_CBY_GLOBAL"))) return 0;   // (env: test aid)
+    if (choose_launch_with(h, max_devs, &w_glob) == 0 && (rc != 0 || w_glob > w_lds || getenv("CYGYM_CBY_GLOBAL"))) {   // (env: test aid)
+      // ... and, if THAT buys yet another one, the tick's device list, the extra-edge list and the in-row bounds too: they are read
+      // where they lie in global memory (2048 devices with a 416-entry extra-edge list: 24.2 -> 22.0 KB per env and 4 KB less of
+      // shared topology: 5 -> 6 waves per CU, i.e. 4096 envs in three residency rounds instead of four)
+      int w_lists = 0;
+      // (the rollout kernels share the plan: 4096 x 2048, 20 ticks per launch: roofline fraction 0.311 -> 0.332 on one box)
+      t.lists_global = 1;
+      if (!getenv("CYGYM_LISTS_LDS") && choose_launch_with(h, max_devs, &w_lists) == 0 && (w_lists > w_glob || getenv("CYGYM_LISTS_GLOBAL"))) return 0;
+      t.lists_global = 0;
+      return choose_launch_with(h, max_devs, &w_glob);
+    }
     t.cby_global = 0;
     return choose_launch_with(h, max_devs, &w_lds);
   }
@@ -202,8 +218,8 @@ static int choose_launch_with(cygym_handle* h, int max_devs, int* waves_out) {
   int best = 0, best_waves = 0, best_floats = 1;
   // The three static float columns (os / version / anomaly, 12 bytes per device) feed only the observation
   // writer: they ride in LDS unless leaving them in the L2-resident blob buys more resident waves (M >= 1024).
-  for (int floats = 1; floats >= 0; --floats) {
-    const size_t shared = (size_t)(floats ? t.o_icol : t.o_os);
+  for (int floats = t.lists_global ? 0 : 1; floats >= 0; --floats) {
+    const size_t shared = (size_t)(t.lists_global ? t.o_iptr : floats ? t.o_icol : t.o_os);   // (lists_global: the staged prefix ends before the in-row bounds)
     static const int shapes[] = {16, 12, 8, 6, 5, 4, 3, 2, 1};
     for (int wpb : shapes) {
       if (forced && wpb != forced) continue;
@@ -228,7 +244,8 @@ static int choose_launch_with(cygym_handle* h, int max_devs, int* waves_out) {
   }
   if (!best) return -1;
   *waves_out = best_waves;
-  const size_t shared = (size_t)(best_floats ? t.o_icol : t.o_os);
+  const size_t shared = (size_t)(t.lists_global ? t.o_iptr : best_floats ? t.o_icol : t.o_os);
+  t.x_bytes = x_section_bytes(t, t.lists_global);
   h->wpb = best; h->wave_lds = (int)wave; h->shared_lds = (int)shared;
   // The rollout kernels are built for 4 waves per SIMD whatever the size: 16 resident waves per CU at most, and one
   // 16-wave workgroup measured 4 % faster than two of 8 (16384 x 256).  Otherwise they share the per-tick shape.
@@ -314,7 +331,8 @@ int cygym_create(const cygym_topology* topo, const cygym_config* cfg, int32_t n_
   // and five resident waves per CU (the lean kernels; with an extra-edge list four either way)
   // (decided in choose_launch: only where it buys a resident wave -- the global-memory accesses cost 3-6 % otherwise)
   t.cby_global = 0;
-  t.x_bytes = t.K > 0 ? (int)align_up((size_t)4 * (t.K + ((t.KW + 1) & ~1)) + (size_t)16 * t.MC, 16) : 0;
+  t.lists_global = 0;
+  t.x_bytes = x_section_bytes(t, false);   // (choose_launch sets the one in effect)
   // one blob, laid out exactly as the LDS-shared section (see DevTopo)
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 16); return (int)o; };
@@ -894,6 +912,13 @@ int cygym_fit_forests(const uint16_t* rows, const int64_t* row_ptr, const uint32
 }
 
 /* diagnostic builds only (-DCG_STAMPS): per-env phase stamps, [N][16] uint64 device buffer (NULL to disable) */
+int cygym_launch_plan(const cygym_handle* h, int32_t* out) {
+  if (!h || !out) return fail(nullptr, CYGYM_EINVAL, "cygym_launch_plan: null argument%s", "");
+  out[0] = h->wpb; out[1] = h->wpb_fused; out[2] = h->wave_lds; out[3] = h->shared_lds;
+  out[4] = h->t.cby_global; out[5] = h->t.lists_global; out[6] = 0; out[7] = h->wide ? 1 : 0;
+  return CYGYM_OK;
+}
+
 int cygym_set_debug(cygym_handle* h, void* buf) {
   if (!h) return fail(h, CYGYM_EINVAL, "null handle%s", "");
   h->dbg = (unsigned long long*)buf;

@@ -447,6 +447,13 @@ int cygym_gen_actions(cygym_handle* h, int32_t tick, int32_t* mode, int32_t* n_g
 int cygym_timer_start(cygym_handle* h, void* stream);
 int cygym_timer_stop(cygym_handle* h, void* stream, float* ms);
 
+/* Introspection: how this handle's tick kernels are launched (what cygym_create / a longer device list planned from the
+ * LDS and register budgets; no reference counterpart -- the reference has no launch).  out[8] =
+ *   {waves per workgroup of cygym_step, ... of cygym_rollout, LDS bytes per wave, LDS bytes of the shared topology section,
+ *    comp_by plane in global memory (0/1), device / extra-edge lists + in-row bounds in global memory (0/1),
+ *    reserved (0), one 16-wave workgroup per CU with the in-CSR maps in LDS (0/1)} */
+int cygym_launch_plan(const cygym_handle* h, int32_t* out);
+
 /* Diagnostic builds only (-DCG_STAMPS, tools/stamps.py): `stamps` = DEVICE int64 [N][16] receiving per-phase
  * s_memtime stamps of every env's last tick, or NULL to switch them off.  Ignored by the product build. */
 int cygym_set_debug(cygym_handle* h, void* stamps);

@@ -355,6 +355,26 @@ def test_differential_fuzz_sample(monkeypatch):
     fuzz.main()   # exits non-zero (SystemExit) on the first mismatch
 
 
+def test_lists_read_from_global_memory(monkeypatch):
+    """Run-time sizes where it buys a resident wave (4096 x 2048 with its extra-edge list: 5 -> 6 per CU) leave the tick's
+    device list, the extra-edge list and the in-row bounds in global memory (choose_launch, cygym_hip.hip).  No network that
+    fits a test picks that plan by itself: force it (CYGYM_CBY_GLOBAL + CYGYM_LISTS_GLOBAL) and run the added-edge scenarios --
+    per tick with aimed block / unblock lists, and as a rollout -- against the oracle."""
+    monkeypatch.setenv("CYGYM_CBY_GLOBAL", "1")
+    monkeypatch.setenv("CYGYM_LISTS_GLOBAL", "1")
+    topo, init, ck = make_topology(600, 4, seed=9, n_active=500, max_extra=192)
+    env = _env(topo, abi.EnvConfig(seed=1, **ck), 8, init, max_groups=1, max_devs=75)
+    plan = env.launch_plan()
+    env.close()
+    assert plan["comp_by_in_global"] == 1 and plan["lists_in_global"] == 1, plan
+    test_hip_matches_oracle_with_added_edges(24, 1, 96, 200, 12, 160)
+    test_hip_matches_oracle_with_added_edges(24, 1, 64, 120, 12, 6)
+    test_hip_matches_oracle_with_added_edges(600, 4, 24, 60, 500, 192)
+    test_rollout_with_added_edges(24, 1, 64, 60, 160)
+    test_rollout_with_added_edges(600, 4, 24, 40, 192)
+    test_hip_matches_oracle_synthetic(600, 4, 24, 60, 550)
+
+
 @pytest.mark.parametrize("M,wpb", [(100, w) for w in (1, 2, 3, 4, 5, 6, 8, 12, 16)] + [(m, w) for m in (64, 256) for w in (1, 2, 4, 8, 16)])
 def test_every_workgroup_shape(M, wpb, monkeypatch):
     """cygym_create picks the waves-per-workgroup shape from the LDS and register budgets, so a given network only ever
