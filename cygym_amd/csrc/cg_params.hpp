@@ -83,7 +83,7 @@ inline void fill_hot(KParams& P) {   // host side, once the rest of P is complet
 template <bool FUSED> struct KParamsOf { using type = const KParams; };
 template <> struct KParamsOf<true> { using type = const __attribute__((address_space(4))) KParams; };
 
-#define CG_DBG_W 24   // uint64 slots per env in the stamp buffer of diagnostic builds
+#define CG_DBG_W 28   // uint64 slots per env in the stamp buffer of diagnostic builds
 #ifdef CG_STAMPS
 #define SUBSTAMP(k) do { if (P.dbg && e.lane == 0) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); P.dbg[(size_t)e.env * CG_DBG_W + (k)] = _t; } } while (0)
 #define SUBVAL(k, v) do { if (P.dbg && e.lane == 0) P.dbg[(size_t)e.env * CG_DBG_W + (k)] = (unsigned long long)(v); } while (0)

@@ -16,7 +16,7 @@ topo, init, ck = make_topology(M, {64: 4, 256: 1, 2048: 32}.get(M, 1), seed=0, m
 cfg = abi.EnvConfig(seed=0, auto_reset=1, lambda_events=0.0, **ck)
 env = BatchedCyberDefenseEnv(topo, cfg, N, init, device="cuda:0", max_groups=1, max_devs=max(1, M // 8))
 env.lib.cygym_set_debug.argtypes = [C.c_void_p, C.c_void_p]
-dbg = torch.zeros((N, 24), dtype=torch.int64, device="cuda:0")
+dbg = torch.zeros((N, 28), dtype=torch.int64, device="cuda:0")
 env.lib.cygym_set_debug(env._h, C.c_void_p(dbg.data_ptr()))
 acc = []
 for t in range(T):

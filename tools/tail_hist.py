@@ -24,7 +24,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 M = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 T = int(sys.argv[3]) if len(sys.argv) > 3 else 205
 OUT = os.environ.get("TAIL_JSON", os.path.join(ROOT, "gpurun_out", "tail_hist.json"))
-W = 24   # CG_DBG_W
+W = 28   # CG_DBG_W
 WPB_ENV = int(os.environ.get("TAIL_WPB", "16"))   # envs per workgroup of the launch shape (16 at 4096 x 256)
 topo, init, ck = make_topology(M, {64: 4, 256: 1, 2048: 32}.get(M, 1), seed=0, max_extra=int(os.environ.get("CYGYM_STAMP_MAX_EXTRA", "0")))
 cfg = abi.EnvConfig(seed=0, auto_reset=1, lambda_events=0.0, **ck)   # bench.py's `target` workload
