@@ -4,9 +4,9 @@
 #define CG_DEFENDER_HPP
 
 // ---------------- defender ----------------
-template <class KP>
+template <class KP, class IE, class FE>   // IE / FE: the env's scalars -- arrays, or lane views of the scalars register (EnvI / EnvF, cg_wave.hpp)
 __device__ __forceinline__ void def_global(Env& e, const KP& P, int at, const int16_t* dev, int L, double& cost,
-                                           bool& dirty, bool grouped, int32_t* ie, double* fe) {
+                                           bool& dirty, bool grouped, IE ie, FE fe) {
   const double ds = P.c.def_scale;
   const int M = e.M;
   if (at == 2) {  // :918-926
@@ -65,9 +65,9 @@ __device__ __forceinline__ void def_global(Env& e, const KP& P, int at, const in
 
 // action 1 over one device list; `occ` (u8 [Mp], LDS) carries stall occurrence numbers across
 // the groups of one step_grouped tick (nullptr for single-action steps).
-template <class KP>
+template <class KP, class IE, class FE>
 __device__ __forceinline__ void def_clean(Env& e, const KP& P, const int16_t* dev, int L, double& cost,
-                                          int32_t* ie, double* fe, uint8_t* occ) {
+                                          IE ie, FE fe, uint8_t* occ) {
   const double ds = P.c.def_scale;
   int a, b, disc;
   if (list_is_simple(e, dev, L)) {   // list-major: one lane per list entry, one draw per lane
@@ -260,8 +260,8 @@ __device__ __forceinline__ void block_one(Env& e, const PoolPtrs q, int d, bool 
 //   n_mult: scans (list entries on active devices); the entries are the same for each of them, so are the trained
 //   detector's predictions -- only the coin mode draws per scan -- and a flagged sender keeps the stall of the last
 //   scan that flagged it (the draw is addressed by sender and scan ordinal, like on the fast path).
-template <class KP>
-__device__ __forceinline__ float slow_scan(Env& e, const KP& P, int n_mult, double& cost, int32_t* ie, double* fe) {
+template <class KP, class IE, class FE>
+__device__ __forceinline__ float slow_scan(Env& e, const KP& P, int n_mult, double& cost, IE ie, FE fe) {
   const int M = e.M;
   const double ds = P.c.def_scale;
   const int w = e.log_total < CG_SLOW_SCAN_WINDOW ? e.log_total : CG_SLOW_SCAN_WINDOW;
@@ -336,9 +336,9 @@ __device__ __forceinline__ float slow_scan(Env& e, const KP& P, int n_mult, doub
 
 // SLOW: the instantiation carries the per-log scan path (full-feature per-tick kernels; the rollout kernels sit at their
 // 128-VGPR cap and do not -- cygym_rollout issues a fast_scan=False handle's ticks as single-tick launches)
-template <bool XE, bool WIDE, bool SLOW, class KP>
+template <bool XE, bool WIDE, bool SLOW, class KP, class IE, class FE>
 __device__ __forceinline__ void def_per_device(Env& e, const KP& P, int at, const int16_t* dev, int L, int app,
-                                               double& cost, bool& dirty, int32_t* ie, double* fe) {
+                                               double& cost, bool& dirty, IE ie, FE fe) {
   const double ds = P.c.def_scale;
   const int M = e.M;
   if (at == 1) { def_clean(e, P, dev, L, cost, ie, fe, nullptr); return; }

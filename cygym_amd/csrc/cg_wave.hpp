@@ -13,6 +13,40 @@ __device__ __forceinline__ void wsync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// The env's 16 + 3 scalars as lanes of ONE vector register (lane i = ienv word i, lanes 16..21 = the three fenv doubles as word
+// pairs: the layout of the prologue's gathered load): read with v_readlane where used, updated with v_writelane, written back by one
+// store.  As 22 SGPRs for the whole kernel they were read out behind the barrier and immediately spilled into another register's
+// lanes (two instructions per scalar before the first use, a restore per use).
+extern "C" __device__ int cg_writelane(int val, int lane, int old) __asm("llvm.amdgcn.writelane.i32");   // v_writelane_b32 (this toolchain's clang has no builtin for it)
+struct LaneI {
+  uint32_t& hv; int i;
+  __device__ __forceinline__ operator int32_t() const { return __builtin_amdgcn_readlane((int)hv, i); }
+  __device__ __forceinline__ void set(int32_t v) const { hv = (uint32_t)cg_writelane(__builtin_amdgcn_readfirstlane(v), i, (int)hv); }
+  __device__ __forceinline__ const LaneI& operator=(int32_t v) const { set(v); return *this; }
+  __device__ __forceinline__ const LaneI& operator+=(int32_t v) const { set((int32_t)*this + v); return *this; }
+  __device__ __forceinline__ const LaneI& operator|=(int32_t v) const { set((int32_t)*this | v); return *this; }
+  __device__ __forceinline__ const LaneI& operator&=(int32_t v) const { set((int32_t)*this & v); return *this; }
+};
+struct EnvI {
+  uint32_t& hv;
+  __device__ __forceinline__ LaneI operator[](int i) const { return LaneI{hv, i}; }
+};
+struct LaneD {
+  uint32_t& hv; int i;   // low word in lane i, high word in lane i + 1
+  __device__ __forceinline__ operator double() const { return __hiloint2double(__builtin_amdgcn_readlane((int)hv, i + 1), __builtin_amdgcn_readlane((int)hv, i)); }
+  __device__ __forceinline__ void set(double v) const {
+    hv = (uint32_t)cg_writelane(__builtin_amdgcn_readfirstlane(__double2loint(v)), i, (int)hv);
+    hv = (uint32_t)cg_writelane(__builtin_amdgcn_readfirstlane(__double2hiint(v)), i + 1, (int)hv);
+  }
+  __device__ __forceinline__ const LaneD& operator=(double v) const { set(v); return *this; }
+  __device__ __forceinline__ const LaneD& operator+=(double v) const { set((double)*this + v); return *this; }
+};
+struct EnvF {
+  uint32_t& hv;
+  __device__ __forceinline__ LaneD operator[](int i) const { return LaneD{hv, 16 + 2 * i}; }
+};
+template <bool LS> __device__ __forceinline__ auto scalars_i(uint32_t& hv, int32_t* a) { if constexpr (LS) return EnvI{hv}; else return a; }
+template <bool LS> __device__ __forceinline__ auto scalars_f(uint32_t& hv, double* a) { if constexpr (LS) return EnvF{hv}; else return a; }
 __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
 __device__ __forceinline__ int below(uint64_t m) {  // set bits of m below this lane
   return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
