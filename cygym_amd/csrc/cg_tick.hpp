@@ -209,6 +209,24 @@ __device__ __forceinline__ WaveAux env_setup(Env& e, uint8_t* smem, const KP& P,
   if (lists_global) { e.xmo = (uint64_t*)e.xk; e.xk = nullptr; e.xb = nullptr; e.devl = nullptr; }   // (the tick body points them at the env's global rows)
   e.xmi = e.xmo + MC;
   e.K = P.t.K;
+#ifndef CG_AFFINE_BLOB
+#define CG_AFFINE_BLOB 1
+#endif
+  if constexpr (CG_AFFINE_BLOB && !RT) {
+    // Compile-time device count: the blob's twelve section offsets (cygym_create: every section padded to 16 bytes) are all
+    // "o_dst + constant" or "+ k * padded column bytes" -- two run-time scalars instead of twelve kept (spilled, restored) for the
+    // whole kernel, and the constants fold into the instructions' offset fields.
+    const int A_M = (M + 15) & ~15, A_P = (2 * (M + 1) + 15) & ~15, A_F = (4 * M + 15) & ~15;
+    const int o_dst = P.t.o_dst, a_e = o_dst - A_P;   // a_e: padded bytes of one u16[E] column (o_ocol == A_P)
+    const uint8_t* sd = smem + o_dst;
+    e.optr = (const uint16_t*)smem; e.ocol = (const uint16_t*)(smem + A_P);
+    e.dst = sd; e.vul = sd + A_M; e.nap = sd + 2 * A_M;
+    e.iptr_l = (const uint16_t*)(sd + 3 * A_M);
+    e.osv = (const float*)(sd + 3 * A_M + A_P); e.ver = (const float*)(sd + 3 * A_M + A_P + A_F); e.ano = (const float*)(sd + 3 * A_M + A_P + 2 * A_F);   // valid when P.t.in_lds
+    const int o_icol = o_dst + 3 * A_M + A_P + 3 * A_F;
+    const uint8_t* mb = MAPS ? (const uint8_t*)smem : P.t.blob;   // MAPS: block / unblock picks no longer pay a global-memory hop per pass
+    e.icol_g = (const uint16_t*)(mb + o_icol); e.ieid_g = (const uint16_t*)(mb + o_icol + a_e); e.oeid_g = (const uint16_t*)(mb + o_icol + 2 * a_e);
+  } else {
   e.optr = (const uint16_t*)(smem + P.t.o_optr); e.ocol = (const uint16_t*)(smem + P.t.o_ocol);
   e.osv = (const float*)(smem + P.t.o_os); e.ver = (const float*)(smem + P.t.o_ver); e.ano = (const float*)(smem + P.t.o_ano);   // valid when P.t.in_lds
   e.dst = smem + P.t.o_dst; e.vul = smem + P.t.o_vul; e.nap = smem + P.t.o_nap;
@@ -217,6 +235,7 @@ __device__ __forceinline__ WaveAux env_setup(Env& e, uint8_t* smem, const KP& P,
     e.icol_g = (const uint16_t*)(smem + P.t.o_icol); e.ieid_g = (const uint16_t*)(smem + P.t.o_ieid); e.oeid_g = (const uint16_t*)(smem + P.t.o_oeid);
   } else {
     e.icol_g = (const uint16_t*)(P.t.blob + P.t.o_icol); e.ieid_g = (const uint16_t*)(P.t.blob + P.t.o_ieid); e.oeid_g = (const uint16_t*)(P.t.blob + P.t.o_oeid);
+  }
   }
   e.M = M; e.MC = MC; e.MS = MS; e.lane = lane; e.env = env;
   e.cbits = 32 - __builtin_clz((unsigned)(4 * ((MS / 4 + WAVE - 1) / WAVE)));

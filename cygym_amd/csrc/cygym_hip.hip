@@ -343,6 +343,12 @@ int cygym_create(const cygym_topology* topo, const cygym_config* cfg, int32_t n_
   t.o_icol = take((size_t)(E > 0 ? E : 1) * 2); t.o_ieid = take((size_t)(E > 0 ? E : 1) * 2);
   t.o_oeid = take((size_t)(E > 0 ? E : 1) * 2);
   h->o_maps_end = (int)off;
+  {  // env_setup (cg_tick.hpp) derives every section offset from o_dst at the compile-time sizes: hold the layout to that
+    const int A_M = (M + 15) & ~15, A_P = (2 * (M + 1) + 15) & ~15, A_F = (4 * M + 15) & ~15, a_e = t.o_dst - A_P;
+    if (t.o_optr != 0 || t.o_ocol != A_P || t.o_vul != t.o_dst + A_M || t.o_nap != t.o_dst + 2 * A_M || t.o_iptr != t.o_dst + 3 * A_M ||
+        t.o_os != t.o_iptr + A_P || t.o_ver != t.o_os + A_F || t.o_ano != t.o_ver + A_F || t.o_icol != t.o_ano + A_F ||
+        t.o_ieid != t.o_icol + a_e || t.o_oeid != t.o_ieid + a_e) { delete h; return fail(nullptr, CYGYM_EINVAL, "internal: blob layout%s", ""); }
+  }
   const int o_apl = take(topo->det_apl ? (size_t)CG_DET_APL_N * 8 : 0);   // global only: read by trained scans
   t.blob_bytes = (int)off;
   t.multi = 0;   // duplicate (u,v) out-entries? (env._blocked holds pairs, so duplicates share their state)
