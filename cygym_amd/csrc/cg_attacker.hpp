@@ -770,9 +770,15 @@ __device__ __forceinline__ void attacker_spread_ct(Env& e, const KP& P, const in
         const bool is_long = mine && (o1 - o0) > LONG_ROW;
         const int last = k < o1 ? k : o1 - 1;
         if (mine && !is_long) {
+          // a short row's entries = the clear bits of its blocked-word pair below the pick: one read of the pair, then one step per
+          // ENTRY (not per slot, and no blocked-bit read inside the loop)
+          const int w0 = o0 >> 5, wl = ((P.t.EW + 3) & ~3) - 1;
+          const uint64_t bits = ((uint64_t)e.blk[w0] | ((uint64_t)e.blk[w0 < wl ? w0 + 1 : w0] << 32)) >> (o0 & 31);
+          uint64_t z = ~bits & (~0ull >> (63 - (last - o0)));   // slots o0 .. last (rows of <= LONG_ROW slots)
           uint32_t idx = off;
-          for (int kk = o0; kk <= last; ++kk) {
-            if (e.blocked(kk)) continue;
+          while (z) {
+            const int kk = o0 + __builtin_ctzll(z);
+            z &= z - 1;
             if (idx >= lo) { e.ring[2 * (idx % CG_LOG_RING)] = (uint16_t)s; e.ring[2 * (idx % CG_LOG_RING) + 1] = e.ocol[kk]; }
             ++idx;
           }
