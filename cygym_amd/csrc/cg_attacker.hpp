@@ -729,6 +729,9 @@ __device__ __forceinline__ void attacker_spread_ct(Env& e, const KP& P, const in
 #pragma unroll
     for (int b = 0; b < MCT; ++b) {
       cnt[b] = 0;
+#ifdef CG_ABL_NO_CNT
+      continue;
+#endif
       if (b * WAVE >= n_src) continue;   // (uniform)
       const int o0 = (int)(row[b] & 0xFFFFu), o1 = (int)(row[b] >> 16), k = (int)(pkv[b] & 0xFFFFu);
       int n = 0;
@@ -751,7 +754,12 @@ __device__ __forceinline__ void attacker_spread_ct(Env& e, const KP& P, const in
     wsync();
     SUBSTAMP(12);
     // ring: only the last CG_LOG_RING entries (global order: source id, then row order) matter
+#ifdef CG_ABL_NO_RING
+    e.log_total += total_new;   // (timing ablation: the counts stay alive, the ring is not written)
+    if (false) {
+#else
     if (total_new > 0) {
+#endif
       const uint32_t base = (uint32_t)e.log_total;
       const uint32_t end = base + (uint32_t)total_new;
       const uint32_t lo = end > CG_LOG_RING ? end - CG_LOG_RING : 0;
@@ -769,7 +777,11 @@ __device__ __forceinline__ void attacker_spread_ct(Env& e, const KP& P, const in
         const bool mine = n > 0 && off + (uint32_t)n > lo;
         const bool is_long = mine && (o1 - o0) > LONG_ROW;
         const int last = k < o1 ? k : o1 - 1;
+#ifdef CG_ABL_RING_NOLANE
+        if (false) {
+#else
         if (mine && !is_long) {
+#endif
           // a short row's entries = the clear bits of its blocked-word pair below the pick: one read of the pair, then one step per
           // ENTRY (not per slot, and no blocked-bit read inside the loop)
           const int w0 = o0 >> 5, wl = ((P.t.EW + 3) & ~3) - 1;
@@ -783,20 +795,29 @@ __device__ __forceinline__ void attacker_spread_ct(Env& e, const KP& P, const in
             ++idx;
           }
         }
+#ifdef CG_ABL_RING_NOCOOP
+        uint64_t lm = 0;
+#else
         uint64_t lm = ballot(is_long);
+#endif
         while (lm) {
           const int ll = __builtin_ctzll(lm);
           lm &= lm - 1;
           const int ls = __builtin_amdgcn_readlane(s, ll);
-          uint32_t idx0 = (uint32_t)__builtin_amdgcn_readlane((int)off, ll);
+          // BACKWARDS from the pick, 64 slots per step, and only until the ring's window is covered: a hub that found no target
+          // logs its whole row (255 entries at 256 devices) of which at most the last CG_LOG_RING are kept -- walked forwards that
+          // was four steps per such hub, and the spread env with a hub among its last sources is the one an attacker launch waits for
+          const uint32_t endidx = (uint32_t)__builtin_amdgcn_readlane((int)off + n, ll);   // just past this source's entries
           const int lo0 = __builtin_amdgcn_readlane(o0, ll), llast = __builtin_amdgcn_readlane(last, ll);
-          for (int k0 = lo0; k0 <= llast; k0 += WAVE) {
-            const int kk = k0 + lane;
-            const bool p = kk <= llast && !e.blocked(kk);
+          uint32_t tail = 0;   // entries of the steps already taken (they follow this step's)
+          for (int k1 = llast; k1 >= lo0 && endidx - tail > lo; k1 -= WAVE) {
+            const int kk = k1 - (WAVE - 1) + lane;
+            const bool p = kk >= lo0 && !e.blocked(kk);
             const uint64_t m = ballot(p);
-            const uint32_t idx = idx0 + (uint32_t)below(m);
+            const uint32_t c = (uint32_t)__popcll(m);
+            const uint32_t idx = endidx - tail - c + (uint32_t)below(m);
             if (p && idx >= lo) { e.ring[2 * (idx % CG_LOG_RING)] = (uint16_t)ls; e.ring[2 * (idx % CG_LOG_RING) + 1] = e.ocol[kk]; }
-            idx0 += (uint32_t)__popcll(m);
+            tail += c;
           }
         }
         after = cbase;
