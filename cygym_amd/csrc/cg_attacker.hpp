@@ -269,7 +269,49 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
     for (int sweep = 0; sweep <= M + 1; ++sweep) {
       ++n_rounds;
       bool lost_any = false;    // some pick is not settled yet: another sweep is needed
+#ifndef CG_SPREAD_PRECHECK
+#define CG_SPREAD_PRECHECK 1
+#endif
+      // Sweeps >= 1 first ask, for ALL blocks with the loads of four blocks in flight together, which sources lost their pick
+      // (bit b of `need` <-> block b: at most 32 blocks); the block loop below then runs only for blocks that hold one.  A
+      // verification sweep used to walk every block through its four dependent round trips -- 14 blocks, ~40 k cycles at 2048
+      // devices -- to find the three or four sources that have to resume (profiles/r04_tail_hist_cfg5.txt).  A resumed source's
+      // take that reaches a LATER source's target is reported as a conflict by the take itself, so the next sweep re-checks.
+      uint32_t need = 0xFFFFFFFFu;
+      if (CG_SPREAD_PRECHECK && sweep > 0) {
+        need = 0u;
+        constexpr int PB = 4;
+#pragma nounroll
+        for (int bb = 0; bb * WAVE < n_src; bb += PB) {
+          int sj[PB], kj[PB], oj0[PB], oj1[PB];
+          uint32_t stj[PB];
+#pragma unroll
+          for (int j = 0; j < PB; ++j) { const int i = (bb + j) * WAVE + e.lane; sj[j] = slist[i < n_src ? i : 0]; }
+#pragma unroll
+          for (int j = 0; j < PB; ++j) { oj0[j] = e.optr[sj[j]]; oj1[j] = e.optr[sj[j] + 1]; stj[j] = e.dst[sj[j]]; kj[j] = (int)cur[sj[j]]; }
+          int vj[PB];
+#pragma unroll
+          for (int j = 0; j < PB; ++j) {
+            const bool full = (oj1[j] - oj0[j] > LONG_ROW) && (stj[j] & CG_D_FULLROW) && !(stj[j] & CG_D_DC);
+            const int kc = kj[j] < oj1[j] ? kj[j] : (oj1[j] > 0 ? oj1[j] - 1 : 0);
+            vj[j] = full ? (kj[j] - oj0[j]) + ((kj[j] - oj0[j]) >= sj[j] ? 1 : 0) : (int)e.ocol[kc];
+            if (vj[j] >= M) vj[j] = M - 1;
+          }
+          uint32_t tj[PB];
+#pragma unroll
+          for (int j = 0; j < PB; ++j) tj[j] = T[vj[j]];
+#pragma unroll
+          for (int j = 0; j < PB; ++j) {
+            const int i = (bb + j) * WAVE + e.lane;
+            const bool okv = (tj[j] & 1u) || ((tj[j] & 2u) && ((tj[j] >> 2) >= (uint32_t)(sj[j] + 1)));
+            const bool lost = i < n_src && kj[j] < oj1[j] && !(stj[j] & CG_D_DC) && !okv;
+            const bool xr = XE && COLD(xany) && i < n_src && x_isout(e, sj[j]);   // (rows with added edges: spread_x_round's business)
+            if (__any(lost && !xr)) need |= 1u << ((bb + j) & 31);
+          }
+        }
+      }
       for (int b0 = 0; b0 < n_src; b0 += WAVE) {
+        if (!((need >> ((b0 / WAVE) & 31)) & 1u)) continue;   // (uniform) nobody in this block has to resume
         const int i = b0 + e.lane;
         bool coop = false;
         int s = 0, o1 = 0, k0 = 0;
