@@ -346,7 +346,9 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
               cur[s] = (uint16_t)k;
               if (k < o1 && spread_take_c(T, v, s, low)) lost_any = true;
             } else {
+#ifndef CG_ABL_NO_COOP_ROWS
               coop = true;
+#endif
             }
 #ifdef CG_STAMPS
             if (sweep == 0) { dg_full += full ? 1 : 0; dg_coop += coop ? 1 : 0; } else dg_resc += 1;
