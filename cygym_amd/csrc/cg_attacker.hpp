@@ -331,23 +331,38 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
             rescan = !spread_ok(T, vc, s);
           }
           if (rescan && !xrow) {
-            if (shortrow || full) {
-              const int from = sweep == 0 ? o0 : k0 + 1;
+#ifndef CG_LONG_PREFIX
+#define CG_LONG_PREFIX 1
+#endif
+            // A long row that is not "full" (a hub's 47 slots at 2048 devices) first has its next four slots scanned by its own lane,
+            // with -- and by the same instructions as -- the short rows of the block; only if none of them is a pick does the rest
+            // of the row take a cooperative step.  (Those steps, four rows each and ~90 rows per exploit, were 40 us of a 165 us
+            // tick at 4096 x 2048: timing ablation, PERFLOG.md; the usual pick is among a hub's first neighbours.)
+            const int from = sweep == 0 ? o0 : k0 + 1;
+            const bool prefix = CG_LONG_PREFIX && CR > 1 && !shortrow && !full;
+            if (shortrow || full || prefix) {
+              const int lim1 = prefix ? (from + 4 < o1 ? from + 4 : o1) : o1;
               uint32_t low = 0;
               int k, v = 0;
-              if (shortrow) {
-                if constexpr (CR > 1) k = spread_scan_lane_st(e, T, s, dc, from, o1, v, low);
-                else { k = spread_scan_lane(e, T, s, dc, from, o1); if (k < o1) { v = e.ocol[k]; low = T[v] & 3u; } }
+              if (!full) {
+                if constexpr (CR > 1) k = spread_scan_lane_st(e, T, s, dc, from, lim1, v, low);
+                else { k = spread_scan_lane(e, T, s, dc, from, lim1); if (k < lim1) { v = e.ocol[k]; low = T[v] & 3u; } }
               }
               else {
                 k = spread_scan_full(e, T, cand, s, from, o0, o1);
                 if (k < o1) { v = (k - o0) + ((k - o0) >= s ? 1 : 0); low = T[v] & 3u; }
               }
-              cur[s] = (uint16_t)k;
-              if (k < o1 && spread_take_c(T, v, s, low)) lost_any = true;
+              if (prefix && k >= lim1 && lim1 < o1) {
+#ifndef CG_ABL_NO_COOP_ROWS
+                coop = true; k0 = lim1;   // the rest of the row, cooperatively, from here
+#endif
+              } else {
+                cur[s] = (uint16_t)k;
+                if (k < o1 && spread_take_c(T, v, s, low)) lost_any = true;
+              }
             } else {
 #ifndef CG_ABL_NO_COOP_ROWS
-              coop = true;
+              coop = true; k0 = from;
 #endif
             }
 #ifdef CG_STAMPS
@@ -370,8 +385,7 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
             nm &= nm - 1;   // (0 stays 0)
             rs[j] = __builtin_amdgcn_readlane(s, src_lane);
             ro1[j] = rhave[j] ? __builtin_amdgcn_readlane(o1, src_lane) : 0;
-            const int lk0 = __builtin_amdgcn_readlane(k0, src_lane);
-            rfrom[j] = sweep == 0 ? lk0 : lk0 + 1;
+            rfrom[j] = __builtin_amdgcn_readlane(k0, src_lane);   // (k0 of a cooperative lane: the slot its scan starts at)
             rdc[j] = __builtin_amdgcn_readlane((int)st, src_lane) & CG_D_DC;
           }
           // staged and branch-free: the loads of one stage (blocked word + neighbour, then its T word) are issued for
