@@ -457,6 +457,52 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
     // log entries of every source: unblocked out-entries up to and including its pick
     // ... and, in the same pass, the domain-controller attribution (:1163-1185): a DC source marks its pick
     int total_new = 0;
+#ifndef CG_COUNTS_STAGED
+#define CG_COUNTS_STAGED 1
+#endif
+    if constexpr (CG_COUNTS_STAGED && CR > 1) {
+      // four blocks of sources per step, each stage's loads in flight together (source id -> row bounds + pick + static byte ->
+      // the blocked-word pair of the prefix): three round trips per FOUR blocks where the loop below pays five per block; a prefix
+      // of more than 33 slots (a hub without a target) takes the rolled count, only when some lane of the step has one.  One
+      // wave sum per step.  (14 blocks per exploit at 2048 devices: 17 k cycles of a spread env's 119 k.)
+      constexpr int CB = 4;
+      const int wl = ((P.t.EW + 3) & ~3) - 1;
+#pragma nounroll
+      for (int bb = 0; bb * WAVE < n_src; bb += CB) {
+        int sj[CB], oj0[CB], oj1[CB], cj[CB];
+        uint32_t stj[CB];
+#pragma unroll
+        for (int j = 0; j < CB; ++j) { const int i = (bb + j) * WAVE + e.lane; sj[j] = slist[i < n_src ? i : 0]; }
+#pragma unroll
+        for (int j = 0; j < CB; ++j) { oj0[j] = e.optr[sj[j]]; oj1[j] = e.optr[sj[j] + 1]; cj[j] = (int)cur[sj[j]]; stj[j] = e.dst[sj[j]]; }
+        uint32_t blo[CB], bhi[CB];
+        int endj[CB];
+#pragma unroll
+        for (int j = 0; j < CB; ++j) {
+          endj[j] = cj[j] < oj1[j] ? cj[j] + 1 : oj1[j];
+          const int w0 = oj0[j] >> 5;
+          blo[j] = e.blk[w0]; bhi[j] = e.blk[w0 < wl ? w0 + 1 : w0];
+        }
+        int nsum = 0;
+#pragma unroll
+        for (int j = 0; j < CB; ++j) {
+          const int i = (bb + j) * WAVE + e.lane;
+          const bool valid = i < n_src && !(XE && COLD(xany) && x_isout(e, sj[j]));   // (rows with added edges: spread_x_counts below)
+          const int len = endj[j] - oj0[j];
+          const bool far = valid && len > 33;
+          int n = 0;
+          if (valid && !far) {
+            const uint64_t bits = ((uint64_t)blo[j] | ((uint64_t)bhi[j] << 32)) >> (oj0[j] & 31);
+            n = len - __popcll(len > 0 ? bits & (~0ull >> (64 - len)) : 0ull);
+          }
+          if (__any(far)) { if (far) n = len - (WIDE ? range_popc_wide(e.blk, oj0[j], endj[j]) : range_popc(e.blk, oj0[j], endj[j])); }
+          if (valid && (stj[j] & CG_D_DC) && cj[j] < oj1[j]) cby_or(e, e.ocol[cj[j]], ebit);
+          if (i < Mp) cntv[i] = (uint16_t)n;
+          nsum += n;
+        }
+        total_new += wave_sum(nsum);
+      }
+    } else {
     for (int b0 = 0; b0 < n_src; b0 += WAVE) {
       const int i = b0 + e.lane;
       int n = 0;
@@ -473,6 +519,7 @@ __device__ __forceinline__ void attacker_spread(Env& e, const KP& P, const int32
       }
       cntv[i < Mp ? i : 0] = (uint16_t)n;
       total_new += wave_sum(n);
+    }
     }
     wsync();
     if constexpr (XE) { if (COLD(xany)) { total_new += spread_x_counts(e, cur, slist, cntv, n_src, ebit); wsync(); } }
