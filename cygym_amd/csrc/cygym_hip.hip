@@ -182,6 +182,9 @@ static size_t wave_lds_bytes(const DevTopo& t, int max_devs) {
 // The in-CSR columns and slot maps (icol/ieid/oeid, ~2/3 of the blob) are read by block/unblock only (~9 % of
 // env-ticks): they stay in global memory (L2-resident); the staged prefix ends before them (o_icol), or already
 // before the float columns (o_os).
+#ifndef CG_RT_REG_CAP
+#define CG_RT_REG_CAP 20
+#endif
 static int choose_launch_with(cygym_handle* h, int max_devs, int* waves_out);
 static int choose_launch(cygym_handle* h, int max_devs) {
   // comp_by in LDS (as ever), or -- run-time sizes with M % 4 == 0 -- in global memory when that frees enough LDS for
@@ -235,7 +238,9 @@ static int choose_launch_with(cygym_handle* h, int max_devs, int* waves_out) {
       const bool ct = t.M == 64 || t.M == 256, ct_lean = ct && !full_feature(h);
       // (the full-feature per-tick kernels at a compile-time size need <= 102 VGPRs: 5 waves per SIMD;
       // tests/test_host_cpu.py holds them to that)
-      const int reg_cap = ct_lean ? ((wpb > 1 && wpb <= 8) ? 24 : 20) : (ct ? 20 : 16);
+      // (run-time sizes, per-tick kernels: <= 81 VGPRs since the topology blob is staged by LDS-DMA instead of through registers:
+      // five waves per SIMD; tests/test_host_cpu.py holds them to that)
+      const int reg_cap = ct_lean ? ((wpb > 1 && wpb <= 8) ? 24 : 20) : (ct ? 20 : CG_RT_REG_CAP);
       if (waves > reg_cap / wpb * wpb) waves = reg_cap / wpb * wpb;
       // ties: two 8-wave workgroups per CU beat one 16-wave workgroup (their phases interleave)
       const bool better = waves > best_waves || (waves == best_waves && floats == best_floats && wpb == 8);
