@@ -105,9 +105,27 @@ __device__ __forceinline__ int range_popc(const uint32_t* blk, int a, int b) {
 // (Rows longer than 9 words cannot occur where these are used: the WIDE kernel is only chosen for topologies whose
 // out- and in-rows hold at most 256 slots, choose_launch -- so there is no fallback loop, whose LDS addresses were the
 // kernel's last two spilled VGPRs.)
+#ifndef CG_POPC_WIDE_ARITH
+#define CG_POPC_WIDE_ARITH 1
+#endif
 __device__ __forceinline__ int range_popc_wide(const uint32_t* blk, int a, int b) {
   if (a >= b) return 0;
   const int w0 = a >> 5, w1 = (b - 1) >> 5;
+#if CG_POPC_WIDE_ARITH
+  // Nine clamped reads, nine popcount-accumulates, then arithmetic instead of per-word masks and selects: the last word was read
+  // (9 - words) times and counts once; the first word's bits below a and the last word's bits from b on are taken off.  (Half the
+  // vector instructions of the masked form -- and under four waves per SIMD a pool pick costs what it issues, not what it waits for.)
+  uint32_t x[CG_WIDE_W];
+#pragma unroll
+  for (int j = 0; j < CG_WIDE_W; ++j) { const int w = w0 + j; x[j] = blk[w <= w1 ? w : w1]; }
+  int n = 0;
+#pragma unroll
+  for (int j = 0; j < CG_WIDE_W; ++j) n += __popc(x[j]);
+  n -= (CG_WIDE_W - 1 - (w1 - w0)) * __popc(x[CG_WIDE_W - 1]);
+  n -= __popc(x[0] & ~(0xFFFFFFFFu << (a & 31)));
+  if (b & 31) n -= __popc(x[CG_WIDE_W - 1] & (0xFFFFFFFFu << (b & 31)));
+  return n;
+#else
   int n = 0;
 #pragma unroll
   for (int j = 0; j < CG_WIDE_W; ++j) {
@@ -118,6 +136,7 @@ __device__ __forceinline__ int range_popc_wide(const uint32_t* blk, int a, int b
     n += w <= w1 ? __popc(x) : 0;
   }
   return n;
+#endif
 }
 // slot of the r-th entry in [a, b) whose blocked bit == want (uniform); r must be in range
 __device__ __forceinline__ int range_select(const uint32_t* blk, int a, int b, bool want, int r) {
