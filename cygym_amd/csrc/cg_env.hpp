@@ -157,6 +157,23 @@ __device__ __forceinline__ int range_select(const uint32_t* blk, int a, int b, b
 __device__ __forceinline__ int range_select_wide(const uint32_t* blk, int a, int b, bool want, int r) {
   const int w0 = a >> 5, w1 = (b - 1) >> 5;
   const uint32_t inv = want ? 0u : 0xFFFFFFFFu;
+#if CG_POPC_WIDE_ARITH
+  // No masks at all: the candidates of the first word BELOW a are skipped by raising the rank by their number; what lies past b --
+  // the last word's upper bits, the clamped re-reads of that word -- comes after every candidate in range and is never reached
+  // (r is in range).  Five vector instructions per word instead of ten.
+  uint32_t x[CG_WIDE_W - 1];
+#pragma unroll
+  for (int j = 0; j < CG_WIDE_W - 1; ++j) { const int w = w0 + j; x[j] = blk[w <= w1 ? w : w1] ^ inv; }
+  const int rr = r + __popc(x[0] & ~(0xFFFFFFFFu << (a & 31)));
+  int cum = 0, wsel = 0, rbase = 0;
+#pragma unroll
+  for (int j = 0; j < CG_WIDE_W - 1; ++j) {
+    cum += __popc(x[j]);
+    if (cum <= rr) { wsel = j + 1; rbase = cum; }   // the candidate lies beyond word j
+  }
+  const uint32_t xs = blk[w0 + wsel] ^ inv;   // one more read for the word itself
+  return ((w0 + wsel) << 5) + nth_bit32_bisect(xs, rr - rbase);
+#else
   const uint32_t m_lo = 0xFFFFFFFFu << (a & 31), m_hi = (b & 31) ? 0xFFFFFFFFu >> (32 - (b & 31)) : 0xFFFFFFFFu;
   int cum = 0, wsel = 0, rbase = 0;
 #pragma unroll
@@ -172,6 +189,7 @@ __device__ __forceinline__ int range_select_wide(const uint32_t* blk, int a, int
   if (wsel == 0) xs &= m_lo;
   if (w0 + wsel == w1) xs &= m_hi;
   return ((w0 + wsel) << 5) + nth_bit32_bisect(xs, r - rbase);
+#endif
 }
 
 // multiplicity of every device in a list -> bytes in scr (as uint8 [Mp]); ids >= M ignored.
