@@ -139,14 +139,15 @@ struct PoolPtrs {
   const uint16_t *optr, *ocol;           // LDS
   const uint16_t *icol, *ieid, *oeid;    // global
 };
-template <bool WIDE>
+// NW: words a row's bits can span, known at compile time (9 at 256 devices, 3 at 64: cygym_create sends a topology with a longer
+// row -- duplicate edges -- to the run-time-size kernels), or 0: run-time sizes, the rolled per-lane loops (both forms in one kernel
+// cost it a wave per SIMD: 114 VGPRs).
+template <int NW>
 __device__ __forceinline__ Pick pool_pick(const PoolPtrs q, bool want, uint32_t u, int o0, int o1, int i0, int i1) {
   Pick p; p.slot = -1; p.j = -1; p.x = -1;
-  int nbo = WIDE ? range_popc_wide(q.blk, o0, o1) : range_popc(q.blk, o0, o1);
-#ifdef CG_SEQ_POOLS
-  if constexpr (WIDE) asm volatile("" : "+v"(nbo));   // the out-pool count is complete before the in-pool words are loaded
-#endif
-  const int nbi = WIDE ? range_popc_wide(q.bin, i0, i1) : range_popc(q.bin, i0, i1);
+  int nbo, nbi;
+  if constexpr (NW > 0) { nbo = range_popc_words<NW>(q.blk, o0, o1); nbi = range_popc_words<NW>(q.bin, i0, i1); }
+  else { nbo = range_popc(q.blk, o0, o1); nbi = range_popc(q.bin, i0, i1); }
   const int n_out = want ? nbo : (o1 - o0) - nbo;
   const int n_in = want ? nbi : (i1 - i0) - nbi;
   const int n = n_out + n_in;
@@ -154,8 +155,13 @@ __device__ __forceinline__ Pick pool_pick(const PoolPtrs q, bool want, uint32_t 
   const int r = (int)cg_index(u, (uint32_t)n);
   const bool from_out = r < n_out;
   int slot = -1, j = -1;
-  if (from_out) slot = WIDE ? range_select_wide(q.blk, o0, o1, want, r) : range_select(q.blk, o0, o1, want, r);
-  else          j = WIDE ? range_select_wide(q.bin, i0, i1, want, r - n_out) : range_select(q.bin, i0, i1, want, r - n_out);
+  if constexpr (NW > 0) {
+    if (from_out) slot = range_select_words<NW>(q.blk, o0, o1, want, r);
+    else          j = range_select_words<NW>(q.bin, i0, i1, want, r - n_out);
+  } else {
+    if (from_out) slot = range_select(q.blk, o0, o1, want, r);
+    else          j = range_select(q.bin, i0, i1, want, r - n_out);
+  }
   if (from_out) { p.slot = slot; p.j = q.oeid[slot]; p.x = q.ocol[slot]; }      // independent loads
   else          { p.j = j; p.slot = q.ieid[j]; p.x = q.icol[j]; }
   return p;
@@ -336,7 +342,7 @@ __device__ __forceinline__ float slow_scan(Env& e, const KP& P, int n_mult, doub
 
 // SLOW: the instantiation carries the per-log scan path (full-feature per-tick kernels; the rollout kernels sit at their
 // 128-VGPR cap and do not -- cygym_rollout issues a fast_scan=False handle's ticks as single-tick launches)
-template <bool XE, bool WIDE, bool SLOW, class KP, class IE, class FE>
+template <bool XE, bool WIDE, bool SLOW, int NW, class KP, class IE, class FE>
 __device__ __forceinline__ void def_per_device(Env& e, const KP& P, int at, const int16_t* dev, int L, int app,
                                                double& cost, bool& dirty, IE ie, FE fe) {
   const double ds = P.c.def_scale;
@@ -344,6 +350,9 @@ __device__ __forceinline__ void def_per_device(Env& e, const KP& P, int at, cons
   if (at == 1) { def_clean(e, P, dev, L, cost, ie, fe, nullptr); return; }
   if (at == 6 || at == 9) {  // sequential semantics: each pick changes the pools of BOTH endpoints
     __builtin_amdgcn_s_setprio(3);   // long path: see the spread
+    // (every per-lane address of this path is derived from the lane id HERE: hoisted to the prologue -- "list + 2 * lane",
+    // "scratch + 4 * lane" -- and kept live to this point they were spilled registers of the 80-VGPR kernels)
+    asm volatile("" : "+v"(e.lane));
     const uint32_t site = at == 6 ? CG_SITE_PICK_BLOCK : CG_SITE_PICK_UNBLOCK;
     const bool want = (at == 9);
     const bool simple = list_is_simple(e, dev, L);   // no device twice => occurrence number is always 0
@@ -405,7 +414,7 @@ __device__ __forceinline__ void def_per_device(Env& e, const KP& P, int at, cons
         if (mine) {
           uint32_t uu = u;
           if (!simple) { const int b = occ[d]; if (b > 0) uu = e.draw(site, d, b); }
-          pk = pool_pick<WIDE>(q, want, uu, o0, o1, i0, i1);
+          pk = pool_pick<NW>(q, want, uu, o0, o1, i0, i1);
           // key = epoch | (63 - lane): atomicMax keeps the newest pass and, within it, the smallest lane
           if (pk.slot >= 0) atomicMax(&fh[pk.x], epoch | (uint32_t)(63 - e.lane));
           if (!simple) atomicMax(&fh[d], epoch | (uint32_t)(63 - e.lane));   // a repeated device must wait for its first occurrence

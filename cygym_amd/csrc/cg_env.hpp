@@ -105,39 +105,26 @@ __device__ __forceinline__ int range_popc(const uint32_t* blk, int a, int b) {
 // (Rows longer than 9 words cannot occur where these are used: the WIDE kernel is only chosen for topologies whose
 // out- and in-rows hold at most 256 slots, choose_launch -- so there is no fallback loop, whose LDS addresses were the
 // kernel's last two spilled VGPRs.)
-#ifndef CG_POPC_WIDE_ARITH
-#define CG_POPC_WIDE_ARITH 1
-#endif
-__device__ __forceinline__ int range_popc_wide(const uint32_t* blk, int a, int b) {
+// W words read at once: 9 covers any row of <= 256 slots (256 devices), 3 any row of <= 64 slots (64 devices).
+// Nine (W) clamped reads, W popcount-accumulates, then arithmetic instead of per-word masks and selects: the last word was read
+// (W - words) times and counts once; the first word's bits below a and the last word's bits from b on are taken off.  (Half the
+// vector instructions of a masked form -- and under four waves per SIMD a pool pick costs what it issues, not what it waits for.)
+template <int W>
+__device__ __forceinline__ int range_popc_words(const uint32_t* blk, int a, int b) {
   if (a >= b) return 0;
   const int w0 = a >> 5, w1 = (b - 1) >> 5;
-#if CG_POPC_WIDE_ARITH
-  // Nine clamped reads, nine popcount-accumulates, then arithmetic instead of per-word masks and selects: the last word was read
-  // (9 - words) times and counts once; the first word's bits below a and the last word's bits from b on are taken off.  (Half the
-  // vector instructions of the masked form -- and under four waves per SIMD a pool pick costs what it issues, not what it waits for.)
-  uint32_t x[CG_WIDE_W];
+  uint32_t x[W];
 #pragma unroll
-  for (int j = 0; j < CG_WIDE_W; ++j) { const int w = w0 + j; x[j] = blk[w <= w1 ? w : w1]; }
+  for (int j = 0; j < W; ++j) { const int w = w0 + j; x[j] = blk[w <= w1 ? w : w1]; }
   int n = 0;
 #pragma unroll
-  for (int j = 0; j < CG_WIDE_W; ++j) n += __popc(x[j]);
-  n -= (CG_WIDE_W - 1 - (w1 - w0)) * __popc(x[CG_WIDE_W - 1]);
+  for (int j = 0; j < W; ++j) n += __popc(x[j]);
+  n -= (W - 1 - (w1 - w0)) * __popc(x[W - 1]);
   n -= __popc(x[0] & ~(0xFFFFFFFFu << (a & 31)));
-  if (b & 31) n -= __popc(x[CG_WIDE_W - 1] & (0xFFFFFFFFu << (b & 31)));
+  if (b & 31) n -= __popc(x[W - 1] & (0xFFFFFFFFu << (b & 31)));
   return n;
-#else
-  int n = 0;
-#pragma unroll
-  for (int j = 0; j < CG_WIDE_W; ++j) {
-    const int w = w0 + j;
-    uint32_t x = blk[w <= w1 ? w : w1];
-    if (j == 0) x &= 0xFFFFFFFFu << (a & 31);
-    if (w == w1 && ((b & 31) != 0)) x &= 0xFFFFFFFFu >> (32 - (b & 31));
-    n += w <= w1 ? __popc(x) : 0;
-  }
-  return n;
-#endif
 }
+__device__ __forceinline__ int range_popc_wide(const uint32_t* blk, int a, int b) { return range_popc_words<CG_WIDE_W>(blk, a, b); }
 // slot of the r-th entry in [a, b) whose blocked bit == want (uniform); r must be in range
 __device__ __forceinline__ int range_select(const uint32_t* blk, int a, int b, bool want, int r) {
   const int w0 = a >> 5, w1 = (b - 1) >> 5;
@@ -152,45 +139,28 @@ __device__ __forceinline__ int range_select(const uint32_t* blk, int a, int b, b
   return -1;
 }
 
-// range_select with up to nine words read at once (rows of <= 256 slots) and the in-word rank by bisection; per-lane
-// callers only (block / unblock pools), see range_popc_wide
-__device__ __forceinline__ int range_select_wide(const uint32_t* blk, int a, int b, bool want, int r) {
+// range_select with W words read at once and the in-word rank by bisection; per-lane callers (block / unblock pools).
+// No masks at all: the candidates of the first word BELOW a are skipped by raising the rank by their number; what lies past b --
+// the last word's upper bits, the clamped re-reads of that word -- comes after every candidate in range and is never reached
+// (r is in range).  Five vector instructions per word.
+template <int W>
+__device__ __forceinline__ int range_select_words(const uint32_t* blk, int a, int b, bool want, int r) {
   const int w0 = a >> 5, w1 = (b - 1) >> 5;
   const uint32_t inv = want ? 0u : 0xFFFFFFFFu;
-#if CG_POPC_WIDE_ARITH
-  // No masks at all: the candidates of the first word BELOW a are skipped by raising the rank by their number; what lies past b --
-  // the last word's upper bits, the clamped re-reads of that word -- comes after every candidate in range and is never reached
-  // (r is in range).  Five vector instructions per word instead of ten.
-  uint32_t x[CG_WIDE_W - 1];
+  uint32_t x[W > 1 ? W - 1 : 1];
 #pragma unroll
-  for (int j = 0; j < CG_WIDE_W - 1; ++j) { const int w = w0 + j; x[j] = blk[w <= w1 ? w : w1] ^ inv; }
+  for (int j = 0; j < W - 1; ++j) { const int w = w0 + j; x[j] = blk[w <= w1 ? w : w1] ^ inv; }
   const int rr = r + __popc(x[0] & ~(0xFFFFFFFFu << (a & 31)));
   int cum = 0, wsel = 0, rbase = 0;
 #pragma unroll
-  for (int j = 0; j < CG_WIDE_W - 1; ++j) {
+  for (int j = 0; j < W - 1; ++j) {
     cum += __popc(x[j]);
     if (cum <= rr) { wsel = j + 1; rbase = cum; }   // the candidate lies beyond word j
   }
   const uint32_t xs = blk[w0 + wsel] ^ inv;   // one more read for the word itself
   return ((w0 + wsel) << 5) + nth_bit32_bisect(xs, rr - rbase);
-#else
-  const uint32_t m_lo = 0xFFFFFFFFu << (a & 31), m_hi = (b & 31) ? 0xFFFFFFFFu >> (32 - (b & 31)) : 0xFFFFFFFFu;
-  int cum = 0, wsel = 0, rbase = 0;
-#pragma unroll
-  for (int j = 0; j < CG_WIDE_W; ++j) {   // which word holds rank r: nine independent reads, values die in their popcount
-    const int w = w0 + j;
-    uint32_t v = blk[w <= w1 ? w : w1] ^ inv;
-    if (j == 0) v &= m_lo;
-    if (w == w1) v &= m_hi;
-    cum += w <= w1 ? __popc(v) : 0;
-    if (cum <= r && w < w1) { wsel = j + 1; rbase = cum; }
-  }
-  uint32_t xs = blk[w0 + wsel] ^ inv;   // one more read for the word itself
-  if (wsel == 0) xs &= m_lo;
-  if (w0 + wsel == w1) xs &= m_hi;
-  return ((w0 + wsel) << 5) + nth_bit32_bisect(xs, r - rbase);
-#endif
 }
+__device__ __forceinline__ int range_select_wide(const uint32_t* blk, int a, int b, bool want, int r) { return range_select_words<CG_WIDE_W>(blk, a, b, want, r); }
 
 // multiplicity of every device in a list -> bytes in scr (as uint8 [Mp]); ids >= M ignored.
 __device__ __forceinline__ void list_counts(Env& e, const int16_t* dev, int L) {

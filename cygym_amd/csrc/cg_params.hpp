@@ -19,6 +19,7 @@ struct DevTopo {
   int blob_bytes, lds_bytes, in_lds, multi;
   int K, KW, x_bytes;   // extra-edge list: capacity, blocked-bit words, bytes of its per-wave LDS section
   int cby_global;       // run-time sizes with M % 4 == 0: the comp_by plane stays in global memory (3 planes staged, Env::cby_g)
+  int ct;               // 64 or 256 devices AND no row longer than the device count: the compile-time-size kernels apply (else the run-time ones)
   int lists_global;     // ... and so do the tick's device list, the extra-edge list and the in-row bounds (choose_launch: where that buys a resident wave)
   const double* apl;    // [CG_DET_APL_N] leaf-term table of the trained detector (global; tail of the blob), or nullptr
   // global views (host-side convenience; kernels outside the tick use them)

@@ -113,8 +113,8 @@ static const void* kernel_for(int wpb) {
 template <bool FUSED, bool XE, bool WIDE>
 static const void* kernel_for_m(const cygym_handle* h) {
   const int wpb = FUSED ? h->wpb_fused : h->wpb;
-  if (h->t.M == 256) return kernel_for<256, FUSED, XE, WIDE>(wpb);
-  if (h->t.M == 64) return kernel_for<64, FUSED, XE, false>(wpb);   // rows of <= 3 words: nothing to gain (measured: -9 %)
+  if (h->t.ct && h->t.M == 256) return kernel_for<256, FUSED, XE, WIDE>(wpb);
+  if (h->t.ct && h->t.M == 64) return kernel_for<64, FUSED, XE, false>(wpb);   // rows of <= 3 words: nothing to gain (measured: -9 %)
   return kernel_for<0, FUSED, XE, false>(wpb);   // run-time M: the wide variant would spill
 }
 // XE: the kernel that follows the edges evolve_network adds (max_extra_edges > 0).  With no extra-edge list
@@ -172,11 +172,11 @@ static int x_section_bytes(const DevTopo& t, bool lists_global) {
   return (int)align_up((lists_global ? 0 : (size_t)4 * (t.K + ((t.KW + 1) & ~1))) + (size_t)16 * t.MC, 16);
 }
 static size_t wave_lds_bytes(const DevTopo& t, int max_devs) {
-  const bool rt = t.M != 64 && t.M != 256;   // run-time size: 4 bytes of scratch per device (16-bit T table), else 6 (env_setup)
+  const bool rt = !t.ct;   // run-time size: 4 bytes of scratch per device (16-bit T table), else 6 (env_setup)
   size_t w = align_up((size_t)(t.cby_global ? 3 : 4) * ((t.M + 3) & ~3), 16) + (size_t)t.Mp * (rt ? 4 : 6) + (size_t)((t.EW + 3) & ~3) * 4 * 2 + CG_LOG_RING * 4 +
              (size_t)((t.Mp / 32 + 2) & ~1) * 4 + (size_t)t.MC * 8 + (size_t)t.Mp * 2 +
              (t.lists_global ? 0 : align_up((size_t)max_devs * 2, 16)) + (size_t)x_section_bytes(t, t.lists_global) + 128 /* scalar parking of the fused kernel */ +
-             (t.M == 64 ? CG_OBS_STAGE_BYTES / 2 : 0) /* the observation's LDS stage at 64 devices (write_obs_staged) */;
+             (t.ct && t.M == 64 ? CG_OBS_STAGE_BYTES / 2 : 0) /* the observation's LDS stage at 64 devices (write_obs_staged) */;
   return align_up(w, 16);
 }
 // The in-CSR columns and slot maps (icol/ieid/oeid, ~2/3 of the blob) are read by block/unblock only (~9 % of
@@ -193,7 +193,7 @@ static int choose_launch(cygym_handle* h, int max_devs) {
   int w_lds = 0, w_glob = 0;
   t.cby_global = 0; t.lists_global = 0;
   const int rc = choose_launch_with(h, max_devs, &w_lds);
-  const bool can = t.M != 64 && t.M != 256 && (t.M & 3) == 0 && !getenv("CYGYM_CBY_LDS");
+  const bool can = !t.ct && (t.M & 3) == 0 && !getenv("CYGYM_CBY_LDS");
   if (can) {
     t.cby_global = 1;
     if (choose_launch_with(h, max_devs, &w_glob) == 0 && (rc != 0 || w_glob > w_lds || getenv("CYGYM_CBY_GLOBAL"))) {   // (env: test aid)
@@ -226,7 +226,7 @@ static int choose_launch_with(cygym_handle* h, int max_devs, int* waves_out) {
     static const int shapes[] = {16, 12, 8, 6, 5, 4, 3, 2, 1};
     for (int wpb : shapes) {
       if (forced && wpb != forced) continue;
-      if ((wpb & (wpb - 1)) != 0 && (t.M == 64 || t.M == 256)) continue;   // the compile-time sizes come in powers of two only
+      if ((wpb & (wpb - 1)) != 0 && t.ct) continue;   // the compile-time sizes come in powers of two only
       const size_t per_wg = shared + wave * wpb;
       if (per_wg > lds_cap) continue;
       int waves = (int)(lds_cap / per_wg) * wpb;
@@ -235,7 +235,7 @@ static int choose_launch_with(cygym_handle* h, int max_devs, int* waves_out) {
       // compile-time size is built for 6 waves per SIMD in workgroups of 2-8 waves and 5 otherwise, everything else
       // for 4 (launch bounds of step_kernel).  Without this a 16-wave shape that LDS would hold twice won over three
       // 8-wave workgroups although only one of the two ever runs (16384 x 256: -11 %).
-      const bool ct = t.M == 64 || t.M == 256, ct_lean = ct && !full_feature(h);
+      const bool ct = t.ct != 0, ct_lean = ct && !full_feature(h);
       // (the full-feature per-tick kernels at a compile-time size need <= 102 VGPRs: 5 waves per SIMD;
       // tests/test_host_cpu.py holds them to that)
       // (run-time sizes, per-tick kernels: <= 81 VGPRs since the topology blob is staged by LDS-DMA instead of through registers:
@@ -255,7 +255,7 @@ static int choose_launch_with(cygym_handle* h, int max_devs, int* waves_out) {
   // The rollout kernels are built for 4 waves per SIMD whatever the size: 16 resident waves per CU at most, and one
   // 16-wave workgroup measured 4 % faster than two of 8 (16384 x 256).  Otherwise they share the per-tick shape.
   h->wpb_fused = best;
-  if (!forced && (t.M == 64 || t.M == 256) && best < 16 && shared + wave * 16 <= lds_cap) h->wpb_fused = 16;
+  if (!forced && t.ct && best < 16 && shared + wave * 16 <= lds_cap) h->wpb_fused = 16;
   t.lds_bytes = (int)shared; t.in_lds = best_floats;   // in_lds: the float columns are staged too
   h->max_devs = max_devs;
   // Few envs per CU (<= 16: every env has its own resident wave and a launch lasts as long as its slowest env, which
@@ -263,7 +263,7 @@ static int choose_launch_with(cygym_handle* h, int max_devs, int* waves_out) {
   // slot maps in LDS as well, so a speculation pass no longer waits on global memory.  Compile-time size 256, lean only.
   h->wide = false;
   // (its nine-word pool reads cover rows of at most 256 slots: max_row is checked here, there is no fallback in the kernel)
-  if (h->few_waves && t.M == 256 && !full_feature(h) && !forced && h->max_row <= 256 && (size_t)h->o_maps_end + (wave + CG_OBS_STAGE_BYTES) * 16 <= lds_cap) {
+  if (h->few_waves && t.ct && t.M == 256 && !full_feature(h) && !forced && h->max_row <= 256 && (size_t)h->o_maps_end + (wave + CG_OBS_STAGE_BYTES) * 16 <= lds_cap) {
     h->wide = true;
     h->wave_lds = (int)wave + CG_OBS_STAGE_BYTES;   // + the observation's LDS stage (write_obs_staged)
     h->wpb = 16; h->wpb_fused = 16; h->shared_lds = h->o_maps_end;
@@ -367,6 +367,9 @@ int cygym_create(const cygym_topology* topo, const cygym_config* cfg, int32_t n_
     if (lo > h->max_row) h->max_row = lo;
     if (li > h->max_row) h->max_row = li;
   }
+  // A compile-time size whose longest row exceeds the device count (duplicate edges) runs on the run-time-size kernels: the
+  // compile-time ones count and select a row's bits in a fixed number of words (pool_pick<NW>, cg_defender.hpp).
+  t.ct = ((M == 64 && h->max_row <= 64) || (M == 256 && h->max_row <= 256)) ? 1 : 0;
   if (choose_launch(h, M > 8 ? M / 8 : 1) != 0) { delete h; return fail(nullptr, CYGYM_EUNSUPPORTED, "topology does not fit in LDS%s", ""); }
   uint8_t* host = (uint8_t*)calloc(1, off);
   if (!host) { delete h; return fail(nullptr, CYGYM_EINVAL, "out of host memory%s", ""); }

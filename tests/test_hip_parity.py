@@ -355,6 +355,57 @@ def test_differential_fuzz_sample(monkeypatch):
     fuzz.main()   # exits non-zero (SystemExit) on the first mismatch
 
 
+@pytest.mark.parametrize("M", [64, 256])
+def test_long_rows_at_a_compile_time_size_run_on_the_run_time_kernels(M):
+    """The 64- and 256-device kernels count and select a row's blocked bits in a fixed number of words (pool_pick<NW>,
+    cg_defender.hpp): a topology with duplicate edges whose longest row exceeds the device count is routed to the run-time-size
+    kernels by cygym_create (DevTopo::ct).  One device's out-entries are repeated until its row holds more than M slots; block /
+    unblock lists aimed at it and at its neighbours, and every other action of the script, must match the oracle."""
+    import dataclasses
+    from oracle import driver as od
+    topo, init, ck = make_topology(M, 4 if M == 64 else 1, seed=5, n_active=(M * 9) // 10, max_extra=0)
+    op, oc = np.asarray(topo.out_ptr), np.asarray(topo.out_col)
+    hub = int(np.argmax(np.diff(op)))
+    row = oc[op[hub]:op[hub + 1]]
+    reps = M // len(row) + 2                      # the row becomes reps * len(row) > M slots
+    rows = [oc[op[u]:op[u + 1]] if u != hub else np.sort(np.tile(row, reps)) for u in range(M)]
+    out_ptr = np.zeros(M + 1, np.int32); out_ptr[1:] = np.cumsum([len(r) for r in rows])
+    out_col = np.concatenate(rows).astype(np.int32)
+    assert out_ptr[hub + 1] - out_ptr[hub] > M
+    in_ptr, in_col, in_eid = abi.build_in_csr(M, out_ptr, out_col)
+    topo = dataclasses.replace(topo, out_ptr=out_ptr, out_col=out_col, in_ptr=in_ptr, in_col=in_col, in_eid=in_eid).normalised()
+    EW = (len(out_col) + 31) // 32
+    init = dict(init)
+    init["blocked"] = np.zeros((1, EW), np.uint32); init["blocked_in"] = np.zeros((1, EW), np.uint32)
+    cfg = abi.EnvConfig(seed=5, env_id_base=40, **ck)
+    N, L, T = 48, max(1, M // 8), 80
+    env = _env(topo, cfg, N, init, max_groups=1, max_devs=L)
+    ob = od.OracleBatch(topo, cfg, N)
+    ob.load_state(init)
+    nb = np.unique(np.concatenate([[hub], row]))[:L]
+    for t in range(T):
+        env.gen_actions(t)
+        act = gen_actions_numpy(cfg.seed, cfg.env_id_base, N, M, topo.X, t, L)
+        if t % 2 == 0:   # defender ticks: every third env blocks / unblocks around the long row
+            for e_ in range(0, N, 3):
+                if act["mode"][e_] != S.MODE_DEFENDER:
+                    continue
+                act["atype"][e_, 0] = 6 if (t // 2 + e_) % 3 else 9
+                act["dev_cnt"][e_, 0] = len(nb)
+                act["dev_idx"][e_, :len(nb)] = nb
+            env.set_actions_numpy(act)
+        obs, raw, shaped, done = env.step()
+        o_obs, o_raw, o_shaped, o_done = ob.step(act)
+        np.testing.assert_allclose(raw.cpu().numpy(), o_raw, rtol=0, atol=1e-9, err_msg=f"raw t={t}")
+        if t % 4 == 0 or t == T - 1:
+            got = env.state_numpy()
+            got["ienv"] = got["ienv"].copy(); got["ienv"][:, S.I_FLAGS] &= ~0x80
+            bad = gio.compare_state(got, ob.state, f"M={M} t={t}")
+            assert not bad, "\n".join(bad[:8])
+    assert (ob.state["blocked"] != 0).any()
+    env.close()
+
+
 def test_lists_read_from_global_memory(monkeypatch):
     """Run-time sizes where it buys a resident wave (4096 x 2048 with its extra-edge list: 5 -> 6 per CU) leave the tick's
     device list, the extra-edge list and the in-row bounds in global memory (choose_launch, cygym_hip.hip).  No network that
