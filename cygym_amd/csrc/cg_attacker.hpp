@@ -880,8 +880,10 @@ __device__ __forceinline__ void attacker_spread_ct(Env& e, const KP& P, const in
         const uint32_t cbase = after - (uint32_t)blk_total;
         const uint32_t off = cbase + (uint32_t)(incl - n);
         const bool mine = n > 0 && off + (uint32_t)n > lo;
-        const bool is_long = mine && (o1 - o0) > LONG_ROW;
         const int last = k < o1 ? k : o1 - 1;
+        // (cooperative only for sources with many entries or a pick far into the row: a hub whose pick is among its first neighbours --
+        // the usual case -- goes with the short rows, one step per ENTRY on the bits of its blocked-word pair)
+        const bool is_long = mine && (last - o0 >= 33 || n > LONG_ROW);
 #ifdef CG_ABL_RING_NOLANE
         if (false) {
 #else
