@@ -95,16 +95,14 @@ __device__ __forceinline__ int range_popc(const uint32_t* blk, int a, int b) {
   }
   return n;
 }
-// The same count with up to nine words read at once (any row of <= 256 slots): nine independent reads, one LDS
-// latency.  For per-lane callers whose rows differ a lot in length (block / unblock pools: a full row next to a
-// two-entry row) the rolled loop above makes every lane wait out the longest row, one word per trip.  It costs
-// registers, so only the per-tick kernel -- whose launch lasts as long as its slowest env -- uses it.
+// The same count with a fixed number of words read at once: W independent reads, one LDS latency.  For per-lane callers whose
+// rows differ a lot in length (block / unblock pools: a full row next to a two-entry row) the rolled loop above makes every lane
+// wait out the longest row, one word per trip.  Every kernel of a compile-time size uses these forms (pool_pick<NW>); rows longer
+// than W words cannot occur there: cygym_create sends such a topology to the run-time-size kernels (DevTopo::ct), so there is no
+// fallback loop.
 #ifndef CG_WIDE_W
 #define CG_WIDE_W 9
 #endif
-// (Rows longer than 9 words cannot occur where these are used: the WIDE kernel is only chosen for topologies whose
-// out- and in-rows hold at most 256 slots, choose_launch -- so there is no fallback loop, whose LDS addresses were the
-// kernel's last two spilled VGPRs.)
 // W words read at once: 9 covers any row of <= 256 slots (256 devices), 3 any row of <= 64 slots (64 devices).
 // Nine (W) clamped reads, W popcount-accumulates, then arithmetic instead of per-word masks and selects: the last word was read
 // (W - words) times and counts once; the first word's bits below a and the last word's bits from b on are taken off.  (Half the

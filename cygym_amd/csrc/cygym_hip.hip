@@ -119,9 +119,9 @@ static const void* kernel_for_m(const cygym_handle* h) {
 }
 // XE: the kernel that follows the edges evolve_network adds (max_extra_edges > 0).  With no extra-edge list
 // the lean instantiation runs: none of that code is in it.
-// WIDE (lean per-tick kernel only): the block / unblock pools count their bits nine words at a time.  That costs
-// registers (108 VGPRs: 4 waves per SIMD), so it is used when the batch cannot fill more than that anyway
-// (envs <= 16 per CU) -- there a launch lasts as long as its slowest env, and block / unblock is that env.
+// WIDE (lean per-tick kernel, 256 devices, envs <= 16 per CU: one 16-wave workgroup per CU): the in-CSR columns and slot maps
+// ride in LDS as well, the observation leaves through an LDS stage as full 1 KB stores, the spread's log counts read nine words
+// at once.  (Its nine-word pool picks are every compile-time-size kernel's since they are arithmetic: cg_env.hpp.)
 static bool full_feature(const cygym_handle* h) { return h->t.K > 0 || h->b.forest || h->b.hist || h->b.anomaly; }
 static const void* pick_kernel(const cygym_handle* h, bool fused, int full = -1) {
   const bool xe = full < 0 ? full_feature(h) : full != 0;

@@ -136,8 +136,7 @@ def test_philox_known_answers():
 
 def test_tick_kernels_do_not_spill():
     """A select between addresses of struct members once pinned the whole per-wave state in scratch and cost
-    40 % throughput: every instantiation of the tick kernel stays free of spilled VGPRs (only the WIDE per-tick kernel
-    trades a handful for its nine-word reads)."""
+    40 % throughput: every instantiation of the tick kernel stays free of spilled VGPRs."""
     import json
     from cygym_amd import build as B
     B.build()
@@ -153,8 +152,8 @@ def test_tick_kernels_do_not_spill():
         assert m, name
         mt, fused, xe, wide = int(m.group(1)), m.group(2) == "1", m.group(3) == "1", m.group(4) == "1"
         seen.add((fused, xe))
-        if wide:          # held at 128 VGPRs (4 waves per SIMD = the whole 4096-env batch in one residency round) with its
-            # nine-words-at-once pool counts and selects -- and, like every other variant, without a single spilled VGPR
+        if wide:          # at most 128 VGPRs (4 waves per SIMD = the whole 4096-env batch in one residency round; 80 since the pool
+            # counts and selects are arithmetic) -- and, like every other variant, without a single spilled VGPR
             # (round 2 tolerated 7 here, next to ~130 SGPRs in VGPR lanes: the pattern CG_LB records as miscompiled once)
             assert r["vgprs"] <= 128 and r.get("vgpr_spill", 0) == 0 and r["scratch"] == 0, (name, r)
             continue
