@@ -152,10 +152,10 @@ def test_tick_kernels_do_not_spill():
         assert m, name
         mt, fused, xe, wide = int(m.group(1)), m.group(2) == "1", m.group(3) == "1", m.group(4) == "1"
         seen.add((fused, xe))
-        if wide:          # at most 128 VGPRs (4 waves per SIMD = the whole 4096-env batch in one residency round; 80 since the pool
+        if wide:          # held under 96 VGPRs (it needs 4 waves per SIMD = the whole 4096-env batch in one residency round; 80 since the pool
             # counts and selects are arithmetic) -- and, like every other variant, without a single spilled VGPR
             # (round 2 tolerated 7 here, next to ~130 SGPRs in VGPR lanes: the pattern CG_LB records as miscompiled once)
-            assert r["vgprs"] <= 128 and r.get("vgpr_spill", 0) == 0 and r["scratch"] == 0, (name, r)
+            assert r["vgprs"] <= 96 and r.get("vgpr_spill", 0) == 0 and r["scratch"] == 0, (name, r)
             continue
         # every instantiation -- lean and full-feature, per-tick and rollout, every workgroup shape: NO spilled
         # VGPRs.  (History: spills in the rollout kernel once meant flat addressing through generic pointers, -25 %;
